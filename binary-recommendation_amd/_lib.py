@@ -1,0 +1,87 @@
+"""ctypes binding of libbinrec_hip.so, generated from include/binrec.h.
+
+The prototypes are parsed out of the header so the Python side can never drift from the
+C-ABI.  There is NO CPU fallback: if the library is missing or fails to load, importing the
+ops raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "binrec.h")
+LIB_PATH = os.path.join(HERE, "libbinrec_hip.so")
+
+_SCALARS = {
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+    "uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32, "float": ctypes.c_float,
+    "double": ctypes.c_double, "brStream": ctypes.c_void_p,
+}
+
+
+def parse_header(path: str = HEADER) -> dict[str, tuple[object, list[object], list[str]]]:
+    """-> {name: (restype, [argtypes], [argnames])} for every function the header declares."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = {}
+    for m in re.finditer(r"\b(const\s+char\s*\*|int64_t|int)\s+(br[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = ctypes.c_char_p if "char" in ret else _SCALARS[ret.strip()]
+        argtypes, argnames = [], []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                nm = re.search(r"([A-Za-z_][A-Za-z0-9_]*)$", a).group(1)
+                ty = a[: -len(nm)].strip()
+                if "*" in ty:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_SCALARS[ty.replace("const", "").strip()])
+                argnames.append(nm)
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+class BinrecError(RuntimeError):
+    pass
+
+
+_lib = None
+_protos = None
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BinrecError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (restype, argtypes, _names) in _protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BinrecError(f"libbinrec_hip.so does not export {name} declared in include/binrec.h") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def prototypes():
+    load()
+    return _protos
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().brGetLastError()
+        raise BinrecError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

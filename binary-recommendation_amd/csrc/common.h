@@ -1,0 +1,80 @@
+// Shared host/device helpers for libbinrec_hip.so (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/binrec.h"
+
+namespace br {
+
+void set_error(const char* fmt, ...);
+
+#define BR_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      br::set_error(__VA_ARGS__);          \
+      return BR_ERR_ARG;                   \
+    }                                      \
+  } while (0)
+
+#define BR_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ != hipSuccess) {                                                     \
+      br::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+      return BR_ERR_HIP;                                                        \
+    }                                                                           \
+  } while (0)
+
+constexpr int kWave = 64;
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// id load: int32 or int64 storage, identity when ids == nullptr.
+template <typename IdT>
+__device__ __forceinline__ int64_t load_id(const IdT* ids, int64_t b) {
+  return ids ? (int64_t)ids[b] : b;
+}
+
+// wave-wide and sub-group sums via DPP/shuffles (64-lane wavefront).
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WIDTH);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_stable(float x) {
+  float e = __expf(-fabsf(x));
+  // expf via v_exp_f32 (1 ulp-ish); division kept IEEE for the 1e-5 budget
+  float r = 1.0f / (1.0f + e);
+  return x >= 0.f ? r : e * r;
+}
+
+// accurate forms used where the loss / gradient tolerance is tight
+__device__ __forceinline__ float sigmoidf_acc(float x) {
+  float e = expf(-fabsf(x));
+  float r = 1.0f / (1.0f + e);
+  return x >= 0.f ? r : e * r;
+}
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+  if (act == BR_ACT_SIGMOID) return sigmoidf_acc(z);
+  if (act == BR_ACT_RELU) return fmaxf(z, 0.f);
+  return z;
+}
+// derivative expressed through the activation OUTPUT a
+__device__ __forceinline__ float act_grad_from_out(float a, int act) {
+  if (act == BR_ACT_SIGMOID) return a * (1.f - a);
+  if (act == BR_ACT_RELU) return a > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+}  // namespace br

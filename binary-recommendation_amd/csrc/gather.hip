@@ -1,0 +1,367 @@
+// G1/G2 embedding gather, M1 row dot, NeuMF embed block, BPR fused step.
+// HBM-bound kernels: one row group (16 lanes x 16 B at dim 64) per embedding row, all the
+// lookups of one (user,item[,neg]) tuple issued before any store so each lane keeps 3-4
+// independent 16-B loads in flight; 4096+ workgroups at batch 65 536 to fill 256 CUs.
+#include "common.h"
+#include "rows.h"
+
+namespace br {
+
+struct GatherArgs {
+  const float* tables[4];
+  const void* ids[4];
+  float* outs[4];
+  int64_t rows[4];
+};
+
+template <typename IdT, int VEC, int NT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a, int dim, int chunks,
+                                                           int lpr_log2, int64_t batch, int* err) {
+  using V = typename VecT<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (b >= batch) return;
+  int64_t id[NT];
+  bool ok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    id[t] = load_id(reinterpret_cast<const IdT*>(a.ids[t]), b);
+    ok[t] = (uint64_t)id[t] < (uint64_t)a.rows[t];
+    if (!ok[t] && err && lir == 0) *err = 1;
+  }
+  for (int c = lir; c < chunks; c += lpr) {
+    V v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      v[t] = ok[t] ? vload<VEC>(a.tables[t] + id[t] * dim + c * VEC) : vzero<VEC>();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) vstore<VEC>(a.outs[t] + b * dim + c * VEC, v[t]);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       float* __restrict__ out, int dim, int chunks,
+                                                       int lpr_log2, int64_t batch) {
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  const bool live = b < batch;
+  if (!live) b = batch - 1;  // keep the whole wave in the shuffles
+  float s = 0.f;
+  for (int c = lir; c < chunks; c += lpr)
+    s += vdot(vload<VEC>(A + b * dim + c * VEC), vload<VEC>(Bm + b * dim + c * VEC));
+  s = rowgroup_sum(s, lpr);
+  if (live && lir == 0) out[b] = s;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void row_dot_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                           const float* __restrict__ dout, float* __restrict__ dA,
+                                                           float* __restrict__ dB, int dim, int chunks,
+                                                           int lpr_log2, int64_t batch) {
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (b >= batch) return;
+  const float g = dout[b];
+  for (int c = lir; c < chunks; c += lpr) {
+    auto va = vload<VEC>(A + b * dim + c * VEC);
+    auto vb = vload<VEC>(Bm + b * dim + c * VEC);
+    vstore<VEC>(dA + b * dim + c * VEC, vmul(vb, g));
+    vstore<VEC>(dB + b * dim + c * VEC, vmul(va, g));
+  }
+}
+
+// ---- NeuMF embed block ---------------------------------------------------------------------
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void neumf_embed_fwd_kernel(
+    const float* __restrict__ user_mlp, const float* __restrict__ item_mlp,
+    const float* __restrict__ user_mf, const float* __restrict__ item_mf, int64_t user_rows,
+    int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items, int dim,
+    int chunks, int lpr_log2, int64_t batch, int item_first, float* __restrict__ x0,
+    float* __restrict__ dot, int* err) {
+  using V = typename VecT<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  const bool live = b < batch;
+  if (!live) b = batch - 1;
+  const int64_t u = load_id(users, b), i = load_id(items, b);
+  const bool uok = (uint64_t)u < (uint64_t)user_rows, iok = (uint64_t)i < (uint64_t)item_rows;
+  if ((!uok || !iok) && err && lir == 0) *err = 1;
+  float* xrow = x0 + b * (2 * (int64_t)dim);
+  const int uoff = item_first ? dim : 0, ioff = item_first ? 0 : dim;
+  float s = 0.f;
+  for (int c = lir; c < chunks; c += lpr) {
+    V um = uok ? vload<VEC>(user_mlp + u * dim + c * VEC) : vzero<VEC>();
+    V im = iok ? vload<VEC>(item_mlp + i * dim + c * VEC) : vzero<VEC>();
+    V uf = uok ? vload<VEC>(user_mf + u * dim + c * VEC) : vzero<VEC>();
+    V vf = iok ? vload<VEC>(item_mf + i * dim + c * VEC) : vzero<VEC>();
+    if (live) {
+      vstore<VEC>(xrow + uoff + c * VEC, um);
+      vstore<VEC>(xrow + ioff + c * VEC, im);
+    }
+    s += vdot(uf, vf);
+  }
+  s = rowgroup_sum(s, lpr);
+  if (live && lir == 0) dot[b] = s;
+}
+
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void neumf_embed_bwd_kernel(
+    const float* __restrict__ user_mf, const float* __restrict__ item_mf, int64_t user_rows,
+    int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items, int dim,
+    int chunks, int lpr_log2, int64_t batch, int item_first, const float* __restrict__ dx0,
+    const float* __restrict__ ddot, float* __restrict__ g_user_mlp, float* __restrict__ g_item_mlp,
+    float* __restrict__ g_user_mf, float* __restrict__ g_item_mf) {
+  using V = typename VecT<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (b >= batch) return;
+  const int64_t u = load_id(users, b), i = load_id(items, b);
+  const bool uok = (uint64_t)u < (uint64_t)user_rows, iok = (uint64_t)i < (uint64_t)item_rows;
+  const float g = ddot[b];
+  const int uoff = item_first ? dim : 0, ioff = item_first ? 0 : dim;
+  for (int c = lir; c < chunks; c += lpr) {
+    V uf = uok ? vload<VEC>(user_mf + u * dim + c * VEC) : vzero<VEC>();
+    V vf = iok ? vload<VEC>(item_mf + i * dim + c * VEC) : vzero<VEC>();
+    vstore<VEC>(g_user_mf + b * dim + c * VEC, vmul(vf, g));
+    vstore<VEC>(g_item_mf + b * dim + c * VEC, vmul(uf, g));
+    if (g_user_mlp) {
+      const float* xr = dx0 + b * (2 * (int64_t)dim);
+      vstore<VEC>(g_user_mlp + b * dim + c * VEC, vload<VEC>(xr + uoff + c * VEC));
+      vstore<VEC>(g_item_mlp + b * dim + c * VEC, vload<VEC>(xr + ioff + c * VEC));
+    }
+  }
+}
+
+// ---- BPR fused step --------------------------------------------------------------------------
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void bpr_fwd_bwd_kernel(
+    const float* __restrict__ user_table, const float* __restrict__ item_table, int64_t user_rows,
+    int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ pos,
+    const IdT* __restrict__ neg, int dim, int chunks, int lpr_log2, int64_t batch, float inv_batch,
+    float* __restrict__ per_triplet, double* __restrict__ loss_sum, float* __restrict__ g_user,
+    float* __restrict__ g_item, int* err) {
+  using V = typename VecT<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  const bool live = b < batch;
+  if (!live) b = batch - 1;
+  const int64_t u = load_id(users, b), p = load_id(pos, b), n = load_id(neg, b);
+  const bool uok = (uint64_t)u < (uint64_t)user_rows;
+  const bool pok = (uint64_t)p < (uint64_t)item_rows, nok = (uint64_t)n < (uint64_t)item_rows;
+  if (!(uok && pok && nok) && err && lir == 0) *err = 1;
+  float sp = 0.f, sn = 0.f;
+  // single-pass fast path keeps the three rows in registers (chunks <= lpr: dim <= 256)
+  const bool one_pass = chunks <= lpr;
+  V eu = vzero<VEC>(), ep = vzero<VEC>(), en = vzero<VEC>();
+  if (one_pass) {
+    if (lir < chunks) {
+      eu = uok ? vload<VEC>(user_table + u * dim + lir * VEC) : vzero<VEC>();
+      ep = pok ? vload<VEC>(item_table + p * dim + lir * VEC) : vzero<VEC>();
+      en = nok ? vload<VEC>(item_table + n * dim + lir * VEC) : vzero<VEC>();
+    }
+    sp = vdot(eu, ep);
+    sn = vdot(eu, en);
+  } else {
+    for (int c = lir; c < chunks; c += lpr) {
+      V a = uok ? vload<VEC>(user_table + u * dim + c * VEC) : vzero<VEC>();
+      V bp = pok ? vload<VEC>(item_table + p * dim + c * VEC) : vzero<VEC>();
+      V bn = nok ? vload<VEC>(item_table + n * dim + c * VEC) : vzero<VEC>();
+      sp += vdot(a, bp);
+      sn += vdot(a, bn);
+    }
+  }
+  sp = rowgroup_sum(sp, lpr);
+  sn = rowgroup_sum(sn, lpr);
+  const float x = sp - sn;
+  const float s = sigmoidf_acc(x);
+  const float l = 1.f - s;
+  const float dx = -s * (1.f - s) * inv_batch;
+  if (live) {
+    if (per_triplet && lir == 0) per_triplet[b] = l;
+    float* gu = g_user + b * dim;
+    float* gp = g_item + b * dim;
+    float* gn = g_item + (batch + b) * dim;
+    if (one_pass) {
+      if (lir < chunks) {
+        vstore<VEC>(gu + lir * VEC, vmul(vsub(ep, en), dx));
+        vstore<VEC>(gp + lir * VEC, vmul(eu, dx));
+        vstore<VEC>(gn + lir * VEC, vmul(eu, -dx));
+      }
+    } else {
+      for (int c = lir; c < chunks; c += lpr) {
+        V a = uok ? vload<VEC>(user_table + u * dim + c * VEC) : vzero<VEC>();
+        V bp = pok ? vload<VEC>(item_table + p * dim + c * VEC) : vzero<VEC>();
+        V bn = nok ? vload<VEC>(item_table + n * dim + c * VEC) : vzero<VEC>();
+        vstore<VEC>(gu + c * VEC, vmul(vsub(bp, bn), dx));
+        vstore<VEC>(gp + c * VEC, vmul(a, dx));
+        vstore<VEC>(gn + c * VEC, vmul(a, -dx));
+      }
+    }
+  }
+  // loss: one contribution per row group -> wave sum -> block sum -> one double atomic per block
+  __shared__ double red[4];
+  double contrib = (live && lir == 0) ? (double)l : 0.0;
+  contrib = wave_sum_d(contrib);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) red[wave] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace br
+
+using namespace br;
+
+static inline unsigned grid_for_rows(int64_t batch, int lpr_log2) {
+  const int64_t rows_per_block = 256 >> lpr_log2;
+  return (unsigned)ceil_div(batch, rows_per_block);
+}
+
+extern "C" int brGatherRows(int n_tables, const float* const* tables, const int64_t* table_rows,
+                            const void* const* ids, float* const* outs, int dim, int64_t batch,
+                            int id_type, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(n_tables >= 1 && n_tables <= BR_MAX_TABLES, "brGatherRows: n_tables %d out of [1,%d]", n_tables, BR_MAX_TABLES);
+  BR_CHECK_ARG(dim >= 1 && batch >= 0, "brGatherRows: bad dim/batch");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brGatherRows: bad id_type %d", id_type);
+  if (batch == 0) return BR_OK;
+  for (int t = 0; t < n_tables; ++t)
+    BR_CHECK_ARG(tables[t] && outs[t] && table_rows[t] > 0, "brGatherRows: null table/out %d", t);
+  const RowGeom g = row_geom(dim);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = grid_for_rows(batch, g.lpr_log2);
+  for (int t0 = 0; t0 < n_tables; t0 += 4) {
+    const int nt = (n_tables - t0) < 4 ? (n_tables - t0) : 4;
+    GatherArgs a{};
+    for (int t = 0; t < nt; ++t) {
+      a.tables[t] = tables[t0 + t];
+      a.ids[t] = ids ? ids[t0 + t] : nullptr;
+      a.outs[t] = outs[t0 + t];
+      a.rows[t] = table_rows[t0 + t];
+    }
+#define LAUNCH_G(IdT, NT) \
+  BR_DISPATCH_VEC(g.vec, (gather_rows_kernel<IdT, VEC, NT><<<grid, 256, 0, s>>>(a, dim, g.chunks, g.lpr_log2, batch, err_flag)))
+#define LAUNCH_G_ID(NT)                                   \
+  do {                                                    \
+    if (id_type == BR_IDS_I32) LAUNCH_G(int32_t, NT);     \
+    else LAUNCH_G(int64_t, NT);                           \
+  } while (0)
+    switch (nt) {
+      case 1: LAUNCH_G_ID(1); break;
+      case 2: LAUNCH_G_ID(2); break;
+      case 3: LAUNCH_G_ID(3); break;
+      default: LAUNCH_G_ID(4); break;
+    }
+    BR_CHECK_LAUNCH("brGatherRows");
+  }
+  return BR_OK;
+}
+
+extern "C" int brRowDot(const float* a, const float* b, float* out, int dim, int64_t batch, brStream stream) {
+  BR_CHECK_ARG(a && b && out && dim >= 1 && batch >= 0, "brRowDot: bad args");
+  if (batch == 0) return BR_OK;
+  const RowGeom g = row_geom(dim);
+  BR_DISPATCH_VEC(g.vec, (row_dot_kernel<VEC><<<grid_for_rows(batch, g.lpr_log2), 256, 0, (hipStream_t)stream>>>(
+                             a, b, out, dim, g.chunks, g.lpr_log2, batch)));
+  BR_CHECK_LAUNCH("brRowDot");
+  return BR_OK;
+}
+
+extern "C" int brRowDotBackward(const float* a, const float* b, const float* dout, float* da, float* db,
+                                int dim, int64_t batch, brStream stream) {
+  BR_CHECK_ARG(a && b && dout && da && db && dim >= 1 && batch >= 0, "brRowDotBackward: bad args");
+  if (batch == 0) return BR_OK;
+  const RowGeom g = row_geom(dim);
+  BR_DISPATCH_VEC(g.vec, (row_dot_bwd_kernel<VEC><<<grid_for_rows(batch, g.lpr_log2), 256, 0, (hipStream_t)stream>>>(
+                             a, b, dout, da, db, dim, g.chunks, g.lpr_log2, batch)));
+  BR_CHECK_LAUNCH("brRowDotBackward");
+  return BR_OK;
+}
+
+extern "C" int brNeumfEmbedForward(const float* user_mlp, const float* item_mlp, const float* user_mf,
+                                   const float* item_mf, int64_t user_rows, int64_t item_rows,
+                                   const void* users, const void* items, int id_type, int dim, int64_t batch,
+                                   int item_first, float* x0, float* dot, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(user_mlp && item_mlp && user_mf && item_mf && x0 && dot, "brNeumfEmbedForward: null pointer");
+  BR_CHECK_ARG(dim >= 1 && batch >= 0 && user_rows > 0 && item_rows > 0, "brNeumfEmbedForward: bad sizes");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brNeumfEmbedForward: bad id_type");
+  if (batch == 0) return BR_OK;
+  const RowGeom g = row_geom(dim);
+  const unsigned grid = grid_for_rows(batch, g.lpr_log2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32) {
+    BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
+                               user_mlp, item_mlp, user_mf, item_mf, user_rows, item_rows, (const int32_t*)users,
+                               (const int32_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag)));
+  } else {
+    BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
+                               user_mlp, item_mlp, user_mf, item_mf, user_rows, item_rows, (const int64_t*)users,
+                               (const int64_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag)));
+  }
+  BR_CHECK_LAUNCH("brNeumfEmbedForward");
+  return BR_OK;
+}
+
+extern "C" int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t user_rows,
+                                    int64_t item_rows, const void* users, const void* items, int id_type,
+                                    int dim, int64_t batch, int item_first, const float* dx0, const float* ddot,
+                                    float* g_user_mlp, float* g_item_mlp, float* g_user_mf, float* g_item_mf,
+                                    brStream stream) {
+  BR_CHECK_ARG(user_mf && item_mf && ddot && g_user_mf && g_item_mf, "brNeumfEmbedBackward: null pointer");
+  BR_CHECK_ARG((g_user_mlp == nullptr) == (g_item_mlp == nullptr), "brNeumfEmbedBackward: g_*_mlp both or neither");
+  BR_CHECK_ARG(!g_user_mlp || dx0, "brNeumfEmbedBackward: dx0 required for g_*_mlp");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brNeumfEmbedBackward: bad id_type");
+  if (batch == 0) return BR_OK;
+  const RowGeom g = row_geom(dim);
+  const unsigned grid = grid_for_rows(batch, g.lpr_log2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32) {
+    BR_DISPATCH_VEC(g.vec, (neumf_embed_bwd_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
+                               user_mf, item_mf, user_rows, item_rows, (const int32_t*)users, (const int32_t*)items, dim,
+                               g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf)));
+  } else {
+    BR_DISPATCH_VEC(g.vec, (neumf_embed_bwd_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
+                               user_mf, item_mf, user_rows, item_rows, (const int64_t*)users, (const int64_t*)items, dim,
+                               g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf)));
+  }
+  BR_CHECK_LAUNCH("brNeumfEmbedBackward");
+  return BR_OK;
+}
+
+extern "C" int brBprForwardBackward(const float* user_table, const float* item_table, int64_t user_rows,
+                                    int64_t item_rows, const void* users, const void* pos, const void* neg,
+                                    int id_type, int dim, int64_t batch, float inv_batch, float* per_triplet,
+                                    double* loss_sum, float* g_user, float* g_item, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(user_table && item_table && users && pos && neg && g_user && g_item, "brBprForwardBackward: null pointer");
+  BR_CHECK_ARG(dim >= 1 && batch >= 0 && user_rows > 0 && item_rows > 0, "brBprForwardBackward: bad sizes");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brBprForwardBackward: bad id_type");
+  if (batch == 0) return BR_OK;
+  const RowGeom g = row_geom(dim);
+  const unsigned grid = grid_for_rows(batch, g.lpr_log2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32) {
+    BR_DISPATCH_VEC(g.vec, (bpr_fwd_bwd_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
+                               user_table, item_table, user_rows, item_rows, (const int32_t*)users, (const int32_t*)pos,
+                               (const int32_t*)neg, dim, g.chunks, g.lpr_log2, batch, inv_batch, per_triplet, loss_sum,
+                               g_user, g_item, err_flag)));
+  } else {
+    BR_DISPATCH_VEC(g.vec, (bpr_fwd_bwd_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
+                               user_table, item_table, user_rows, item_rows, (const int64_t*)users, (const int64_t*)pos,
+                               (const int64_t*)neg, dim, g.chunks, g.lpr_log2, batch, inv_batch, per_triplet, loss_sum,
+                               g_user, g_item, err_flag)));
+  }
+  BR_CHECK_LAUNCH("brBprForwardBackward");
+  return BR_OK;
+}

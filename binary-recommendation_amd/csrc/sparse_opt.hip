@@ -1,0 +1,373 @@
+// S1 duplicate-id handling + O1 TF-form Adam + O2 Keras Adagrad.
+//
+// Design: no float atomics on the training path.  ids are radix-sorted once per id stream
+// together with their batch position (stable => equal ids stay in ascending position); every
+// table that shares the stream reuses the index.  The optimizer kernels walk each segment in
+// that order, so the duplicate sum is exactly a sequential unsorted_segment_sum ([TF-sem]
+// _deduplicate_indexed_slices): bitwise reproducible, and (sum g)^2 feeds Adam's v.
+// The per-pair row gradients are written ONCE with plain stores by the backward kernels and
+// read back here through the inverted index (cdna_hip_programming.md App. B "Scatter / gather").
+#include "common.h"
+#include "rows.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace br {
+
+__global__ void iota_kernel(int32_t* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int32_t)i;
+}
+
+// one row group per sorted position; only segment heads do work
+template <typename IdT>
+__device__ __forceinline__ bool segment_head(const IdT* sid, int64_t i) {
+  return i == 0 || sid[i - 1] != sid[i];
+}
+
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const IdT* __restrict__ sid, const int32_t* __restrict__ spos,
+                                                           int64_t n, const float* __restrict__ g, int64_t ldg, int dim,
+                                                           int chunks, int lpr_log2, float* __restrict__ out,
+                                                           int32_t* __restrict__ head_flag) {
+  using V = typename VecT<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (i >= n) return;
+  const bool head = segment_head(sid, i);
+  if (lir == 0 && head_flag) head_flag[i] = head ? 1 : 0;
+  if (!head) return;
+  const IdT row = sid[i];
+  for (int c = lir; c < chunks; c += lpr) {
+    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg + c * VEC);
+    for (int64_t j = i + 1; j < n && sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg + c * VEC));
+    vstore<VEC>(out + i * dim + c * VEC, acc);
+  }
+}
+
+struct AdamHp {
+  float alpha, b1, omb1, b2, omb2, eps;
+};
+
+__device__ __forceinline__ void adam_update1(float& th, float& m, float& v, float g, const AdamHp& h) {
+  m = h.b1 * m + h.omb1 * g;
+  v = h.b2 * v + h.omb2 * (g * g);
+  th = th - h.alpha * m / (sqrtf(v) + h.eps);
+}
+__device__ __forceinline__ void adam_update(float4& th, float4& m, float4& v, float4 g, const AdamHp& h) {
+  adam_update1(th.x, m.x, v.x, g.x, h); adam_update1(th.y, m.y, v.y, g.y, h);
+  adam_update1(th.z, m.z, v.z, g.z, h); adam_update1(th.w, m.w, v.w, g.w, h);
+}
+__device__ __forceinline__ void adam_update(float2& th, float2& m, float2& v, float2 g, const AdamHp& h) {
+  adam_update1(th.x, m.x, v.x, g.x, h); adam_update1(th.y, m.y, v.y, g.y, h);
+}
+__device__ __forceinline__ void adam_update(float& th, float& m, float& v, float g, const AdamHp& h) {
+  adam_update1(th, m, v, g, h);
+}
+
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict__ table, float* __restrict__ M,
+                                                                float* __restrict__ Vv, int64_t table_rows, int dim,
+                                                                int chunks, int lpr_log2, const IdT* __restrict__ sid,
+                                                                const int32_t* __restrict__ spos, int64_t n,
+                                                                const float* __restrict__ g, int64_t ldg, AdamHp h,
+                                                                uint8_t* __restrict__ mark) {
+  using V = typename VecT<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (i >= n) return;
+  if (!segment_head(sid, i)) return;
+  const int64_t row = (int64_t)sid[i];
+  if ((uint64_t)row >= (uint64_t)table_rows) return;  // out-of-range ids were flagged by the forward
+  if (mark && lir == 0) mark[row] = 1;
+  for (int c = lir; c < chunks; c += lpr) {
+    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg + c * VEC);
+    for (int64_t j = i + 1; j < n && (int64_t)sid[j] == row; ++j)
+      acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg + c * VEC));
+    const int64_t off = row * dim + c * VEC;
+    V th = vload<VEC>(table + off), m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
+    adam_update(th, m, v, acc, h);
+    vstore<VEC>(table + off, th);
+    vstore<VEC>(M + off, m);
+    vstore<VEC>(Vv + off, v);
+  }
+}
+
+// Dense sweep: all rows NOT marked get the zero-gradient update.  float4 streaming,
+// 2 vectors per thread in flight, grid-stride.
+template <int VEC>
+__global__ __launch_bounds__(256) void adam_dense_sweep_kernel(float* __restrict__ table, float* __restrict__ M,
+                                                                float* __restrict__ Vv, int64_t n_vec, int chunks,
+                                                                AdamHp h, const uint8_t* __restrict__ mark) {
+  using V = typename VecT<VEC>::type;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_vec; e += stride) {
+    const int64_t row = e / chunks;
+    if (mark && mark[row]) continue;
+    V th = vload<VEC>(table + e * VEC), m = vload<VEC>(M + e * VEC), v = vload<VEC>(Vv + e * VEC);
+    adam_update(th, m, v, vzero<VEC>(), h);
+    vstore<VEC>(table + e * VEC, th);
+    vstore<VEC>(M + e * VEC, m);
+    vstore<VEC>(Vv + e * VEC, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ th, float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ g, int64_t n, AdamHp h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) adam_update1(th[i], m[i], v[i], g[i], h);
+}
+
+__device__ __forceinline__ void adagrad_update1(float& th, float& acc, float g, float lr, float eps) {
+  acc = acc + g * g;
+  th = th - lr * g / (sqrtf(acc) + eps);
+}
+
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void adagrad_rows_sorted_kernel(float* __restrict__ table, float* __restrict__ A,
+                                                                   int64_t table_rows, int dim, int chunks, int lpr_log2,
+                                                                   const IdT* __restrict__ sid, const int32_t* __restrict__ spos,
+                                                                   int64_t n, const float* __restrict__ g, int64_t ldg,
+                                                                   float lr, float eps) {
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (i >= n) return;
+  if (!segment_head(sid, i)) return;
+  const int64_t row = (int64_t)sid[i];
+  if ((uint64_t)row >= (uint64_t)table_rows) return;
+  for (int c = lir; c < chunks; c += lpr) {
+    float accg[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) accg[k] = g[(int64_t)spos[i] * ldg + c * VEC + k];
+    for (int64_t j = i + 1; j < n && (int64_t)sid[j] == row; ++j)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) accg[k] += g[(int64_t)spos[j] * ldg + c * VEC + k];
+    const int64_t off = row * dim + c * VEC;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float th = table[off + k], a = A[off + k];
+      adagrad_update1(th, a, accg[k], lr, eps);
+      table[off + k] = th;
+      A[off + k] = a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adagrad_flat_kernel(float* __restrict__ th, float* __restrict__ acc,
+                                                            const float* __restrict__ g, int64_t n, float lr, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) adagrad_update1(th[i], acc[i], g[i], lr, eps);
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ gt, int64_t table_rows, const IdT* __restrict__ ids,
+                                                           int64_t n, const float* __restrict__ rows, int dim, int* err) {
+  // one lane per float: a wave covers 64 contiguous floats (256 B) of one row => the atomic
+  // shape MI355X_MICROARCH.md "Global float atomics" measures at full rate for dim >= 64.
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * dim) return;
+  const int64_t b = e / dim;
+  const int d = (int)(e - b * dim);
+  const int64_t id = load_id(ids, b);
+  if ((uint64_t)id >= (uint64_t)table_rows) {
+    if (err) *err = 1;
+    return;
+  }
+  atomicAdd(gt + id * dim + d, rows[e]);
+}
+
+static inline AdamHp make_hp(double alpha, double b1, double b2, double eps) {
+  AdamHp h;
+  h.alpha = (float)alpha;
+  h.b1 = (float)b1;
+  h.omb1 = (float)(1.0 - b1);
+  h.b2 = (float)b2;
+  h.omb2 = (float)(1.0 - b2);
+  h.eps = (float)eps;
+  return h;
+}
+
+static inline int bits_for(int64_t upper) {
+  int bits = 1;
+  while (bits < 63 && ((int64_t)1 << bits) < upper) ++bits;
+  return bits;
+}
+
+template <typename IdT>
+static int64_t sort_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const IdT*)nullptr, (IdT*)nullptr, (const int32_t*)nullptr,
+                                     (int32_t*)nullptr, (int)n, 0, (int)sizeof(IdT) * 8, (hipStream_t)0);
+  return (int64_t)bytes;
+}
+
+}  // namespace br
+
+using namespace br;
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern "C" int64_t brRowIndexWorkspaceBytes(int64_t n, int id_type) {
+  if (n <= 0) return 256;
+  const int64_t iota = align256(n * 4);
+  const int64_t tmp = id_type == BR_IDS_I64 ? sort_temp_bytes<int64_t>(n) : sort_temp_bytes<int32_t>(n);
+  return iota + align256(tmp) + 256;
+}
+
+extern "C" int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t id_upper_bound, void* sorted_ids,
+                               int32_t* sorted_pos, void* workspace, int64_t workspace_bytes, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brRowIndexBuild: bad id_type");
+  BR_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31), "brRowIndexBuild: n out of range");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(ids && sorted_ids && sorted_pos && workspace, "brRowIndexBuild: null pointer");
+  const int64_t need = brRowIndexWorkspaceBytes(n, id_type);
+  if (workspace_bytes < need) {
+    set_error("brRowIndexBuild: workspace %lld < required %lld", (long long)workspace_bytes, (long long)need);
+    return BR_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* iota = (int32_t*)workspace;
+  void* tmp = (char*)workspace + align256(n * 4);
+  size_t tmp_bytes = (size_t)(workspace_bytes - align256(n * 4));
+  iota_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, s>>>(iota, n);
+  const int end_bit_cap = (id_type == BR_IDS_I64 ? 64 : 32);
+  int end_bit = id_upper_bound > 0 ? bits_for(id_upper_bound) : end_bit_cap;
+  if (end_bit > end_bit_cap) end_bit = end_bit_cap;
+  hipError_t e;
+  if (id_type == BR_IDS_I64)
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const int64_t*)ids, (int64_t*)sorted_ids, (const int32_t*)iota,
+                                           sorted_pos, (int)n, 0, end_bit, s);
+  else
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const int32_t*)ids, (int32_t*)sorted_ids, (const int32_t*)iota,
+                                           sorted_pos, (int)n, 0, end_bit, s);
+  if (e != hipSuccess) {
+    set_error("brRowIndexBuild: radix sort failed: %s", hipGetErrorString(e));
+    return BR_ERR_HIP;
+  }
+  BR_CHECK_LAUNCH("brRowIndexBuild");
+  return BR_OK;
+}
+
+extern "C" int brSegmentSumRows(const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                                const float* row_grads, int64_t ldg, int dim, float* out_rows, int32_t* head_flag,
+                                brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brSegmentSumRows: bad id_type");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(sorted_ids && sorted_pos && row_grads && out_rows && dim >= 1 && ldg >= dim, "brSegmentSumRows: bad args");
+  const RowGeom g = row_geom_ld(dim, ldg);
+  const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(g.vec, (segment_sum_kernel<int32_t, VEC><<<grid, 256, 0, s>>>((const int32_t*)sorted_ids, sorted_pos, n, row_grads,
+                                                                                   ldg, dim, g.chunks, g.lpr_log2, out_rows, head_flag)));
+  else
+    BR_DISPATCH_VEC(g.vec, (segment_sum_kernel<int64_t, VEC><<<grid, 256, 0, s>>>((const int64_t*)sorted_ids, sorted_pos, n, row_grads,
+                                                                                   ldg, dim, g.chunks, g.lpr_log2, out_rows, head_flag)));
+  BR_CHECK_LAUNCH("brSegmentSumRows");
+  return BR_OK;
+}
+
+extern "C" int brScatterAddRows(float* g_table, int64_t table_rows, const void* ids, int id_type, int64_t n,
+                                const float* rows, int dim, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brScatterAddRows: bad id_type");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(g_table && rows && dim >= 1 && table_rows > 0, "brScatterAddRows: bad args");
+  const unsigned grid = (unsigned)ceil_div(n * dim, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32)
+    scatter_add_kernel<int32_t><<<grid, 256, 0, s>>>(g_table, table_rows, (const int32_t*)ids, n, rows, dim, err_flag);
+  else
+    scatter_add_kernel<int64_t><<<grid, 256, 0, s>>>(g_table, table_rows, (const int64_t*)ids, n, rows, dim, err_flag);
+  BR_CHECK_LAUNCH("brScatterAddRows");
+  return BR_OK;
+}
+
+extern "C" int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int dim, const void* sorted_ids,
+                                int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
+                                double alpha_t, double beta1, double beta2, double eps, uint8_t* mark, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdamRowsSorted: bad id_type");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(table && m && v && sorted_ids && sorted_pos && row_grads && dim >= 1 && ldg >= dim && table_rows > 0,
+               "brAdamRowsSorted: bad args");
+  const RowGeom g = row_geom_ld(dim, ldg);
+  const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
+  const AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
+                               table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int32_t*)sorted_ids, sorted_pos, n,
+                               row_grads, ldg, h, mark)));
+  else
+    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
+                               table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int64_t*)sorted_ids, sorted_pos, n,
+                               row_grads, ldg, h, mark)));
+  BR_CHECK_LAUNCH("brAdamRowsSorted");
+  return BR_OK;
+}
+
+extern "C" int brAdamDenseSweep(float* table, float* m, float* v, int64_t table_rows, int dim, double alpha_t,
+                                double beta1, double beta2, double eps, uint8_t* mark, brStream stream) {
+  BR_CHECK_ARG(table && m && v && dim >= 1 && table_rows > 0, "brAdamDenseSweep: bad args");
+  const RowGeom g = row_geom(dim);
+  const int64_t n_vec = table_rows * g.chunks;
+  int64_t blocks = ceil_div(n_vec, 256);
+  const int64_t cap = 256 * 16;  // 16 workgroups per CU, grid-stride beyond
+  if (blocks > cap) blocks = cap;
+  const AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
+  hipStream_t s = (hipStream_t)stream;
+  BR_DISPATCH_VEC(g.vec, (adam_dense_sweep_kernel<VEC><<<(unsigned)blocks, 256, 0, s>>>(table, m, v, n_vec, g.chunks, h, mark)));
+  BR_CHECK_LAUNCH("brAdamDenseSweep");
+  if (mark) {
+    hipError_t e = hipMemsetAsync(mark, 0, (size_t)table_rows, s);
+    if (e != hipSuccess) {
+      set_error("brAdamDenseSweep: memset failed: %s", hipGetErrorString(e));
+      return BR_ERR_HIP;
+    }
+  }
+  return BR_OK;
+}
+
+extern "C" int brAdamFlat(float* theta, float* m, float* v, const float* g, int64_t n, double alpha_t, double beta1,
+                          double beta2, double eps, brStream stream) {
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(theta && m && v && g && n > 0, "brAdamFlat: bad args");
+  adam_flat_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(theta, m, v, g, n, make_hp(alpha_t, beta1, beta2, eps));
+  BR_CHECK_LAUNCH("brAdamFlat");
+  return BR_OK;
+}
+
+extern "C" int brAdagradRowsSorted(float* table, float* acc, int64_t table_rows, int dim, const void* sorted_ids,
+                                   int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
+                                   double lr, double eps, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdagradRowsSorted: bad id_type");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(table && acc && sorted_ids && sorted_pos && row_grads && dim >= 1 && ldg >= dim && table_rows > 0,
+               "brAdagradRowsSorted: bad args");
+  const RowGeom g = row_geom_ld(dim, ldg);
+  const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(g.vec, (adagrad_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
+                               table, acc, table_rows, dim, g.chunks, g.lpr_log2, (const int32_t*)sorted_ids, sorted_pos, n,
+                               row_grads, ldg, (float)lr, (float)eps)));
+  else
+    BR_DISPATCH_VEC(g.vec, (adagrad_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
+                               table, acc, table_rows, dim, g.chunks, g.lpr_log2, (const int64_t*)sorted_ids, sorted_pos, n,
+                               row_grads, ldg, (float)lr, (float)eps)));
+  BR_CHECK_LAUNCH("brAdagradRowsSorted");
+  return BR_OK;
+}
+
+extern "C" int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n, double lr, double eps, brStream stream) {
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(theta && acc && g && n > 0, "brAdagradFlat: bad args");
+  adagrad_flat_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(theta, acc, g, n, (float)lr, (float)eps);
+  BR_CHECK_LAUNCH("brAdagradFlat");
+  return BR_OK;
+}

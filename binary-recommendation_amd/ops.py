@@ -1,0 +1,215 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/binrec.h).
+
+PyTorch is plumbing here: device memory (`tensor.data_ptr()`), the current HIP stream and,
+for the multi-GPU path, `torch.distributed` (RCCL).  All arithmetic happens in
+libbinrec_hip.so; nothing in this module computes on the CPU or with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+I32, I64 = 0, 1
+ACT = {"linear": 0, "sigmoid": 1, "relu": 2}
+LOSS = {"bce": 0, "mse": 1}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32(t: torch.Tensor, name: str):
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name}: expected a contiguous float32 device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t
+
+
+def _ids(t, name: str):
+    if t is None:
+        return None, I32
+    if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"{name}: expected contiguous int32/int64 device ids, got {t.dtype} {t.device}")
+    return t, (I64 if t.dtype == torch.int64 else I32)
+
+
+def _same_id_type(*types):
+    ts = {t for t in types}
+    if len(ts) != 1:
+        raise TypeError("all id tensors of one call must share a dtype (int32 or int64)")
+    return ts.pop()
+
+
+def new_err_flag(device) -> torch.Tensor:
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def raise_if_flag(flag: torch.Tensor, what="embedding id"):
+    """Host sync. Turns the device flag into the IndexError TF-CPU would raise [TF-sem]."""
+    if int(flag.item()) != 0:
+        flag.zero_()
+        raise IndexError(f"{what} out of range")
+
+
+# ------------------------------------------------------------------------------ G1 / M1
+def gather_rows(tables, ids, outs=None, err_flag=None):
+    """outs[t] = tables[t][ids[t]] for all t in ONE launch (Embedding lookups)."""
+    n = len(tables)
+    dim = tables[0].shape[1]
+    idt = [_ids(i, "ids") for i in ids]
+    id_type = _same_id_type(*[t for _, t in idt])
+    batch = ids[0].shape[0] if ids[0] is not None else outs[0].shape[0]
+    if outs is None:
+        outs = [torch.empty((batch, dim), dtype=torch.float32, device=tables[0].device) for _ in range(n)]
+    for t in tables:
+        _f32(t, "table")
+        if t.shape[1] != dim:
+            raise ValueError("gather_rows: all tables must share dim")
+    TP = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tables])
+    IP = (ctypes.c_void_p * n)(*[_p(i) for i, _ in idt])
+    OP = (ctypes.c_void_p * n)(*[_f32(o, "out").data_ptr() for o in outs])
+    RW = (ctypes.c_int64 * n)(*[t.shape[0] for t in tables])
+    check(_lib.load().brGatherRows(n, TP, RW, IP, OP, dim, batch, id_type, _p(err_flag), _stream()), "brGatherRows")
+    return outs
+
+
+def row_dot(a, b, out=None):
+    _f32(a, "a"); _f32(b, "b")
+    if out is None:
+        out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    check(_lib.load().brRowDot(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[1], a.shape[0], _stream()), "brRowDot")
+    return out
+
+
+def row_dot_backward(a, b, dout, da=None, db=None):
+    da = torch.empty_like(a) if da is None else da
+    db = torch.empty_like(b) if db is None else db
+    check(_lib.load().brRowDotBackward(_f32(a, "a").data_ptr(), _f32(b, "b").data_ptr(), _f32(dout, "dout").data_ptr(),
+                                       da.data_ptr(), db.data_ptr(), a.shape[1], a.shape[0], _stream()), "brRowDotBackward")
+    return da, db
+
+
+def neumf_embed_forward(user_mlp, item_mlp, user_mf, item_mf, users, items, item_first, x0, dot, err_flag=None):
+    u, ut = _ids(users, "users"); i, it = _ids(items, "items")
+    id_type = _same_id_type(ut, it)
+    dim = user_mlp.shape[1]
+    batch = x0.shape[0]
+    check(_lib.load().brNeumfEmbedForward(_f32(user_mlp, "user_mlp").data_ptr(), _f32(item_mlp, "item_mlp").data_ptr(),
+                                          _f32(user_mf, "user_mf").data_ptr(), _f32(item_mf, "item_mf").data_ptr(),
+                                          user_mlp.shape[0], item_mlp.shape[0], _p(u), _p(i), id_type, dim, batch,
+                                          int(item_first), _f32(x0, "x0").data_ptr(), _f32(dot, "dot").data_ptr(),
+                                          _p(err_flag), _stream()), "brNeumfEmbedForward")
+
+
+def neumf_embed_backward(user_mf, item_mf, users, items, item_first, dx0, ddot, g_user_mf, g_item_mf,
+                         g_user_mlp=None, g_item_mlp=None):
+    u, ut = _ids(users, "users"); i, it = _ids(items, "items")
+    id_type = _same_id_type(ut, it)
+    dim = user_mf.shape[1]
+    batch = ddot.shape[0]
+    check(_lib.load().brNeumfEmbedBackward(_f32(user_mf, "user_mf").data_ptr(), _f32(item_mf, "item_mf").data_ptr(),
+                                           user_mf.shape[0], item_mf.shape[0], _p(u), _p(i), id_type, dim, batch,
+                                           int(item_first), _p(dx0), _f32(ddot, "ddot").data_ptr(), _p(g_user_mlp),
+                                           _p(g_item_mlp), _f32(g_user_mf, "g_user_mf").data_ptr(),
+                                           _f32(g_item_mf, "g_item_mf").data_ptr(), _stream()), "brNeumfEmbedBackward")
+
+
+# ------------------------------------------------------------------------------ L3 BPR
+def bpr_forward_backward(user_table, item_table, users, pos, neg, inv_batch, loss_sum, g_user, g_item,
+                         per_triplet=None, err_flag=None):
+    u, ut = _ids(users, "users"); p, pt = _ids(pos, "pos"); n, nt = _ids(neg, "neg")
+    id_type = _same_id_type(ut, pt, nt)
+    check(_lib.load().brBprForwardBackward(_f32(user_table, "user_table").data_ptr(), _f32(item_table, "item_table").data_ptr(),
+                                           user_table.shape[0], item_table.shape[0], u.data_ptr(), p.data_ptr(), n.data_ptr(),
+                                           id_type, user_table.shape[1], u.shape[0], float(inv_batch), _p(per_triplet),
+                                           loss_sum.data_ptr(), _f32(g_user, "g_user").data_ptr(),
+                                           _f32(g_item, "g_item").data_ptr(), _p(err_flag), _stream()), "brBprForwardBackward")
+
+
+# ------------------------------------------------------------------------------ S1 index
+class RowIndex:
+    """Sorted (id, batch position) index of one id stream, reusable by every table fed by it."""
+
+    def __init__(self, capacity: int, id_dtype: torch.dtype, device):
+        self.capacity = capacity
+        self.id_dtype = id_dtype
+        self.id_type = I64 if id_dtype == torch.int64 else I32
+        self.sorted_ids = torch.empty(capacity, dtype=id_dtype, device=device)
+        self.sorted_pos = torch.empty(capacity, dtype=torch.int32, device=device)
+        self.ws_bytes = int(_lib.load().brRowIndexWorkspaceBytes(capacity, self.id_type))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.n = 0
+
+    def build(self, ids: torch.Tensor, id_upper_bound: int = 0):
+        t, ty = _ids(ids, "ids")
+        if ty != self.id_type or t.shape[0] > self.capacity:
+            raise ValueError("RowIndex.build: dtype/capacity mismatch")
+        self.n = t.shape[0]
+        check(_lib.load().brRowIndexBuild(t.data_ptr(), ty, self.n, int(id_upper_bound), self.sorted_ids.data_ptr(),
+                                          self.sorted_pos.data_ptr(), self.ws.data_ptr(), self.ws_bytes, _stream()),
+              "brRowIndexBuild")
+        return self
+
+
+def segment_sum_rows(index: RowIndex, row_grads, dim=None, ldg=None, out=None, head_flag=None):
+    dim = row_grads.shape[1] if dim is None else dim
+    ldg = row_grads.stride(0) if ldg is None else ldg
+    if out is None:
+        out = torch.zeros((index.n, dim), dtype=torch.float32, device=row_grads.device)
+    if head_flag is None:
+        head_flag = torch.empty(index.n, dtype=torch.int32, device=row_grads.device)
+    check(_lib.load().brSegmentSumRows(index.sorted_ids.data_ptr(), index.id_type, index.sorted_pos.data_ptr(), index.n,
+                                       row_grads.data_ptr(), ldg, dim, out.data_ptr(), head_flag.data_ptr(), _stream()),
+          "brSegmentSumRows")
+    return out, head_flag
+
+
+def scatter_add_rows(g_table, ids, rows, err_flag=None):
+    t, ty = _ids(ids, "ids")
+    check(_lib.load().brScatterAddRows(_f32(g_table, "g_table").data_ptr(), g_table.shape[0], t.data_ptr(), ty, t.shape[0],
+                                       _f32(rows, "rows").data_ptr(), g_table.shape[1], _p(err_flag), _stream()),
+          "brScatterAddRows")
+
+
+# ------------------------------------------------------------------------------ O1 / O2
+def adam_rows_sorted(table, m, v, index: RowIndex, row_grads, ldg, alpha_t, beta1=0.9, beta2=0.999, eps=1e-7, mark=None):
+    check(_lib.load().brAdamRowsSorted(_f32(table, "table").data_ptr(), _f32(m, "m").data_ptr(), _f32(v, "v").data_ptr(),
+                                       table.shape[0], table.shape[1], index.sorted_ids.data_ptr(), index.id_type,
+                                       index.sorted_pos.data_ptr(), index.n, row_grads.data_ptr(), int(ldg), float(alpha_t),
+                                       float(beta1), float(beta2), float(eps), _p(mark), _stream()), "brAdamRowsSorted")
+
+
+def adam_dense_sweep(table, m, v, alpha_t, beta1=0.9, beta2=0.999, eps=1e-7, mark=None):
+    check(_lib.load().brAdamDenseSweep(_f32(table, "table").data_ptr(), _f32(m, "m").data_ptr(), _f32(v, "v").data_ptr(),
+                                       table.shape[0], table.shape[1], float(alpha_t), float(beta1), float(beta2), float(eps),
+                                       _p(mark), _stream()), "brAdamDenseSweep")
+
+
+def adam_flat(theta, m, v, g, alpha_t, beta1=0.9, beta2=0.999, eps=1e-7):
+    check(_lib.load().brAdamFlat(_f32(theta, "theta").data_ptr(), _f32(m, "m").data_ptr(), _f32(v, "v").data_ptr(),
+                                 _f32(g, "g").data_ptr(), theta.numel(), float(alpha_t), float(beta1), float(beta2), float(eps),
+                                 _stream()), "brAdamFlat")
+
+
+def adagrad_rows_sorted(table, acc, index: RowIndex, row_grads, ldg, lr, eps=1e-7):
+    check(_lib.load().brAdagradRowsSorted(_f32(table, "table").data_ptr(), _f32(acc, "acc").data_ptr(), table.shape[0],
+                                          table.shape[1], index.sorted_ids.data_ptr(), index.id_type,
+                                          index.sorted_pos.data_ptr(), index.n, row_grads.data_ptr(), int(ldg), float(lr),
+                                          float(eps), _stream()), "brAdagradRowsSorted")
+
+
+def adagrad_flat(theta, acc, g, lr, eps=1e-7):
+    check(_lib.load().brAdagradFlat(_f32(theta, "theta").data_ptr(), _f32(acc, "acc").data_ptr(), _f32(g, "g").data_ptr(),
+                                    theta.numel(), float(lr), float(eps), _stream()), "brAdagradFlat")
+
+
+def adam_alpha(lr: float, t: int, beta1=0.9, beta2=0.999) -> float:
+    """[TF-sem] alpha_t = lr*sqrt(1-b2^t)/(1-b1^t) in double on the host."""
+    return lr * (1.0 - beta2 ** t) ** 0.5 / (1.0 - beta1 ** t)

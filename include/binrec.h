@@ -1,0 +1,218 @@
+/*
+ * binrec.h — C-ABI of libbinrec_hip.so: the MI355X (gfx950) hot path of the
+ * NeuMF / BPR / TwoTower trainers of leotimus/binary-recommendation.
+ *
+ * The reference has NO plugin / FFI / operator interface for this path: every op is a stock
+ * Keras layer declared in Python.  Each entry point below therefore cites the
+ * reference *call site* (path:line under /root/reference) whose arithmetic it replaces; the
+ * Python host in binary-recommendation_amd/ re-exposes the reference's model surface
+ * (compileModel / fit / train_step / predict ...) on top of these.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.  Every function returns int:
+ *    BR_OK (0) or a negative BR_ERR_*; brGetLastError() gives the thread-local message.
+ *  - Caller owns ALL memory (device buffers, e.g. torch tensors' data_ptr()).  The library
+ *    never allocates, never synchronises, and keeps no global state but the error string.
+ *    Scratch needs are queried (br*WorkspaceBytes) and passed in by the caller.
+ *  - Every launch goes to the caller's stream (`brStream` = hipStream_t).
+ *  - Tables are row-major fp32 [rows][dim].  ids are int32 or int64 (BR_IDS_*); ids == NULL
+ *    means identity (row b of an already-gathered [batch][dim] buffer: the row-sharded
+ *    multi-GPU path hands rows over that way).
+ *  - Out-of-range ids never fault: the access is skipped (zeros are produced) and *err_flag
+ *    (device int, may be NULL) is set to 1.  TF-CPU raises InvalidArgument there [TF-sem];
+ *    the Python host turns the flag into an IndexError.
+ *  - Dropout masks are a pure function (Philox4x32-10) of (seed, step, site, global row, col):
+ *    see csrc/philox.h; restated bit-exactly in oracle/binrec_oracle.py.
+ */
+#ifndef BINREC_H
+#define BINREC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* brStream; /* hipStream_t */
+
+enum { BR_OK = 0, BR_ERR_ARG = -1, BR_ERR_HIP = -2, BR_ERR_UNSUPPORTED = -3, BR_ERR_WORKSPACE = -4 };
+enum { BR_IDS_I32 = 0, BR_IDS_I64 = 1 };
+enum { BR_ACT_LINEAR = 0, BR_ACT_SIGMOID = 1, BR_ACT_RELU = 2 };
+enum { BR_LOSS_BCE = 0, BR_LOSS_MSE = 1 };
+enum { BR_MAX_TABLES = 8 };
+
+const char* brGetLastError(void);
+int brVersion(void);
+/* cu_count / arch string of the current device (host-side query, no launch). */
+int brDeviceInfo(int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* ---- G1/G2: Embedding(...)(input) + Flatten ------------------------------------------------
+ * NFC_plain.py:115-126, NeuMFModel.py:58-63, BPRModel.py:55-61, twoTower.py:34,36.
+ * outs[t][b,:] = tables[t][ids[t][b],:] for t < n_tables, fused in one launch. Bit-exact. */
+int brGatherRows(int n_tables, const float* const* tables, const int64_t* table_rows,
+                 const void* const* ids, float* const* outs, int dim, int64_t batch,
+                 int id_type, int* err_flag, brStream stream);
+
+/* ---- M1: Dot(axes=1) — NFC_plain.py:148, NeuMFModel.py:79, twoTower.py:44,86 ----------------
+ * out[b] = sum_d a[b,d]*b[b,d];  backward: da = dout*b, db = dout*a. */
+int brRowDot(const float* a, const float* b, float* out, int dim, int64_t batch, brStream stream);
+int brRowDotBackward(const float* a, const float* b, const float* dout, float* da, float* db,
+                     int dim, int64_t batch, brStream stream);
+
+/* ---- G1+M1+T1 fused for NeuMF: 4 lookups, GMF dot, MLP concat ------------------------------
+ * NFC_plain.py:115-126,137,148 (item_first=1) / NeuMFModel.py:58-66,79 (item_first=0).
+ * x0[b] = concat(first_mlp[b], second_mlp[b]) (B x 2*dim), dot[b] = user_mf[u]·item_mf[i]. */
+int brNeumfEmbedForward(const float* user_mlp, const float* item_mlp, const float* user_mf,
+                        const float* item_mf, int64_t user_rows, int64_t item_rows,
+                        const void* users, const void* items, int id_type, int dim, int64_t batch,
+                        int item_first, float* x0, float* dot, int* err_flag, brStream stream);
+/* B1 for the same block: per-pair row gradients (IndexedSlices values, [TF-sem]).
+ * dx0: (B x 2*dim) gradient w.r.t. the (pre-dropout) concat; ddot: (B).
+ * g_user_mf[b] = ddot[b]*item_mf[i_b], g_item_mf[b] = ddot[b]*user_mf[u_b];
+ * g_*_mlp = the two halves of dx0 in concat order.  Outputs are (B x dim) each. */
+int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t user_rows,
+                         int64_t item_rows, const void* users, const void* items, int id_type,
+                         int dim, int64_t batch, int item_first, const float* dx0,
+                         const float* ddot, float* g_user_mlp, float* g_item_mlp,
+                         float* g_user_mf, float* g_item_mf, brStream stream);
+
+/* ---- L3: BPR triplet step — BPRModel.py:49-74,124-144; bpr.py:141-157 -----------------------
+ * x = u·p - u·n ; l = 1 - sigmoid(x) ; loss = mean(l).  One fused launch: 3 gathers, 2 dots,
+ * loss partials, 3 row gradients.  g_item is (2B x dim): rows [0,B) = d/d pos, [B,2B) = d/d neg
+ * (the shared item table's two IndexedSlices concatenated).  loss_sum: device double, += sum l.
+ * per_triplet (B) may be NULL.  inv_batch = 1/global batch. */
+int brBprForwardBackward(const float* user_table, const float* item_table, int64_t user_rows,
+                         int64_t item_rows, const void* users, const void* pos, const void* neg,
+                         int id_type, int dim, int64_t batch, float inv_batch, float* per_triplet,
+                         double* loss_sum, float* g_user, float* g_item, int* err_flag,
+                         brStream stream);
+
+/* ---- S1: duplicate-id handling ([TF-sem] _deduplicate_indexed_slices) ----------------------
+ * brRowIndexBuild: stable radix sort of (id, batch position) -> sorted_ids, sorted_pos (int32).
+ * Equal ids stay in ascending batch position, so every later segment sum runs in exactly the
+ * order of a sequential unsorted_segment_sum: bitwise reproducible, no float atomics. */
+int64_t brRowIndexWorkspaceBytes(int64_t n, int id_type);
+int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t id_upper_bound,
+                    void* sorted_ids, int32_t* sorted_pos, void* workspace,
+                    int64_t workspace_bytes, brStream stream);
+/* Materialised dedup: for each segment head h (sorted position), out_rows[h] = ordered sum of
+ * row_grads[sorted_pos[j]] over the segment, head_flag[h]=1; non-head rows untouched, flag 0. */
+int brSegmentSumRows(const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                     const float* row_grads, int64_t ldg, int dim, float* out_rows,
+                     int32_t* head_flag, brStream stream);
+/* Fast form (order-nondeterministic float atomics): g_table[ids[b],:] += rows[b,:]. */
+int brScatterAddRows(float* g_table, int64_t table_rows, const void* ids, int id_type,
+                     int64_t n, const float* rows, int dim, int* err_flag, brStream stream);
+
+/* ---- O1: Keras/TF-form Adam — NFC_plain.py:153, NeuMFModel.py:89, BPRModel.py:70 ------------
+ * alpha_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller in double; the launcher rounds
+ * alpha_t, b1, 1-b1, b2, 1-b2, eps to fp32 once.  row_grads rows have stride ldg floats (so the
+ * two halves of a (B x 2*dim) dx0 buffer serve as the MLP tables' row gradients in place).
+ * m = b1*m+(1-b1)*g ; v = b2*v+(1-b2)*g^2 ; theta -= alpha_t*m/(sqrt(v)+eps)   (eps outside).
+ * brAdamRowsSorted: touched rows only; g = ordered segment sum (dedup BEFORE the square).
+ *   mark (uint8[table_rows]) non-NULL: set mark[row]=1 for touched rows (for the sweep).
+ * brAdamDenseSweep: every row NOT marked gets the g=0 update (m,v decay + theta step): with
+ *   brAdamRowsSorted before it this is exactly Keras' non-lazy sparse Adam; it clears marks. */
+int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int dim,
+                     const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                     const float* row_grads, int64_t ldg, double alpha_t, double beta1,
+                     double beta2, double eps, uint8_t* mark, brStream stream);
+int brAdamDenseSweep(float* table, float* m, float* v, int64_t table_rows, int dim,
+                     double alpha_t, double beta1, double beta2, double eps, uint8_t* mark,
+                     brStream stream);
+/* Flat dense parameters (MLP weights, biases, BN gamma/beta): plain TF-form Adam. */
+int brAdamFlat(float* theta, float* m, float* v, const float* g, int64_t n, double alpha_t,
+               double beta1, double beta2, double eps, brStream stream);
+
+/* ---- O2: Keras Adagrad — twoTower.py:209,278-279 ([TF-sem] acc0 = 0.1, eps 1e-7) -------------
+ * acc += g^2 ; theta -= lr*g/(sqrt(acc)+eps); sparse apply touches only deduplicated rows. */
+int brAdagradRowsSorted(float* table, float* acc, int64_t table_rows, int dim,
+                        const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                        const float* row_grads, int64_t ldg, double lr, double eps,
+                        brStream stream);
+int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n, double lr, double eps,
+                  brStream stream);
+
+/* ---- T1-T4: MLP tower layer, fp32 MFMA (v_mfma_f32_16x16x4_f32) ----------------------------
+ * Dense/BatchNormalization/Dropout: NFC_plain.py:138-147, NeuMFModel.py:67-78, twoTower.py:40-41.
+ * y = act( T(x)·W + bias ),  T(x)[r,k] = (x[r,k]*in_scale[k] + in_shift[k]) * keep(r,k)/(1-p)
+ *   in_scale/in_shift (K) NULL => identity (they carry the previous layer's BatchNorm);
+ *   drop_p == 0 => no dropout; keep(r,k) from Philox(seed, step, site, row0+r, k).
+ * stats (double[2N], may be NULL): += column sums of y and y^2 (BatchNorm batch statistics).
+ * x: (B x K) row stride ldx; W: (K x N) row-major; y: (B x N) row stride ldy. */
+int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
+                   int64_t ldy, int64_t batch, int K, int N, int act, const float* in_scale,
+                   const float* in_shift, float drop_p, uint64_t seed, uint32_t step,
+                   uint32_t site, int64_t row0, double* stats, brStream stream);
+/* BatchNorm bookkeeping from the column sums (tiny): mean, biased var, scale = gamma*rstd,
+ * shift = beta - mean*scale, moving stats <- momentum*moving + (1-momentum)*batch [TF-sem].
+ * bstats (mean[N], rstd[N]) kept for the backward. */
+int brBnFinalize(const double* stats, double batch_total, const float* gamma, const float* beta,
+                 float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
+                 float* shift, float* mean, float* rstd, int N, brStream stream);
+/* Inference-mode affine from the moving statistics. */
+int brBnInference(const float* gamma, const float* beta, const float* moving_mean,
+                  const float* moving_var, float eps, float* scale, float* shift, int N,
+                  brStream stream);
+/* Backward of one tower layer.
+ *  gy: (B x N) gradient w.r.t. the layer's *consumer input* (i.e. w.r.t. dropout(BN(y))), or
+ *      w.r.t. y itself when the layer has no BN/dropout after it (out_* NULL, out_drop_p 0).
+ *  out BN (after this layer): out_mean/out_rstd/out_gamma (N) and bn_sums (double[2N]:
+ *      sum_r dh, sum_r dh*xhat — produced by the consumer's backward, see in_bn_sums).
+ *  in transform (before this layer) as in brDenseForward, plus in_mean/in_rstd (K) when the
+ *      input carries a BN: then in_bn_sums (double[2K]) += (sum dh_in, sum dh_in*xhat_in).
+ *  Outputs: gx (B x K) gradient w.r.t. T(x) (raw, the producer un-drops it); dW_slabs:
+ *      (n_slabs x (K*N + N)) per-workgroup partials of [dW | db], reduced by brReduceSlabs in a
+ *      fixed order (bitwise reproducible; no float atomics).  n_slabs = brDenseBackwardSlabs(). */
+int brDenseBackwardSlabs(int64_t batch, int K, int N);
+int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
+                    int64_t ldx, const float* W, int64_t batch, int K, int N, int act,
+                    const float* out_mean, const float* out_rstd, const float* out_gamma,
+                    const double* bn_sums, double batch_total, float out_drop_p,
+                    uint32_t out_site, const float* in_scale, const float* in_shift,
+                    const float* in_mean, const float* in_rstd, float in_drop_p, uint32_t in_site,
+                    uint64_t seed, uint32_t step, int64_t row0, float* gx, int64_t ldgx,
+                    float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream);
+int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* out, brStream stream);
+
+/* ---- head: concat [GMF dot | MLP out] -> Dense(1) -> sigmoid -> loss, and its backward --------
+ * NFC_plain.py:149-155 (mf_first=1, BCE) / NeuMFModel.py:80-91 (mf_first=0, MSE).
+ * a3: (B x N3); dot: (B); w4: (N3+1) in concat order; b4: (1).  Outputs: logit, prob (B);
+ * sums (double[4]) += [loss, sum (p-y)^2, sum |p-y|, #correct@0.5]; when labels && training:
+ * da3 (B x N3), ddot (B), head_slabs (n_slabs x (N3+2)) partials of [dW4 | db4].
+ * inv_batch = 1/global batch. */
+int brHeadSlabs(int64_t batch);
+int brNeumfHead(const float* a3, int64_t lda3, const float* dot, const float* labels,
+                const float* w4, const float* b4, int64_t batch, int N3, int mf_first, int loss,
+                float inv_batch, float* logit, float* prob, double* sums, float* da3,
+                int64_t ldda3, float* ddot, float* head_slabs, int n_slabs, brStream stream);
+
+/* ---- L1 stand-alone: sigmoid + BCE-from-logits (twoTower.py:85-87 rdZero path) ---------------
+ * sums[0] += sum_b max(z,0) - z*y + log1p(exp(-|z|)); dz = (sigmoid(z)-y)*inv_batch. */
+int brBceLogits(const float* z, const float* y, int64_t batch, float inv_batch, float* prob,
+                float* dz, double* sums, brStream stream);
+
+/* ---- L4: in-batch softmax (tfrs.tasks.Retrieval, twoTower.py:47,82-83) [TF-sem] --------------
+ * S = Q C^T (Bq x Bc), accidental hits (cand_ids[j]==q_pos_ids[i], j != diag) masked, loss =
+ * SUM_i [logsumexp_j S_ij - S_i,diag(i)].  Streaming (the Bq x Bc matrix is never stored).
+ * Pass 1 (brInBatchSoftmaxLse): row_lse (Bq), loss_sum (double) +=.
+ * Pass 2 (brInBatchSoftmaxGrad): dQ = (P - I) C, dC += (P - I)^T Q.
+ * diag_offset: column of C holding query i's positive = i + diag_offset (data-parallel ranks
+ * all-gather C; rank r's queries sit at offset r*Bq). */
+int brInBatchSoftmaxLse(const float* Q, const float* C, const void* q_pos_ids,
+                        const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
+                        int64_t diag_offset, float* row_lse, double* loss_sum, brStream stream);
+int brInBatchSoftmaxGrad(const float* Q, const float* C, const void* q_pos_ids,
+                         const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
+                         int64_t diag_offset, const float* row_lse, float* dQ, float* dC,
+                         brStream stream);
+
+/* ---- E1: full-catalogue scoring + stable top-k — topKmetrics.py:17-72, twoTower.py:64-69 -----
+ * scores (U x I) row-major -> top-k per user, descending, ties keep the LOWER item position
+ * (strict '>' in __topk, topKmetrics.py:59,68).  out_scores/out_index: (U x k). */
+int brTopKRows(const float* scores, int64_t n_users, int64_t n_items, int k, float* out_scores,
+               int32_t* out_index, brStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BINREC_H */

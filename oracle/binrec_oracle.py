@@ -1,0 +1,543 @@
+"""CPU ORACLE (test infrastructure only) for the NeuMF / BPR / TwoTower hot path.
+
+PARITY UNPINNED: the reference (leotimus/binary-recommendation) delegates every
+arithmetic op on this path to un-vendored `tensorflow>=2.3.1` (requirements.txt:1)
+and an unpinned `tensorflow_recommenders` (trainers/twoTower.py:10); its test/
+scripts hold no assertion, seed, fixture or golden vector.
+This file is therefore a restatement, written by this build, of the algorithm the
+reference *declares* plus the TF-2.3-era Keras semantics it relies on ([TF-sem]).
+It is cross-checked against torch-CPU autograd (oracle/torch_ref.py), not against
+the reference itself.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module. The product package never does.
+
+Everything is plain numpy; `dt` selects float64 (tolerance anchor) or float32
+(bit-level anchor for sequentially-ordered sums such as the duplicate-id
+segment sum).
+
+Reference call sites restated here (path:line under /root/reference):
+  NeuMF-A graph .............. trainers/NFC_plain.py:107-155, fit :165
+  NeuMF-B graph .............. src/models/NeuMFModel.py:53-100
+  NeuMF-B negative sampler ... src/models/NeuMFModel.py:102-123
+  BPR triplet loss ........... src/models/BPRModel.py:49-74,124-144 ; src/models/bpr.py:141-157
+  bpr_predict ................ src/models/bpr.py:122-133
+  TwoTower ................... trainers/twoTower.py:19-111
+  top-k + HR@k ............... trainers/topKmetrics.py:51-99
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------
+# Philox4x32-10 counter RNG: the dropout-mask definition shared (bit-exactly)
+# with csrc/philox.h.  Keras' own dropout stream (NFC_plain.py:138,141,144;
+# NeuMFModel.py:67,71,75) is a stateful TF generator that cannot be reproduced,
+# so the build defines its own: element (row r, col c) of dropout site `site`
+# at optimizer step `step` is KEPT iff
+#     philox(key=(seed_lo, seed_hi), ctr=(r, c>>2, site, step))[c & 3] >= floor(p * 2^32)
+# ----------------------------------------------------------------------------
+PHILOX_M0 = np.uint64(0xD2511F53)
+PHILOX_M1 = np.uint64(0xCD9E8D57)
+PHILOX_W0 = np.uint64(0x9E3779B9)
+PHILOX_W1 = np.uint64(0xBB67AE85)
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10. All inputs uint32-valued arrays (broadcastable)."""
+    c0 = np.asarray(c0, dtype=np.uint64) & _MASK32
+    c1 = np.asarray(c1, dtype=np.uint64) & _MASK32
+    c2 = np.asarray(c2, dtype=np.uint64) & _MASK32
+    c3 = np.asarray(c3, dtype=np.uint64) & _MASK32
+    k0 = np.uint64(k0) & _MASK32
+    k1 = np.uint64(k1) & _MASK32
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    for _ in range(10):
+        p0 = PHILOX_M0 * c0
+        p1 = PHILOX_M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        n0 = (hi1 ^ c1 ^ k0) & _MASK32
+        n1 = lo1
+        n2 = (hi0 ^ c3 ^ k1) & _MASK32
+        n3 = lo0
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + PHILOX_W0) & _MASK32
+        k1 = (k1 + PHILOX_W1) & _MASK32
+    return (c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32))
+
+
+def dropout_threshold(p: float) -> int:
+    """u32 draw < threshold  => element dropped."""
+    return int(np.floor(float(p) * 4294967296.0))
+
+
+def dropout_mask(seed: int, step: int, site: int, nrows: int, ncols: int, p: float, row0: int = 0):
+    """(nrows, ncols) bool keep-mask. row0 = global row offset (data-parallel shards
+    draw the mask of their *global* batch rows, so 1-GPU == N-GPU)."""
+    if p <= 0.0:
+        return np.ones((nrows, ncols), dtype=bool)
+    r = (np.arange(nrows, dtype=np.uint64) + np.uint64(row0))[:, None]
+    c = np.arange(ncols, dtype=np.uint64)[None, :]
+    out = philox4x32_10(r, c >> np.uint64(2), np.uint64(site), np.uint64(step),
+                        seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    lane = (c & np.uint64(3)).astype(np.int64)
+    lane = np.broadcast_to(lane, (nrows, ncols))
+    stacked = np.stack(out, axis=-1)  # (nrows, ncols, 4)
+    draw = np.take_along_axis(stacked, lane[..., None], axis=-1)[..., 0]
+    return draw >= np.uint32(min(dropout_threshold(p), 0xFFFFFFFF))
+
+
+# ----------------------------------------------------------------------------
+# G1 gather / M1 dot / S1 scatter
+# ----------------------------------------------------------------------------
+def gather_rows(table, ids):
+    """out[b,:] = table[ids[b],:]  — Embedding lookup (NFC_plain.py:115-126,
+    NeuMFModel.py:58-63, BPRModel.py:55-60, twoTower.py:34,36). Bit-exact row copy.
+    Out-of-range ids raise (TF-CPU raises InvalidArgument [TF-sem])."""
+    ids = np.asarray(ids)
+    if ids.size and (ids.min() < 0 or ids.max() >= table.shape[0]):
+        raise IndexError("embedding id out of range")
+    return table[ids.astype(np.int64)]
+
+
+def row_dot(a, b):
+    """Dot(axes=1) (NFC_plain.py:148, NeuMFModel.py:79) — (B,D),(B,D)->(B,)."""
+    return np.sum(a * b, axis=1)
+
+
+def dedup_rows_sequential(ids, rows, dt=np.float32):
+    """[TF-sem] optimizer `_deduplicate_indexed_slices`: unique ids, duplicates summed.
+    Sum order = ascending batch position (what a sequential unsorted_segment_sum does);
+    returned sorted by id.  In float32 this is the bit-level anchor for the HIP
+    sort + ordered segment-sum kernel."""
+    ids = np.asarray(ids).astype(np.int64)
+    rows = np.asarray(rows, dtype=dt)
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    uniq, start = np.unique(sid, return_index=True)
+    out = np.zeros((len(uniq), rows.shape[1]), dtype=dt)
+    ends = list(start[1:]) + [len(sid)]
+    for k, (s, e) in enumerate(zip(start, ends)):
+        acc = rows[order[s]].astype(dt).copy()
+        for j in range(s + 1, e):
+            acc = (acc + rows[order[j]]).astype(dt)
+        out[k] = acc
+    return uniq, out
+
+
+def scatter_add_dense(nrows, ids, rows, dt=np.float64):
+    """g_table[ids[b],:] += rows[b,:] (np.add.at) — dense view of the same sum."""
+    g = np.zeros((nrows, rows.shape[1]), dtype=dt)
+    np.add.at(g, np.asarray(ids).astype(np.int64), rows.astype(dt))
+    return g
+
+
+# ----------------------------------------------------------------------------
+# activations / losses
+# ----------------------------------------------------------------------------
+def sigmoid(x):
+    x = np.asarray(x)
+    e = np.exp(-np.abs(x))
+    return np.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e)).astype(x.dtype)
+
+
+def act_fwd(z, act):
+    if act == "sigmoid":
+        return sigmoid(z)
+    if act == "relu":
+        return np.maximum(z, 0).astype(z.dtype)
+    if act == "linear":
+        return z
+    raise ValueError(act)
+
+
+def act_bwd_from_out(a, act):
+    """d act / d z expressed with the activation OUTPUT a (what the kernels keep)."""
+    if act == "sigmoid":
+        return a * (1 - a)
+    if act == "relu":
+        return (a > 0).astype(a.dtype)
+    if act == "linear":
+        return np.ones_like(a)
+    raise ValueError(act)
+
+
+def bce_from_logits(z, y):
+    """[TF-sem] Keras BinaryCrossentropy on a terminal Sigmoid in graph mode
+    (NFC_plain.py:152-155; twoTower.py:86-87,209): max(z,0) - z*y + log1p(exp(-|z|)),
+    mean over batch.  Returns (loss, dloss/dz)."""
+    B = z.shape[0]
+    per = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
+    return per.mean(dtype=z.dtype), ((sigmoid(z) - y) / B).astype(z.dtype)
+
+
+def mse_on_sigmoid(z, y):
+    """'mean_squared_error' on sigmoid output (NeuMFModel.py:83,90). (loss, dloss/dz)."""
+    B = z.shape[0]
+    p = sigmoid(z)
+    return ((p - y) ** 2).mean(dtype=z.dtype), (2.0 * (p - y) * p * (1 - p) / B).astype(z.dtype)
+
+
+# ----------------------------------------------------------------------------
+# NeuMF (variants A = trainers/NFC_plain.py, B = src/models/NeuMFModel.py)
+# ----------------------------------------------------------------------------
+class NeuMFSpec:
+    """One parametrisation covering both reference graphs."""
+
+    def __init__(self, variant="A", dim=10, hidden=None, dropout=0.2, bn_eps=1e-3, bn_momentum=0.99):
+        assert variant in ("A", "B")
+        self.variant = variant
+        self.dim = dim
+        if variant == "A":
+            # NFC_plain.py:137 concat [item_mlp, user_mlp]; :139,142,147 Dense 100/50/10 sigmoid;
+            # :148 Dot([item_mf,user_mf]); :149 concat [pred_mf, pred_mlp]; :155 BCE.
+            self.hidden = tuple(hidden) if hidden else (100, 50, 10)
+            self.act = "sigmoid"
+            self.mlp_concat = ("item", "user")
+            self.head_concat = ("mf", "mlp")
+            self.loss = "bce"
+        else:
+            # NeuMFModel.py:66 concat [user_mlp,item_mlp]; :69,73,78 Dense F, F//2, F//4 relu;
+            # :79 Dot([user_mf,item_mf]); :80 concat [mlp, mf]; :90 MSE.
+            self.hidden = tuple(hidden) if hidden else (dim, dim // 2, dim // 4)
+            self.act = "relu"
+            self.mlp_concat = ("user", "item")
+            self.head_concat = ("mlp", "mf")
+            self.loss = "mse"
+        self.dropout = dropout
+        self.bn_eps = bn_eps
+        self.bn_momentum = bn_momentum
+
+    @property
+    def dense_shapes(self):
+        n1, n2, n3 = self.hidden
+        return {"W1": (2 * self.dim, n1), "b1": (n1,), "g1": (n1,), "be1": (n1,),
+                "W2": (n1, n2), "b2": (n2,), "g2": (n2,), "be2": (n2,),
+                "W3": (n2, n3), "b3": (n3,), "W4": (n3 + 1,), "b4": (1,)}
+
+
+DENSE_ORDER = ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "W3", "b3", "W4", "b4")
+
+
+def neumf_init(spec, num_user_rows, num_item_rows, seed=0, dt=np.float32):
+    """[TF-sem] Keras defaults: Embedding U(-0.05,0.05); Dense glorot-uniform, bias 0;
+    BN gamma 1, beta 0, moving mean 0, moving var 1.  (numpy RNG: the reference has no seed
+    on this path, so only the *distribution* is restated.)"""
+    rng = np.random.default_rng(seed)
+    D = spec.dim
+    p = {}
+    for name, rows in (("user_mlp", num_user_rows), ("item_mlp", num_item_rows),
+                       ("user_mf", num_user_rows), ("item_mf", num_item_rows)):
+        p[name] = rng.uniform(-0.05, 0.05, size=(rows, D)).astype(dt)
+    for k, shp in spec.dense_shapes.items():
+        if k.startswith("W"):
+            fan_in, fan_out = (shp[0], shp[1]) if len(shp) == 2 else (shp[0], 1)
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            p[k] = rng.uniform(-lim, lim, size=shp).astype(dt)
+        elif k.startswith("g"):
+            p[k] = np.ones(shp, dtype=dt)
+        else:
+            p[k] = np.zeros(shp, dtype=dt)
+    n1, n2, _ = spec.hidden
+    p["mm1"], p["mv1"] = np.zeros(n1, dt), np.ones(n1, dt)
+    p["mm2"], p["mv2"] = np.zeros(n2, dt), np.ones(n2, dt)
+    return p
+
+
+def _bn_train(a, gamma, beta, eps):
+    mu = a.mean(axis=0)
+    var = ((a - mu) ** 2).mean(axis=0)  # biased batch variance [TF-sem]
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (a - mu) * rstd
+    return gamma * xhat + beta, (mu, var, rstd, xhat)
+
+
+def neumf_forward(spec, p, users, items, training=False, masks=None, dt=np.float64):
+    """Forward pass. masks = (m0,m1,m2) bool keep-masks for the three Dropout sites
+    (training only; None => no dropout).  Returns dict of every intermediate."""
+    f = lambda x: np.asarray(x, dtype=dt)
+    keep = 1.0 - spec.dropout
+    e = {"user_mlp": f(gather_rows(p["user_mlp"], users)), "item_mlp": f(gather_rows(p["item_mlp"], items)),
+         "user_mf": f(gather_rows(p["user_mf"], users)), "item_mf": f(gather_rows(p["item_mf"], items))}
+    x0 = np.concatenate([e[spec.mlp_concat[0] + "_mlp"], e[spec.mlp_concat[1] + "_mlp"]], axis=1)
+    c = {"e": e, "x0": x0}
+
+    def drop(x, i):
+        if training and masks is not None and masks[i] is not None:
+            return x * masks[i].astype(dt) * dt(1.0 / keep)
+        return x
+
+    x0d = drop(x0, 0)
+    z1 = x0d @ f(p["W1"]) + f(p["b1"]); a1 = act_fwd(z1, spec.act)
+    if training:
+        h1, bn1 = _bn_train(a1, f(p["g1"]), f(p["be1"]), dt(spec.bn_eps))
+    else:
+        rstd = 1.0 / np.sqrt(f(p["mv1"]) + dt(spec.bn_eps))
+        h1, bn1 = f(p["g1"]) * (a1 - f(p["mm1"])) * rstd + f(p["be1"]), None
+    x1d = drop(h1, 1)
+    z2 = x1d @ f(p["W2"]) + f(p["b2"]); a2 = act_fwd(z2, spec.act)
+    if training:
+        h2, bn2 = _bn_train(a2, f(p["g2"]), f(p["be2"]), dt(spec.bn_eps))
+    else:
+        rstd = 1.0 / np.sqrt(f(p["mv2"]) + dt(spec.bn_eps))
+        h2, bn2 = f(p["g2"]) * (a2 - f(p["mm2"])) * rstd + f(p["be2"]), None
+    x2d = drop(h2, 2)
+    z3 = x2d @ f(p["W3"]) + f(p["b3"]); a3 = act_fwd(z3, spec.act)
+    dot = row_dot(e["user_mf"], e["item_mf"])
+    if spec.head_concat[0] == "mf":
+        comb = np.concatenate([dot[:, None], a3], axis=1)
+    else:
+        comb = np.concatenate([a3, dot[:, None]], axis=1)
+    z = comb @ f(p["W4"]) + f(p["b4"])[0]
+    c.update(x0d=x0d, a1=a1, bn1=bn1, h1=h1, x1d=x1d, a2=a2, bn2=bn2, h2=h2, x2d=x2d, a3=a3,
+             dot=dot, comb=comb, logit=z, prob=sigmoid(z))
+    return c
+
+
+def neumf_loss(spec, z, y):
+    return bce_from_logits(z, y) if spec.loss == "bce" else mse_on_sigmoid(z, y)
+
+
+def _bn_bwd(dh, gamma, bn):
+    mu, var, rstd, xhat = bn
+    dgamma = (dh * xhat).sum(axis=0)
+    dbeta = dh.sum(axis=0)
+    B = dh.shape[0]
+    da = (gamma * rstd) * (dh - dbeta / B - xhat * (dgamma / B))
+    return da, dgamma, dbeta
+
+
+def neumf_step_grads(spec, p, users, items, labels, masks=None, dt=np.float64):
+    """One training forward + analytic backward (B1). Returns (loss, cache, dense_grads dict,
+    row_grads dict name->(B,D) aligned with the batch, new BN moving stats)."""
+    f = lambda x: np.asarray(x, dtype=dt)
+    keep = 1.0 - spec.dropout
+    c = neumf_forward(spec, p, users, items, training=True, masks=masks, dt=dt)
+    y = f(labels)
+    loss, dz = neumf_loss(spec, c["logit"], y)
+    g = {}
+    W4 = f(p["W4"])
+    g["W4"] = c["comb"].T @ dz
+    g["b4"] = np.array([dz.sum()], dtype=dt)
+    dcomb = dz[:, None] * W4[None, :]
+    if spec.head_concat[0] == "mf":
+        ddot, da3 = dcomb[:, 0], dcomb[:, 1:]
+    else:
+        da3, ddot = dcomb[:, :-1], dcomb[:, -1]
+
+    def undrop(dx, i):
+        if masks is not None and masks[i] is not None:
+            return dx * masks[i].astype(dt) * dt(1.0 / keep)
+        return dx
+
+    dz3 = da3 * act_bwd_from_out(c["a3"], spec.act)
+    g["W3"] = c["x2d"].T @ dz3; g["b3"] = dz3.sum(axis=0)
+    dh2 = undrop(dz3 @ f(p["W3"]).T, 2)
+    da2, g["g2"], g["be2"] = _bn_bwd(dh2, f(p["g2"]), c["bn2"])
+    dz2 = da2 * act_bwd_from_out(c["a2"], spec.act)
+    g["W2"] = c["x1d"].T @ dz2; g["b2"] = dz2.sum(axis=0)
+    dh1 = undrop(dz2 @ f(p["W2"]).T, 1)
+    da1, g["g1"], g["be1"] = _bn_bwd(dh1, f(p["g1"]), c["bn1"])
+    dz1 = da1 * act_bwd_from_out(c["a1"], spec.act)
+    g["W1"] = c["x0d"].T @ dz1; g["b1"] = dz1.sum(axis=0)
+    dx0 = undrop(dz1 @ f(p["W1"]).T, 0)
+    D = spec.dim
+    rg = {spec.mlp_concat[0] + "_mlp": dx0[:, :D], spec.mlp_concat[1] + "_mlp": dx0[:, D:],
+          "user_mf": ddot[:, None] * c["e"]["item_mf"], "item_mf": ddot[:, None] * c["e"]["user_mf"]}
+    mom = dt(spec.bn_momentum)
+    new_stats = {"mm1": f(p["mm1"]) * mom + c["bn1"][0] * (1 - mom), "mv1": f(p["mv1"]) * mom + c["bn1"][1] * (1 - mom),
+                 "mm2": f(p["mm2"]) * mom + c["bn2"][0] * (1 - mom), "mv2": f(p["mv2"]) * mom + c["bn2"][1] * (1 - mom)}
+    return loss, c, g, rg, new_stats
+
+
+def keras_metrics(prob, y):
+    """RModel.METRICS = ['mse','mae','binary_accuracy'] (RModel.py:20)."""
+    return {"mse": float(np.mean((prob - y) ** 2)), "mae": float(np.mean(np.abs(prob - y))),
+            "binary_accuracy": float(np.mean((prob > 0.5) == (y > 0.5)))}
+
+
+# ----------------------------------------------------------------------------
+# optimizers (O1 TF-form Adam, O2 Keras Adagrad)
+# ----------------------------------------------------------------------------
+def adam_alpha(lr, t, b1=0.9, b2=0.999):
+    """[TF-sem] alpha_t = lr*sqrt(1-b2^t)/(1-b1^t), t = 1 on the first step."""
+    return lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+
+
+def adam_dense(theta, m, v, g, lr, t, b1=0.9, b2=0.999, eps=1e-7, dt=np.float64):
+    """[TF-sem] Keras Adam: eps OUTSIDE the bias correction (!= torch.optim.Adam)."""
+    a = dt(adam_alpha(lr, t, b1, b2))
+    m = (dt(b1) * m + dt(1 - b1) * g).astype(dt)
+    v = (dt(b2) * v + dt(1 - b2) * g * g).astype(dt)
+    theta = (theta - a * m / (np.sqrt(v) + dt(eps))).astype(dt)
+    return theta, m, v
+
+
+def adam_sparse_tf(theta, m, v, ids, row_grads, lr, t, lazy=False, b1=0.9, b2=0.999, eps=1e-7, dt=np.float64):
+    """[TF-sem] Keras Adam `_resource_apply_sparse` after `_deduplicate_indexed_slices`:
+    duplicates summed FIRST (so v gets (sum g)^2), then m,v decayed over the WHOLE table and
+    the WHOLE table updated (non-lazy).  lazy=True touches only the gathered rows
+    (documented throughput deviation, not the reference's semantics)."""
+    theta, m, v = theta.astype(dt).copy(), m.astype(dt).copy(), v.astype(dt).copy()
+    uniq, gs = dedup_rows_sequential(ids, row_grads, dt=dt)
+    if lazy:
+        theta[uniq], m[uniq], v[uniq] = adam_dense(theta[uniq], m[uniq], v[uniq], gs, lr, t, b1, b2, eps, dt)
+        return theta, m, v
+    g = np.zeros_like(theta)
+    g[uniq] = gs
+    return adam_dense(theta, m, v, g, lr, t, b1, b2, eps, dt)
+
+
+def adagrad_dense(theta, acc, g, lr, eps=1e-7, dt=np.float64):
+    """[TF-sem] Keras Adagrad (initial_accumulator_value 0.1): acc += g^2 ; theta -= lr*g/(sqrt(acc)+eps)."""
+    acc = (acc + g * g).astype(dt)
+    theta = (theta - dt(lr) * g / (np.sqrt(acc) + dt(eps))).astype(dt)
+    return theta, acc
+
+
+def adagrad_sparse(theta, acc, ids, row_grads, lr, eps=1e-7, dt=np.float64):
+    """Sparse apply touches only the (deduplicated) rows [TF-sem]."""
+    theta, acc = theta.astype(dt).copy(), acc.astype(dt).copy()
+    uniq, gs = dedup_rows_sequential(ids, row_grads, dt=dt)
+    theta[uniq], acc[uniq] = adagrad_dense(theta[uniq], acc[uniq], gs, lr, eps, dt)
+    return theta, acc
+
+
+# ----------------------------------------------------------------------------
+# BPR (src/models/BPRModel.py:49-74,124-144; src/models/bpr.py:141-157)
+# ----------------------------------------------------------------------------
+def bpr_step_grads(user_table, item_table, u, pos, neg, dt=np.float64):
+    """x = u.p - u.n ; l = 1 - sigmoid(x) (NOT -log sigmoid: BPRModel.py:144); loss = mean l
+    (identityLoss, BPRModel.py:124-126).  Returns loss, per-triplet l, row grads (gu,gp,gn)."""
+    f = lambda x: np.asarray(x, dtype=dt)
+    eu, ep, en = f(gather_rows(user_table, u)), f(gather_rows(item_table, pos)), f(gather_rows(item_table, neg))
+    x = row_dot(eu, ep) - row_dot(eu, en)
+    s = sigmoid(x)
+    l = 1.0 - s
+    B = x.shape[0]
+    dx = (-s * (1.0 - s) / B).astype(dt)
+    gu = dx[:, None] * (ep - en)
+    gp = dx[:, None] * eu
+    gn = -dx[:, None] * eu
+    return l.mean(dtype=dt), l, (gu, gp, gn)
+
+
+def bpr_predict(user_table, item_table, user_id, item_ids):
+    """scores = user_vector . item_matrix^T (src/models/bpr.py:122-133)."""
+    return item_table[np.asarray(item_ids)] @ user_table[user_id]
+
+
+# ----------------------------------------------------------------------------
+# TwoTower (trainers/twoTower.py:19-111)
+# ----------------------------------------------------------------------------
+MIN_FLOAT = float(np.finfo(np.float32).min) / 100.0  # [TF-sem] tfrs RemoveAccidentalHits
+
+
+def twotower_embed(p, users, items, dt=np.float64):
+    """computeEmb (twoTower.py:77-80): Embedding -> Dense(semb) linear (twoTower.py:40-41)."""
+    f = lambda x: np.asarray(x, dtype=dt)
+    eu, ei = f(gather_rows(p["user_emb"], users)), f(gather_rows(p["item_emb"], items))
+    q = eu @ f(p["Wu"]) + f(p["bu"])
+    c = ei @ f(p["Wi"]) + f(p["bi"])
+    return eu, ei, q, c
+
+
+def inbatch_softmax_loss(q, c, cand_ids):
+    """[TF-sem, TFRS unpinned] tfrs.tasks.Retrieval(loss=None) with candidate_ids
+    (twoTower.py:47,82-83): S = q c^T, labels = I, accidental hits
+    (same candidate id, off-diagonal) get + MIN_FLOAT, loss = SUM_i [logsumexp_j S_ij - S_ii].
+    Returns loss, dq, dc."""
+    dt = q.dtype
+    S = q @ c.T
+    ids = np.asarray(cand_ids)
+    dup = (ids[:, None] == ids[None, :]).astype(dt) - np.eye(len(ids), dtype=dt)
+    S = (S + dup * MIN_FLOAT).astype(dt)
+    mx = S.max(axis=1, keepdims=True)
+    ex = np.exp(S - mx)
+    den = ex.sum(axis=1, keepdims=True)
+    lse = (mx + np.log(den))[:, 0]
+    loss = (lse - np.diag(S)).sum()
+    P = ex / den
+    dS = P - np.eye(len(ids), dtype=dt)
+    return loss, dS @ c, dS.T @ q
+
+
+def twotower_step_grads(p, users, items, labels=None, rd_zero=False, dt=np.float64):
+    """train_step (twoTower.py:89-102). rd_zero: sigmoid(dot(q,c)) + BCE (twoTower.py:85-87)."""
+    f = lambda x: np.asarray(x, dtype=dt)
+    eu, ei, q, c = twotower_embed(p, users, items, dt)
+    if rd_zero:
+        z = row_dot(q, c)
+        loss, dz = bce_from_logits(z, f(labels))
+        dq, dc = dz[:, None] * c, dz[:, None] * q
+    else:
+        loss, dq, dc = inbatch_softmax_loss(q, c, items)
+    g = {"Wu": eu.T @ dq, "bu": dq.sum(axis=0), "Wi": ei.T @ dc, "bi": dc.sum(axis=0)}
+    rg = {"user_emb": dq @ f(p["Wu"]).T, "item_emb": dc @ f(p["Wi"]).T}
+    return loss, (q, c), g, rg
+
+
+# ----------------------------------------------------------------------------
+# E1/E2: top-k and HR@k (trainers/topKmetrics.py:51-99)
+# ----------------------------------------------------------------------------
+def topk_reference_order(scores, item_ids, k):
+    """__topk/__insertSorted (topKmetrics.py:51-72) restated literally: seed with the first k,
+    stable-sort descending, then for each later item replace the tail iff STRICTLY greater
+    (ties keep the earlier item position) and insert before the first strictly-smaller entry
+    scanning from the tail (so among equals the newcomer lands AFTER)."""
+    l = [(float(s), i) for s, i in zip(scores, item_ids)]
+    res = l[:k]
+    res.sort(reverse=True, key=lambda x: x[0])
+    for i in range(k, len(l)):
+        if l[i][0] > res[-1][0]:
+            res.pop()
+            # __insertSorted: walk from the tail while the element above is < val
+            j = len(res)
+            cur = res[-1][0] if res else None
+            while j > 0 and cur < l[i][0]:
+                j -= 1
+                cur = res[j - 1][0]  # j==0 reads res[-1] like the reference; loop ends on j>0
+            res.insert(j, l[i])
+    return res
+
+
+def topk_metrics(predictions, positives, users_id, items_id):
+    """topKMetrics (topKmetrics.py:74-99): hitRate = hits / len(usersId) over ALL users."""
+    nbr_user, nbr_item = len(users_id), len(items_id)
+    total = nbr_user * nbr_item
+    real = set(positives)
+    tp = fp = hits = 0
+    for u, topk in predictions:
+        hit = False
+        for _r, i in topk:
+            if (u, i) in real:
+                tp += 1
+                hit = True
+            else:
+                fp += 1
+        if hit:
+            hits += 1
+    fn = len(real) - tp
+    tn = total - tp - fp - fn
+    return {"tp": tp, "tn": tn, "fp": fp, "fn": fn, "precision": tp / (tp + fp),
+            "recall": tp / (tp + fn), "hitRate": hits / nbr_user}
+
+
+# ----------------------------------------------------------------------------
+# negative sampling (NeuMFModel.bootstrapDataset, NeuMFModel.py:102-123)
+# ----------------------------------------------------------------------------
+def bootstrap_negatives(users, items, neg_ratio=3.0, seed=0):
+    """posDf + negDf: sample rows with replacement (frac=negRatio), permute the item column of
+    the sample, label 0; no collision check (NeuMFModel.py:103-109).  numpy RNG stands in for
+    pandas' (the reference is unseeded)."""
+    rng = np.random.default_rng(seed)
+    n = len(users)
+    k = int(round(neg_ratio * n))
+    pick = rng.integers(0, n, size=k)
+    nu, ni = users[pick], items[pick][rng.permutation(k)]
+    U = np.concatenate([users, nu]); I = np.concatenate([items, ni])
+    Y = np.concatenate([np.ones(n, np.float32), np.zeros(k, np.float32)])
+    perm = rng.permutation(n + k)
+    return U[perm], I[perm], Y[perm]

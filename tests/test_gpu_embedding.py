@@ -1,0 +1,121 @@
+"""-m gpu parity: G1 gather (bit-exact), M1 dot, NeuMF embed block, L3 BPR fused step.
+All calls go through the C-ABI (libbinrec_hip.so); the checker is oracle/binrec_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import binrec_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from importlib import import_module
+    return import_module("binary-recommendation_amd.ops")
+
+
+def _mk(rng, rows, dim, dev):
+    t = rng.uniform(-0.05, 0.05, size=(rows, dim)).astype(np.float32)
+    return t, torch.from_numpy(t).to(dev)
+
+
+@pytest.mark.parametrize("dim", [64, 128, 10, 75, 8, 32, 350])
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_gather_bit_exact(dev, dim, idt):
+    ops = _ops()
+    rng = np.random.default_rng(dim)
+    B = 1000 + dim  # ragged vs the 256-thread tiling
+    tabs = [_mk(rng, r, dim, dev) for r in (977, 53, 977, 53, 11)]
+    ids_np = [rng.integers(0, t[0].shape[0], size=B) for t in tabs]
+    ids_np[1][:7] = ids_np[1][0]  # duplicates
+    ids = [torch.from_numpy(i).to(dev).to(idt) for i in ids_np]
+    flag = ops.new_err_flag(dev)
+    outs = ops.gather_rows([t[1] for t in tabs], ids, err_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    for (tn, _), i, o in zip(tabs, ids_np, outs):
+        ref = O.gather_rows(tn, i)
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_gather_empty_and_oob(dev):
+    ops = _ops()
+    rng = np.random.default_rng(0)
+    tn, t = _mk(rng, 97, 64, dev)
+    outs = ops.gather_rows([t], [torch.empty(0, dtype=torch.int32, device=dev)])
+    assert outs[0].shape == (0, 64)
+    ids = torch.tensor([3, 97, -1, 5], dtype=torch.int32, device=dev)
+    flag = ops.new_err_flag(dev)
+    outs = ops.gather_rows([t], [ids], err_flag=flag)
+    torch.cuda.synchronize()
+    o = outs[0].cpu().numpy()
+    assert np.array_equal(o[0], tn[3]) and np.array_equal(o[3], tn[5])
+    assert not o[1].any() and not o[2].any()  # skipped, never faulted
+    with pytest.raises(IndexError):
+        ops.raise_if_flag(flag)
+    with pytest.raises(IndexError):
+        O.gather_rows(tn, np.array([3, 97]))
+
+
+@pytest.mark.parametrize("dim", [64, 10, 75])
+def test_row_dot_and_backward(dev, dim):
+    ops = _ops()
+    rng = np.random.default_rng(1)
+    B = 513
+    a, ad = _mk(rng, B, dim, dev)
+    b, bd = _mk(rng, B, dim, dev)
+    out = ops.row_dot(ad, bd).cpu().numpy()
+    ref = O.row_dot(a.astype(np.float64), b.astype(np.float64))
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-7)
+    g = rng.normal(size=B).astype(np.float32)
+    da, db = ops.row_dot_backward(ad, bd, torch.from_numpy(g).to(dev))
+    np.testing.assert_allclose(da.cpu().numpy(), g[:, None] * b, rtol=1e-6, atol=0)
+    np.testing.assert_allclose(db.cpu().numpy(), g[:, None] * a, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("dim,item_first", [(64, 1), (64, 0), (10, 1), (32, 0)])
+def test_neumf_embed_block(dev, dim, item_first):
+    ops = _ops()
+    rng = np.random.default_rng(2)
+    B, U, I = 777, 97, 53
+    um, umd = _mk(rng, U, dim, dev); im, imd = _mk(rng, I, dim, dev)
+    uf, ufd = _mk(rng, U, dim, dev); vf, vfd = _mk(rng, I, dim, dev)
+    u = rng.integers(0, U, B); i = rng.integers(0, I, B)
+    ud, idd = torch.from_numpy(u).to(dev).int(), torch.from_numpy(i).to(dev).int()
+    x0 = torch.empty(B, 2 * dim, device=dev); dot = torch.empty(B, device=dev)
+    ops.neumf_embed_forward(umd, imd, ufd, vfd, ud, idd, item_first, x0, dot)
+    first, second = (im[i], um[u]) if item_first else (um[u], im[i])
+    assert np.array_equal(x0.cpu().numpy(), np.concatenate([first, second], axis=1))  # gather part bit-exact
+    np.testing.assert_allclose(dot.cpu().numpy(), O.row_dot(uf[u].astype(np.float64), vf[i].astype(np.float64)), rtol=1e-5, atol=1e-8)
+    # backward
+    dx0 = rng.normal(size=(B, 2 * dim)).astype(np.float32); dd = rng.normal(size=B).astype(np.float32)
+    g = [torch.empty(B, dim, device=dev) for _ in range(4)]
+    ops.neumf_embed_backward(ufd, vfd, ud, idd, item_first, torch.from_numpy(dx0).to(dev), torch.from_numpy(dd).to(dev),
+                             g[2], g[3], g[0], g[1])
+    uo, io = (dim, 0) if item_first else (0, dim)
+    assert np.array_equal(g[0].cpu().numpy(), dx0[:, uo:uo + dim])
+    assert np.array_equal(g[1].cpu().numpy(), dx0[:, io:io + dim])
+    np.testing.assert_allclose(g[2].cpu().numpy(), dd[:, None] * vf[i], rtol=1e-6)
+    np.testing.assert_allclose(g[3].cpu().numpy(), dd[:, None] * uf[u], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dim", [64, 32, 350, 10])
+def test_bpr_fused_step(dev, dim):
+    """BPRModel.py:128-144 triplet loss 1 - sigmoid(u.p - u.n) and its row gradients."""
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    B, U, I = 1001, 211, 89
+    ut = rng.normal(0, 0.3, size=(U, dim)).astype(np.float32)
+    it = rng.normal(0, 0.3, size=(I, dim)).astype(np.float32)
+    u = rng.integers(0, U, B); p = rng.integers(0, I, B); n = rng.integers(0, I, B)
+    td = lambda a: torch.from_numpy(a).to(dev)
+    loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+    gu = torch.empty(B, dim, device=dev); gi = torch.empty(2 * B, dim, device=dev); per = torch.empty(B, device=dev)
+    ops.bpr_forward_backward(td(ut), td(it), td(u).int(), td(p).int(), td(n).int(), 1.0 / B, loss_sum, gu, gi, per)
+    loss, l, (rgu, rgp, rgn) = O.bpr_step_grads(ut, it, u, p, n, dt=np.float64)
+    assert abs(loss_sum.item() / B - loss) <= 1e-5 * abs(loss)
+    np.testing.assert_allclose(per.cpu().numpy(), l, rtol=1e-5, atol=1e-7)
+    scale = np.abs(rgu).max()
+    np.testing.assert_allclose(gu.cpu().numpy(), rgu, rtol=1e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(gi[:B].cpu().numpy(), rgp, rtol=1e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(gi[B:].cpu().numpy(), rgn, rtol=1e-5, atol=1e-6 * scale)

@@ -1,0 +1,113 @@
+"""-m gpu parity: S1 sort-index + ordered segment sum (bit-exact vs a sequential fp32
+unsorted_segment_sum), O1 TF-form Adam (lazy rows / dense non-lazy), O2 Adagrad."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import binrec_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from importlib import import_module
+    return import_module("binary-recommendation_amd.ops")
+
+
+def _dup_ids(rng, n, rows):
+    ids = rng.integers(0, rows, size=n)
+    ids[: n // 4] = rng.integers(0, 5, size=n // 4)  # heavy head: long duplicate segments
+    return ids
+
+
+@pytest.mark.parametrize("dim", [64, 10, 75])
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_segment_sum_bit_exact(dev, dim, idt):
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    n, rows = 3001, 400
+    ids = _dup_ids(rng, n, rows)
+    g = rng.normal(size=(n, dim)).astype(np.float32)
+    idx = ops.RowIndex(n, idt, dev).build(torch.from_numpy(ids).to(dev).to(idt), rows)
+    out, head = ops.segment_sum_rows(idx, torch.from_numpy(g).to(dev))
+    torch.cuda.synchronize()
+    sid = idx.sorted_ids.cpu().numpy(); spos = idx.sorted_pos.cpu().numpy()
+    order = np.argsort(ids, kind="stable")
+    assert np.array_equal(sid, ids[order]) and np.array_equal(spos, order)  # stable sort
+    uniq, ref = O.dedup_rows_sequential(ids, g, dt=np.float32)
+    h = head.cpu().numpy().astype(bool)
+    assert np.array_equal(sid[h], uniq)
+    assert np.array_equal(out.cpu().numpy()[h].view(np.uint32), ref.view(np.uint32))  # same order => same bits
+
+
+def test_scatter_add_atomic(dev):
+    ops = _ops()
+    rng = np.random.default_rng(6)
+    n, rows, dim = 2000, 300, 64
+    ids = _dup_ids(rng, n, rows)
+    g = rng.normal(size=(n, dim)).astype(np.float32)
+    gt = torch.zeros(rows, dim, device=dev)
+    ops.scatter_add_rows(gt, torch.from_numpy(ids).to(dev).int(), torch.from_numpy(g).to(dev))
+    ref = O.scatter_add_dense(rows, ids, g)
+    np.testing.assert_allclose(gt.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dim", [64, 10])
+@pytest.mark.parametrize("lazy", [True, False])
+def test_adam_sparse_tf_form(dev, dim, lazy):
+    """3 steps of Keras Adam on an embedding table with duplicate ids; non-lazy = whole-table
+    m/v decay + update ([TF-sem])."""
+    ops = _ops()
+    rng = np.random.default_rng(7)
+    rows, n, lr = 500, 1200, 0.005
+    th = rng.uniform(-0.05, 0.05, size=(rows, dim)).astype(np.float32)
+    m = np.zeros_like(th); v = np.zeros_like(th)
+    td = lambda a: torch.from_numpy(a.copy()).to(dev)
+    thd, md, vd = td(th), td(m), td(v)
+    mark = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    idx = ops.RowIndex(n, torch.int32, dev)
+    th64, m64, v64 = th.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in range(1, 4):
+        ids = _dup_ids(rng, n, rows)
+        g = rng.normal(scale=1e-2, size=(n, dim)).astype(np.float32)
+        idx.build(td(ids).int(), rows)
+        a = ops.adam_alpha(lr, t)
+        ops.adam_rows_sorted(thd, md, vd, idx, td(g), dim, a, mark=None if lazy else mark)
+        if not lazy:
+            ops.adam_dense_sweep(thd, md, vd, a, mark=mark)
+        th64, m64, v64 = O.adam_sparse_tf(th64, m64, v64, ids, g, lr, t, lazy=lazy, dt=np.float64)
+    torch.cuda.synchronize()
+    assert int(mark.sum().item()) == 0
+    np.testing.assert_allclose(thd.cpu().numpy(), th64, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(md.cpu().numpy(), m64, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(vd.cpu().numpy(), v64, rtol=1e-5, atol=1e-12)
+
+
+def test_adam_flat_and_adagrad(dev):
+    ops = _ops()
+    rng = np.random.default_rng(8)
+    n = 12345
+    th = rng.normal(size=n).astype(np.float32); g = rng.normal(size=n).astype(np.float32)
+    td = lambda a: torch.from_numpy(a.copy()).to(dev)
+    thd, md, vd = td(th), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    r = (th.astype(np.float64), np.zeros(n), np.zeros(n))
+    for t in (1, 2):
+        ops.adam_flat(thd, md, vd, td(g), ops.adam_alpha(1e-3, t))
+        r = O.adam_dense(*r, g.astype(np.float64), 1e-3, t)
+    np.testing.assert_allclose(thd.cpu().numpy(), r[0], rtol=1e-5, atol=1e-7)
+    # Adagrad flat + sparse rows (Keras: acc0 = 0.1, eps 1e-7)
+    acc = np.full(n, 0.1, np.float32)
+    thd, ad = td(th), td(acc)
+    ops.adagrad_flat(thd, ad, td(g), 0.1)
+    rt, ra = O.adagrad_dense(th.astype(np.float64), acc.astype(np.float64), g.astype(np.float64), 0.1)
+    np.testing.assert_allclose(thd.cpu().numpy(), rt, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ad.cpu().numpy(), ra, rtol=1e-6)
+    rows, dim, m = 300, 75, 900
+    tb = rng.normal(size=(rows, dim)).astype(np.float32); ac = np.full((rows, dim), 0.1, np.float32)
+    ids = _dup_ids(rng, m, rows); gg = rng.normal(size=(m, dim)).astype(np.float32)
+    tbd, acd = td(tb), td(ac)
+    idx = ops.RowIndex(m, torch.int64, dev).build(td(ids), rows)
+    ops.adagrad_rows_sorted(tbd, acd, idx, td(gg), dim, 0.1)
+    rt, ra = O.adagrad_sparse(tb, ac, ids, gg, 0.1, dt=np.float64)
+    np.testing.assert_allclose(tbd.cpu().numpy(), rt, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(acd.cpu().numpy(), ra, rtol=1e-5)
