@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_bwd_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) red[wave] = contrib;
   __syncthreads();
-  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum + (blockIdx.x & (BR_SUM_SLOTS - 1)), red[0] + red[1] + red[2] + red[3]);
 }
 
 }  // namespace br

@@ -213,3 +213,71 @@ def adagrad_flat(theta, acc, g, lr, eps=1e-7):
 def adam_alpha(lr: float, t: int, beta1=0.9, beta2=0.999) -> float:
     """[TF-sem] alpha_t = lr*sqrt(1-b2^t)/(1-b1^t) in double on the host."""
     return lr * (1.0 - beta2 ** t) ** 0.5 / (1.0 - beta1 ** t)
+
+
+# ------------------------------------------------------------------------------ T1-T4 MLP tower
+def dense_forward(x, W, bias, y, act, in_scale=None, in_shift=None, drop_p=0.0, seed=0, step=0, site=0, row0=0,
+                  stats=None, batch=None):
+    B = x.shape[0] if batch is None else batch
+    K, N = W.shape
+    check(_lib.load().brDenseForward(x.data_ptr(), x.stride(0), _f32(W, "W").data_ptr(), _p(bias), y.data_ptr(), y.stride(0),
+                                     B, K, N, ACT[act], _p(in_scale), _p(in_shift), float(drop_p), int(seed), int(step),
+                                     int(site), int(row0), _p(stats), _stream()), "brDenseForward")
+
+
+def bn_finalize(stats, batch_total, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd):
+    check(_lib.load().brBnFinalize(stats.data_ptr(), float(batch_total), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                   float(momentum), _p(moving_mean), _p(moving_var), scale.data_ptr(), shift.data_ptr(),
+                                   mean.data_ptr(), rstd.data_ptr(), gamma.numel(), _stream()), "brBnFinalize")
+
+
+def bn_inference(gamma, beta, moving_mean, moving_var, eps, scale, shift):
+    check(_lib.load().brBnInference(gamma.data_ptr(), beta.data_ptr(), moving_mean.data_ptr(), moving_var.data_ptr(),
+                                    float(eps), scale.data_ptr(), shift.data_ptr(), gamma.numel(), _stream()), "brBnInference")
+
+
+def dense_backward_slabs(batch, K, N) -> int:
+    return int(_lib.load().brDenseBackwardSlabs(batch, K, N))
+
+
+def dense_backward(gy, y, x, W, act, slabs, n_slabs, gx=None, out_bn=None, bn_sums=None, batch_total=None,
+                   in_scale=None, in_shift=None, in_bn=None, in_drop_p=0.0, in_site=0, seed=0, step=0, row0=0,
+                   in_bn_sums=None, batch=None):
+    """out_bn = (mean, rstd, gamma) of the BN after this layer; in_bn = (mean, rstd) of the BN before it."""
+    B = gy.shape[0] if batch is None else batch
+    K, N = W.shape
+    om, ors, og = out_bn if out_bn is not None else (None, None, None)
+    im, irs = in_bn if in_bn is not None else (None, None)
+    check(_lib.load().brDenseBackward(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0),
+                                      W.data_ptr(), B, K, N, ACT[act], _p(om), _p(ors), _p(og), _p(bn_sums),
+                                      float(batch_total if batch_total is not None else B), _p(in_scale), _p(in_shift),
+                                      _p(im), _p(irs), float(in_drop_p), int(in_site), int(seed), int(step), int(row0),
+                                      _p(gx), gx.stride(0) if gx is not None else 0, slabs.data_ptr(), int(n_slabs),
+                                      _p(in_bn_sums), _stream()), "brDenseBackward")
+
+
+def reduce_slabs(slabs, n_slabs, slab_elems, out):
+    check(_lib.load().brReduceSlabs(slabs.data_ptr(), int(n_slabs), int(slab_elems), out.data_ptr(), _stream()), "brReduceSlabs")
+
+
+def bn_param_grads(bn_sums, dgamma, dbeta):
+    check(_lib.load().brBnParamGrads(bn_sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dgamma.numel(), _stream()),
+          "brBnParamGrads")
+
+
+def head_slabs(batch) -> int:
+    return int(_lib.load().brHeadSlabs(batch))
+
+
+def neumf_head(a3, dot, labels, w4, b4, mf_first, loss, inv_batch, logit=None, prob=None, sums=None, da3=None, ddot=None,
+               slabs=None, n_slabs=0, batch=None):
+    B = dot.shape[0] if batch is None else batch
+    check(_lib.load().brNeumfHead(a3.data_ptr(), a3.stride(0), dot.data_ptr(), _p(labels), w4.data_ptr(), b4.data_ptr(), B,
+                                  a3.shape[1], int(mf_first), LOSS[loss], float(inv_batch), _p(logit), _p(prob), _p(sums),
+                                  _p(da3), da3.stride(0) if da3 is not None else 0, _p(ddot), _p(slabs), int(n_slabs),
+                                  _stream()), "brNeumfHead")
+
+
+def bce_logits(z, y, inv_batch, prob=None, dz=None, sums=None):
+    check(_lib.load().brBceLogits(z.data_ptr(), y.data_ptr(), z.shape[0], float(inv_batch), _p(prob), _p(dz), _p(sums),
+                                  _stream()), "brBceLogits")

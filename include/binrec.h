@@ -38,7 +38,7 @@ enum { BR_OK = 0, BR_ERR_ARG = -1, BR_ERR_HIP = -2, BR_ERR_UNSUPPORTED = -3, BR_
 enum { BR_IDS_I32 = 0, BR_IDS_I64 = 1 };
 enum { BR_ACT_LINEAR = 0, BR_ACT_SIGMOID = 1, BR_ACT_RELU = 2 };
 enum { BR_LOSS_BCE = 0, BR_LOSS_MSE = 1 };
-enum { BR_MAX_TABLES = 8 };
+enum { BR_MAX_TABLES = 8, BR_SUM_SLOTS = 64 };
 
 const char* brGetLastError(void);
 int brVersion(void);
@@ -78,8 +78,10 @@ int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t use
 /* ---- L3: BPR triplet step — BPRModel.py:49-74,124-144; bpr.py:141-157 -----------------------
  * x = u·p - u·n ; l = 1 - sigmoid(x) ; loss = mean(l).  One fused launch: 3 gathers, 2 dots,
  * loss partials, 3 row gradients.  g_item is (2B x dim): rows [0,B) = d/d pos, [B,2B) = d/d neg
- * (the shared item table's two IndexedSlices concatenated).  loss_sum: device double, += sum l.
- * per_triplet (B) may be NULL.  inv_batch = 1/global batch. */
+ * (the shared item table's two IndexedSlices concatenated).  loss_sum: device
+ * double[BR_SUM_SLOTS], slot (workgroup & 63) += sum l (same-address atomics serialise at
+ * ~12 ns each on MI355X; the caller adds the slots).  per_triplet (B) may be NULL.
+ * inv_batch = 1/global batch. */
 int brBprForwardBackward(const float* user_table, const float* item_table, int64_t user_rows,
                          int64_t item_rows, const void* users, const void* pos, const void* neg,
                          int id_type, int dim, int64_t batch, float inv_batch, float* per_triplet,
@@ -154,24 +156,29 @@ int brBnInference(const float* gamma, const float* beta, const float* moving_mea
                   const float* moving_var, float eps, float* scale, float* shift, int N,
                   brStream stream);
 /* Backward of one tower layer.
- *  gy: (B x N) gradient w.r.t. the layer's *consumer input* (i.e. w.r.t. dropout(BN(y))), or
- *      w.r.t. y itself when the layer has no BN/dropout after it (out_* NULL, out_drop_p 0).
+ *  gy: (B x N) gradient w.r.t. this layer's BatchNorm output h = BN(y) (dropout already
+ *      transposed by the consumer's backward), or w.r.t. y itself when no BN follows (out_* NULL).
  *  out BN (after this layer): out_mean/out_rstd/out_gamma (N) and bn_sums (double[2N]:
- *      sum_r dh, sum_r dh*xhat — produced by the consumer's backward, see in_bn_sums).
+ *      sum_r gy, sum_r gy*xhat — accumulated by the consumer's backward, see in_bn_sums).
+ *      da = gamma*rstd*(gy - mean(gy) - xhat*mean(gy*xhat)); dz = da*act'(y).
  *  in transform (before this layer) as in brDenseForward, plus in_mean/in_rstd (K) when the
- *      input carries a BN: then in_bn_sums (double[2K]) += (sum dh_in, sum dh_in*xhat_in).
- *  Outputs: gx (B x K) gradient w.r.t. T(x) (raw, the producer un-drops it); dW_slabs:
- *      (n_slabs x (K*N + N)) per-workgroup partials of [dW | db], reduced by brReduceSlabs in a
- *      fixed order (bitwise reproducible; no float atomics).  n_slabs = brDenseBackwardSlabs(). */
+ *      input carries a BN: then in_bn_sums (double[2K]) += (sum gx, sum gx*xhat_in).
+ *  Outputs: gx (B x K) = (dz·W^T) * keep(r,k)/(1-p): gradient w.r.t. the producer's BN output
+ *      (w.r.t. x itself when the input has no BN) — may be NULL for the first layer of a tower
+ *      whose input needs no gradient;  dW_slabs: (n_slabs x (K*N + N)) per-workgroup partials
+ *      of [dW | db], reduced by brReduceSlabs in a fixed order (bitwise reproducible; no float
+ *      atomics).  n_slabs = brDenseBackwardSlabs(). */
 int brDenseBackwardSlabs(int64_t batch, int K, int N);
 int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
                     int64_t ldx, const float* W, int64_t batch, int K, int N, int act,
                     const float* out_mean, const float* out_rstd, const float* out_gamma,
-                    const double* bn_sums, double batch_total, float out_drop_p,
-                    uint32_t out_site, const float* in_scale, const float* in_shift,
-                    const float* in_mean, const float* in_rstd, float in_drop_p, uint32_t in_site,
-                    uint64_t seed, uint32_t step, int64_t row0, float* gx, int64_t ldgx,
-                    float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream);
+                    const double* bn_sums, double batch_total, const float* in_scale,
+                    const float* in_shift, const float* in_mean, const float* in_rstd,
+                    float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0,
+                    float* gx, int64_t ldgx, float* dW_slabs, int n_slabs, double* in_bn_sums,
+                    brStream stream);
+/* dgamma = sum gy*xhat, dbeta = sum gy: the BN-backward column sums as fp32 parameter grads. */
+int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta, int N, brStream stream);
 int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* out, brStream stream);
 
 /* ---- head: concat [GMF dot | MLP out] -> Dense(1) -> sigmoid -> loss, and its backward --------

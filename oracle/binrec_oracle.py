@@ -346,6 +346,13 @@ def neumf_step_grads(spec, p, users, items, labels, masks=None, dt=np.float64):
     D = spec.dim
     rg = {spec.mlp_concat[0] + "_mlp": dx0[:, :D], spec.mlp_concat[1] + "_mlp": dx0[:, D:],
           "user_mf": ddot[:, None] * c["e"]["item_mf"], "item_mf": ddot[:, None] * c["e"]["user_mf"]}
+    # |summand| totals of every dense gradient: the scale fp32 rounding is relative to (several of
+    # these sums cancel almost completely, e.g. the pre-BN biases), used as test tolerances only.
+    A = np.abs
+    c["gabs"] = {"W4": A(c["comb"]).T @ A(dz), "b4": np.array([A(dz).sum()]),
+                 "W3": A(c["x2d"]).T @ A(dz3), "b3": A(dz3).sum(0), "g2": A(dh2 * c["bn2"][3]).sum(0), "be2": A(dh2).sum(0),
+                 "W2": A(c["x1d"]).T @ A(dz2), "b2": A(dz2).sum(0), "g1": A(dh1 * c["bn1"][3]).sum(0), "be1": A(dh1).sum(0),
+                 "W1": A(c["x0d"]).T @ A(dz1), "b1": A(dz1).sum(0)}
     mom = dt(spec.bn_momentum)
     new_stats = {"mm1": f(p["mm1"]) * mom + c["bn1"][0] * (1 - mom), "mv1": f(p["mv1"]) * mom + c["bn1"][1] * (1 - mom),
                  "mm2": f(p["mm2"]) * mom + c["bn2"][0] * (1 - mom), "mv2": f(p["mv2"]) * mom + c["bn2"][1] * (1 - mom)}

@@ -109,11 +109,11 @@ def test_bpr_fused_step(dev, dim):
     it = rng.normal(0, 0.3, size=(I, dim)).astype(np.float32)
     u = rng.integers(0, U, B); p = rng.integers(0, I, B); n = rng.integers(0, I, B)
     td = lambda a: torch.from_numpy(a).to(dev)
-    loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+    loss_sum = torch.zeros(64, dtype=torch.float64, device=dev)  # BR_SUM_SLOTS
     gu = torch.empty(B, dim, device=dev); gi = torch.empty(2 * B, dim, device=dev); per = torch.empty(B, device=dev)
     ops.bpr_forward_backward(td(ut), td(it), td(u).int(), td(p).int(), td(n).int(), 1.0 / B, loss_sum, gu, gi, per)
     loss, l, (rgu, rgp, rgn) = O.bpr_step_grads(ut, it, u, p, n, dt=np.float64)
-    assert abs(loss_sum.item() / B - loss) <= 1e-5 * abs(loss)
+    assert abs(loss_sum.sum().item() / B - loss) <= 1e-5 * abs(loss)
     np.testing.assert_allclose(per.cpu().numpy(), l, rtol=1e-5, atol=1e-7)
     scale = np.abs(rgu).max()
     np.testing.assert_allclose(gu.cpu().numpy(), rgu, rtol=1e-5, atol=1e-6 * scale)

@@ -44,7 +44,7 @@ def main():
     res["embed_fwd"] = {"us": t * 1e6, "GBps_read": B * 4 * D * 4 / t / 1e9}
     # BPR
     neg = torch.randint(0, I, (B,), generator=g).int().to(dev)
-    ls = torch.zeros(1, dtype=torch.float64, device=dev)
+    ls = torch.zeros(64, dtype=torch.float64, device=dev)
     gu = torch.empty(B, D, device=dev); gi = torch.empty(2 * B, D, device=dev)
     t = timeit(lambda: ops.bpr_forward_backward(tabs["user_mf"], tabs["item_mf"], users, items, neg, 1.0 / B, ls, gu, gi))
     res["bpr_fwd_bwd"] = {"us": t * 1e6, "GBps_rw": B * 6 * D * 4 / t / 1e9}
