@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Headline benchmark: (user,item) pairs/s of one NeuMF training step at batch 65 536, dim 64
+(BASELINE.json configs[1]: NeuMF embed_dim=64, synthetic 1M users x 100K items, 1 x MI355X).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = embedding gather -> GMF dot + MLP tower (fp32 MFMA) -> sigmoid-BCE -> backward ->
+dedup of the per-pair row gradients -> Keras-Adam on the four tables and the dense parameters,
+on one synthetic batch already resident in HBM.  Default optimizer = "adam_dense": Keras'
+NON-lazy sparse Adam (every row of every table decays m, v and moves each step [TF-sem]) — the
+reference's semantics; the lazy-row variant is timed too and reported under "adam_lazy".
+
+Rank 0 prints ONE JSON line (metric/value/... + "roofline" for the dominant kernel, measured
+with HIP events on the launch stream inside the timed region, + "cpu_baseline": the torch-CPU
+fp32 port of trainers/NFC_plain.py's step from oracle/torch_ref.py on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak (same guide)
+
+
+class EventProbe:
+    """HIP events (torch.cuda.Event on the current stream == the launch stream) around selected
+    C-ABI launches; keyed by (entry point, a size argument)."""
+
+    def __init__(self, select):
+        self.select = select   # name -> key function(args) or None
+        self.pairs = {}
+        self._open = None
+
+    def before(self, name, args):
+        kf = self.select.get(name, False)
+        if kf is False:
+            return
+        key = (name, kf(args) if kf else None)
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        self._open = (key, s)
+
+    def after(self, name, args):
+        if self._open is None:
+            return
+        key, s = self._open
+        self._open = None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.setdefault(key, []).append((s, e))
+
+    def mean_us(self):
+        return {k: (sum(s.elapsed_time(e) for s, e in v) / len(v) * 1e3, len(v)) for k, v in self.pairs.items()}
+
+
+def make_batches(n, B, U, I, dev, seed, zipf):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = []
+    for _ in range(n):
+        if zipf:
+            # Zipf(alpha=1.05)-like ranks by inverse-CDF on a truncated power law
+            def draw(N):
+                u = torch.rand(B, generator=g, dtype=torch.float64)
+                a = 1.05
+                r = ((N ** (1 - a) - 1) * u + 1) ** (1 / (1 - a))
+                return (r.long().clamp_(1, N) - 1)
+            users, items = draw(U), draw(I)
+        else:
+            users = torch.randint(0, U, (B,), generator=g)
+            items = torch.randint(0, I, (B,), generator=g)
+        labels = (torch.rand(B, generator=g) < 0.25).float()   # 1 pos : 3 neg (NeuMFModel.py:102)
+        out.append((users.int().to(dev), items.int().to(dev), labels.to(dev)))
+    return out
+
+
+def run_steps(eng, batches, n, row0, batch_total):
+    nb = len(batches)
+    for s in range(n):
+        u, i, y = batches[s % nb]
+        eng.train_step(u, i, y, row0=row0, batch_total=batch_total)
+
+
+def timed(eng, batches, steps, warmup, ctx, row0, batch_total):
+    run_steps(eng, batches, warmup, row0, batch_total)
+    if ctx is not None:
+        ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(eng, batches, steps, row0, batch_total)
+    torch.cuda.synchronize()
+    if ctx is not None:
+        ctx.barrier()
+    dt = time.perf_counter() - t0
+    if ctx is not None and ctx.world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(args, spec_dim):
+    """torch-CPU fp32 port of one trainers/NFC_plain.py step (oracle/torch_ref.py), all host threads."""
+    from oracle import binrec_oracle as O
+    from oracle import torch_ref as T
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))   # the 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
+    torch.set_num_threads(threads)
+    spec = O.NeuMFSpec("A", dim=spec_dim)
+    U, I, B = args.users, args.items, args.batch
+    step = T.NFCPlainCpuStep(spec, U, I, lr=0.005, seed=1, lazy_adam=False)
+    g = torch.Generator().manual_seed(1234)
+    n = args.cpu_steps
+    data = [(torch.randint(0, U, (B,), generator=g), torch.randint(0, I, (B,), generator=g),
+             (torch.rand(B, generator=g) < 0.25).float()) for _ in range(n + 1)]
+    step.step(*data[0])  # warm-up
+    t0 = time.perf_counter()
+    for k in range(1, n + 1):
+        step.step(*data[k])
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of batch {B} (NeuMF-A dim {spec_dim}, {U}x{I} tables, dense Keras-Adam) after 1 warm-up, "
+                      f"{dt:.1f} s; oracle/torch_ref.py::NFCPlainCpuStep"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=100_000)
+    ap.add_argument("--variant", default="A")
+    ap.add_argument("--optimizer", default="adam_dense", choices=["adam_dense", "adam_lazy"])
+    ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) ids instead of uniform")
+    ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lazy", action="store_true", help="skip the extra adam_lazy timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    neumf = importlib.import_module("binary-recommendation_amd.neumf")
+    par = importlib.import_module("binary-recommendation_amd.parallel")
+    _lib = importlib.import_module("binary-recommendation_amd._lib")
+    _lib.load()
+
+    ctx = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+        ctx = par.DistCtx()
+
+    B, D = args.batch, args.dim
+    # weak scaling: per-GPU batch AND per-GPU table shard are fixed as N grows
+    U, I = args.users * world, args.items * world
+    batch_total = B * world
+    row0 = rank * B
+
+    def build(optimizer):
+        cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004)
+        if world == 1:
+            return neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=1)
+        return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1)
+
+    log(f"building engine: {U} users x {I} items, dim {D}, batch {B}/GPU, world {world}, {args.optimizer}")
+    eng = build(args.optimizer)
+    log("engine built")
+    n_batches = min(args.steps + args.warmup, 32)
+    batches = make_batches(n_batches, B, U, I, dev, 1234 + rank, args.zipf)
+
+    # ---- timed region, with HIP events around the kernels the roofline is quoted on ----------
+    probe = EventProbe({
+        "brAdamDenseSweep": lambda a: int(a[3]),          # table_rows
+        "brNeumfEmbedForward": None,
+        "brDenseForward": lambda a: (int(a[7]), int(a[8])),   # K, N
+        "brDenseBackward": lambda a: (int(a[8]), int(a[9])),
+        "brAdamRowsSorted": lambda a: int(a[3]),
+    })
+    run_steps(eng, batches, args.warmup, row0, batch_total)   # warm-up outside the probe
+    _lib.set_probe(probe)
+    dt = timed(eng, batches, args.steps, 0, ctx, row0, batch_total)
+    _lib.set_probe(None)
+    eng.check_ids()
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
+    pairs_per_s = B * world * args.steps / dt
+    per_kernel = probe.mean_us()
+
+    n1 = eng.cfg.hidden[0]
+    kernels = {}
+    loc_users = eng.local_rows("user_mf")
+    for (name, key), (us, n) in per_kernel.items():
+        if name == "brAdamDenseSweep":
+            bytes_ = 6 * key * D * 4      # read+write theta, m, v of every row (6*4 B per element)
+            kernels[f"adam_dense_sweep[{key} rows]"] = {"us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
+                                                        "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
+        elif name == "brNeumfEmbedForward":
+            bytes_ = B * (4 * D * 4 + 8)  # 4 rows of D fp32 + 2 int32 ids per pair (1024 B + 8)
+            kernels["neumf_embed_fwd(gather4+dot+concat)"] = {"us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
+                                                               "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
+        elif name in ("brDenseForward", "brDenseBackward"):
+            K, N = key
+            flop = 2.0 * B * K * N * (1 if name == "brDenseForward" else 2)
+            tag = ("dense_fwd" if name == "brDenseForward" else "dense_bwd") + f"[{K}x{N}]"
+            kernels[tag] = {"us": us, "launches": n, "bound": "mfma", "achieved_TFLOPs": flop / us * 1e-6,
+                            "frac": flop / us * 1e-6 / MFMA_F32_PEAK_TFLOPS, "flop": flop}
+        elif name == "brAdamRowsSorted":
+            bytes_ = B * 7 * D * 4        # read g row + read/write theta, m, v of each touched row (upper bound: no duplicates)
+            kernels[f"adam_rows_sorted[{key} rows]"] = {"us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
+                                                        "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
+
+    # dominant kernel of the step
+    if args.optimizer == "adam_dense":
+        dom = kernels.get(f"adam_dense_sweep[{loc_users} rows]")
+        dom_name = "adam_dense_sweep_kernel (user tables)"
+    else:
+        dom = kernels.get(f"dense_bwd[{2 * D}x{n1}]")
+        dom_name = f"dense_bwd_kernel [{2 * D}x{n1}]"
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name.split(" ")[0])
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = None
+    if dom is not None:
+        if dom["bound"] == "hbm":
+            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": dom["frac"], "traffic": traffic, "avg_launch_us": dom["us"], "algorithmic_bytes_per_launch": dom["bytes"]}
+        else:
+            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": dom["achieved_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "avg_launch_us": dom["us"],
+                        "algorithmic_flop_per_launch": dom["flop"]}
+
+    lazy = None
+    if not args.no_lazy and args.optimizer == "adam_dense":
+        del eng
+        torch.cuda.empty_cache()
+        eng2 = build("adam_lazy")
+        dt2 = timed(eng2, batches, args.steps, args.warmup, ctx, row0, batch_total)
+        log(f"adam_lazy done: {dt2 / args.steps * 1e3:.3f} ms/step")
+        lazy = {"value": B * world * args.steps / dt2, "unit": "pairs/s", "ms_per_step": dt2 / args.steps * 1e3,
+                "note": "touched-rows-only Adam: NOT the reference's (Keras non-lazy) semantics"}
+        del eng2
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline start")
+        cpu = cpu_baseline(args, D)
+        log("cpu baseline done")
+
+    if rank == 0:
+        line = {
+            "metric": "(user,item) pairs/sec at batch 65536 dim 64", "value": pairs_per_s, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NeuMF-{args.variant} full training step (trainers/NFC_plain.py graph: 4 embeddings, "
+                                   f"{2 * D}->{'->'.join(map(str, eng_hidden(args, neumf)))}->1, BCE, Keras-Adam {args.optimizer}), "
+                                   f"embed_dim={D}, {args.users} users x {args.items} items per GPU, batch {B} per GPU, "
+                                   f"{'Zipf(1.05)' if args.zipf else 'uniform'} ids",
+                       "global_batch": batch_total, "parallelism": "single GPU" if world == 1 else f"row-sharded tables x{world} + dp{world}",
+                       "optimizer": args.optimizer},
+            "roofline": roofline, "cpu_baseline": cpu, "adam_lazy": lazy, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def eng_hidden(args, neumf):
+    return neumf.NeuMFConfig(variant=args.variant, dim=args.dim).hidden
+
+
+if __name__ == "__main__":
+    main()

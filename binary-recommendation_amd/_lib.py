@@ -52,6 +52,35 @@ class BinrecError(RuntimeError):
 
 _lib = None
 _protos = None
+_probe = None   # optional callable pair (before(name, args), after(name, args)) — bench.py's HIP-event timing
+
+
+def set_probe(probe):
+    """probe: object with .before(name, args) / .after(name, args), or None."""
+    global _probe
+    _probe = probe
+
+
+class _Lib:
+    """Attribute access returns the ctypes entry point, wrapped so a probe can bracket launches."""
+
+    def __init__(self, cdll, protos):
+        self._cdll = cdll
+        for name in protos:
+            setattr(self, name, self._wrap(name, getattr(cdll, name)))
+
+    @staticmethod
+    def _wrap(name, fn):
+        def call(*args):
+            p = _probe
+            if p is None:
+                return fn(*args)
+            p.before(name, args)
+            rc = fn(*args)
+            p.after(name, args)
+            return rc
+        call.__name__ = name
+        return call
 
 
 def load():
@@ -72,8 +101,8 @@ def load():
             raise BinrecError(f"libbinrec_hip.so does not export {name} declared in include/binrec.h") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
-    return lib
+    _lib = _Lib(lib, _protos)
+    return _lib
 
 
 def prototypes():

@@ -97,9 +97,7 @@ class NeuMFEngine:
         g = torch.Generator(device="cpu").manual_seed(init_seed)
         # [TF-sem] Embedding init U(-0.05, 0.05); Dense glorot-uniform; bias 0; BN gamma 1 beta 0
         self.tables = {}
-        for name in TABLES:
-            rows = self.num_user_rows if name.startswith("user") else self.num_item_rows
-            self.tables[name] = (torch.rand(rows, D, generator=g) * 0.1 - 0.05).to(dev)
+        self._init_tables(g, init_seed)
         self.theta = _Flat(cfg.dense_shapes(), dev)
         for k, (_, _, shp) in self.theta.offsets.items():
             if k.startswith("W"):
@@ -117,6 +115,20 @@ class NeuMFEngine:
                        "mm2": torch.zeros(n2, device=dev), "mv2": torch.ones(n2, device=dev)}
         self.t = 0
         self._alloc(self.max_batch)
+
+    def local_rows(self, name: str) -> int:
+        """rows of `name` held by this process (all of them without row-sharding)."""
+        return self.num_user_rows if name.startswith("user") else self.num_item_rows
+
+    def _init_tables(self, g, init_seed):
+        D, dev = self.cfg.dim, self.device
+        for name in TABLES:
+            rows = self.local_rows(name)
+            if rows * D > (1 << 26):   # big tables: draw on the device (same distribution)
+                dg = torch.Generator(device=dev).manual_seed(init_seed + 7919 * (1 + TABLES.index(name)))
+                self.tables[name] = torch.rand(rows, D, generator=dg, device=dev, dtype=torch.float32).mul_(0.1).sub_(0.05)
+            else:
+                self.tables[name] = (torch.rand(rows, D, generator=g) * 0.1 - 0.05).to(dev)
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, B):
@@ -144,20 +156,22 @@ class NeuMFEngine:
         self.nsh = ops.head_slabs(B)
         self.hslabs = f(self.nsh * (n3 + 2))
         self.err = ops.new_err_flag(dev)
+        self._alloc_sparse(B)
+
+    def _alloc_sparse(self, B):
+        dev = self.device
         self.user_index = ops.RowIndex(B, self.id_dtype, dev)
         self.item_index = ops.RowIndex(B, self.id_dtype, dev)
-        if cfg.optimizer == "adam_dense":
-            self.user_mark = torch.zeros(self.num_user_rows, dtype=torch.uint8, device=dev)
-            self.item_mark = torch.zeros(self.num_item_rows, dtype=torch.uint8, device=dev)
+        if self.cfg.optimizer == "adam_dense":
+            self.user_mark = torch.zeros(self.local_rows("user_mf"), dtype=torch.uint8, device=dev)
+            self.item_mark = torch.zeros(self.local_rows("item_mf"), dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------ forward (shared)
     def _forward(self, users, items, B, training, row0, batch_total):
         cfg, th, bn = self.cfg, self.theta, self.bn
         p = cfg.dropout if training else 0.0
         x0, a1, a2, a3 = self.x0[:B], self.a1[:B], self.a2[:B], self.a3[:B]
-        t = self.tables
-        ops.neumf_embed_forward(t["user_mlp"], t["item_mlp"], t["user_mf"], t["item_mf"], users, items,
-                                cfg.item_first, x0, self.dot[:B], self.err)
+        self._embed_forward(users, items, B)
         step = self.t
         ops.dense_forward(x0, th.view("W1"), th.view("b1"), a1, cfg.act, drop_p=p, seed=cfg.seed, step=step, site=0,
                           row0=row0, stats=self.stats1 if training else None)
@@ -181,6 +195,12 @@ class NeuMFEngine:
                              bn["scale2"], bn["shift2"])
         ops.dense_forward(a2, th.view("W3"), th.view("b3"), a3, cfg.act, bn["scale2"], bn["shift2"], drop_p=p,
                           seed=cfg.seed, step=step, site=2, row0=row0)
+
+    def _embed_forward(self, users, items, B):
+        """G1+M1+T1: 4 lookups, GMF dot, MLP concat -> x0, dot (one launch)."""
+        t = self.tables
+        ops.neumf_embed_forward(t["user_mlp"], t["item_mlp"], t["user_mf"], t["item_mf"], users, items,
+                                self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
 
     # ------------------------------------------------------------------ one optimizer step
     def train_step(self, users, items, labels, row0: int = 0, batch_total: int | None = None):
@@ -218,7 +238,6 @@ class NeuMFEngine:
                            in_scale=bn["scale1"], in_shift=bn["shift1"], in_bn=(bn["mean1"], bn["rstd1"]), in_drop_p=p,
                            in_site=1, seed=seed, step=step, row0=row0, in_bn_sums=self.bsum1)
         ops.reduce_slabs(self.slabs, ns, n1 * n2 + n2, gr.slice("W2", "b2"))
-        ops.bn_param_grads(self.bsum2, gr.view("g2"), gr.view("be2"))
         if self.dist is not None and cfg.sync_bn:
             self.dist.all_reduce_sum(self.bsum1)
         # layer 1: input = raw concat with dropout site 0, no BN below
@@ -226,11 +245,21 @@ class NeuMFEngine:
                            out_bn=(bn["mean1"], bn["rstd1"], th.view("g1")), bn_sums=self.bsum1, batch_total=batch_total,
                            in_drop_p=p, in_site=0, seed=seed, step=step, row0=row0)
         ops.reduce_slabs(self.slabs, ns, 2 * D * n1 + n1, gr.slice("W1", "b1"))
-        ops.bn_param_grads(self.bsum1, gr.view("g1"), gr.view("be1"))
-        t = self.tables
-        ops.neumf_embed_backward(t["user_mf"], t["item_mf"], users, items, cfg.item_first, None, self.ddot[:B],
-                                 self.g_user_mf[:B], self.g_item_mf[:B])
-        self._apply(users, items, B)
+        # dgamma/dbeta are the BN-backward column sums.  With sync_bn those sums are already global,
+        # so they are written AFTER the dense all-reduce; per-replica BN sums are local like the rest.
+        synced = self.dist is not None and cfg.sync_bn
+        if not synced:
+            ops.bn_param_grads(self.bsum2, gr.view("g2"), gr.view("be2"))
+            ops.bn_param_grads(self.bsum1, gr.view("g1"), gr.view("be1"))
+        if self.dist is not None:
+            self.dist.all_reduce_sum(self.grad.buf)
+        if synced:
+            ops.bn_param_grads(self.bsum2, gr.view("g2"), gr.view("be2"))
+            ops.bn_param_grads(self.bsum1, gr.view("g1"), gr.view("be1"))
+        self._embed_backward_apply(users, items, B)
+        a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
+        ops.adam_flat(self.theta.buf, self.adam_m.buf, self.adam_v.buf, self.grad.buf, a, beta1=cfg.beta1, beta2=cfg.beta2,
+                      eps=cfg.adam_eps)
 
     def row_grad_views(self, B):
         """name -> (tensor, row stride): the MLP tables' row gradients are the halves of dx0."""
@@ -240,15 +269,20 @@ class NeuMFEngine:
         return {"user_mlp": (dx0[:, uo:uo + D], 2 * D), "item_mlp": (dx0[:, io:io + D], 2 * D),
                 "user_mf": (self.g_user_mf[:B], D), "item_mf": (self.g_item_mf[:B], D)}
 
-    def _apply(self, users, items, B):
-        cfg = self.cfg
-        if self.dist is not None:
-            self.dist.all_reduce_sum(self.grad.buf)
-        a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
-        hp = dict(beta1=cfg.beta1, beta2=cfg.beta2, eps=cfg.adam_eps)
+    def _embed_backward_apply(self, users, items, B):
+        """B1 row gradients of the 4 tables, S1 dedup index, O1 Adam on the tables."""
+        cfg, t = self.cfg, self.tables
+        ops.neumf_embed_backward(t["user_mf"], t["item_mf"], users, items, cfg.item_first, None, self.ddot[:B],
+                                 self.g_user_mf[:B], self.g_item_mf[:B])
         self.user_index.build(users, self.num_user_rows)
         self.item_index.build(items, self.num_item_rows)
-        rg = self.row_grad_views(B)
+        self._adam_tables(self.row_grad_views(B))
+
+    def _adam_tables(self, rg):
+        """rg: name -> (row_grads, row stride) aligned with the positions the indexes were built on."""
+        cfg = self.cfg
+        a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
+        hp = dict(beta1=cfg.beta1, beta2=cfg.beta2, eps=cfg.adam_eps)
         dense = cfg.optimizer == "adam_dense"
         for name in TABLES:
             idx = self.user_index if name.startswith("user") else self.item_index
@@ -257,7 +291,6 @@ class NeuMFEngine:
             ops.adam_rows_sorted(self.tables[name], self.tab_m[name], self.tab_v[name], idx, g, ldg, a, mark=mark, **hp)
             if dense:
                 ops.adam_dense_sweep(self.tables[name], self.tab_m[name], self.tab_v[name], a, mark=mark, **hp)
-        ops.adam_flat(self.theta.buf, self.adam_m.buf, self.adam_v.buf, self.grad.buf, a, **hp)
 
     # ------------------------------------------------------------------ inference
     def predict(self, users, items, out=None):

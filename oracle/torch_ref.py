@@ -100,7 +100,7 @@ def neumf_autograd(spec, p_np, users, items, labels, masks=None, dtype=torch.flo
     loss.backward()
     g = {k: p[k].grad.numpy() for k in DENSE_ORDER}
     rg = {k: rows[k].grad.numpy() for k in keys}
-    return float(loss), z.detach().numpy(), g, rg
+    return float(loss.detach()), z.detach().numpy(), g, rg
 
 
 # ----------------------------------------------------------------------------
@@ -167,4 +167,4 @@ class NFCPlainCpuStep:
             self.mv[0].mul_(mom).add_(st["var1"].detach(), alpha=1 - mom)
             self.mm[1].mul_(mom).add_(st["mu2"].detach(), alpha=1 - mom)
             self.mv[1].mul_(mom).add_(st["var2"].detach(), alpha=1 - mom)
-        return float(loss)
+        return float(loss.detach())
