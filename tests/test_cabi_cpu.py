@@ -2,6 +2,7 @@
 include/binrec.h declares (no compute calls here)."""
 import ctypes
 import os
+import re
 from importlib import import_module
 
 import pytest
