@@ -62,12 +62,13 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
 
 
 def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle", flags=re.M)
     pkg = os.path.join(ROOT, "binary-recommendation_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith(".py"):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in src and "from oracle" not in src, f
-    for f in ("bench.py",):
-        src = open(os.path.join(ROOT, f)).read()
-        assert src.count("from oracle") == 2 and "def cpu_baseline" in src   # only inside the cpu_baseline leg
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f
+    # bench.py may touch the oracle only inside its cpu_baseline leg
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def cpu_baseline"):src.index("def log(")]
+    assert len(pat.findall(src)) == len(pat.findall(body)) == 2
