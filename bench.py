@@ -34,35 +34,44 @@ HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s 
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak (same guide)
 
 
-class EventProbe:
-    """HIP events (torch.cuda.Event on the current stream == the launch stream) around selected
-    C-ABI launches; keyed by (entry point, a size argument)."""
+class PyProbe:
+    """Row-sharded runs launch their table kernels from Python (parallel.py), outside the C step
+    driver's probe: bracket those launches with torch.cuda.Event on the current (= launch) stream."""
 
-    def __init__(self, select):
-        self.select = select   # name -> key function(args) or None
-        self.pairs = {}
-        self._open = None
+    def __init__(self, tags):
+        self.tags, self.pairs, self._open = tags, {}, None
 
     def before(self, name, args):
-        kf = self.select.get(name, False)
-        if kf is False:
-            return
-        key = (name, kf(args) if kf else None)
-        s = torch.cuda.Event(enable_timing=True)
-        s.record()
-        self._open = (key, s)
+        if name in self.tags:
+            s = torch.cuda.Event(enable_timing=True)
+            s.record()
+            self._open = (self.tags[name](args), s)
 
     def after(self, name, args):
-        if self._open is None:
-            return
-        key, s = self._open
-        self._open = None
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        self.pairs.setdefault(key, []).append((s, e))
+        if self._open is not None:
+            tag, s = self._open
+            self._open = None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pairs.setdefault(tag, []).append((s, e))
 
-    def mean_us(self):
-        return {k: (sum(s.elapsed_time(e) for s, e in v) / len(v) * 1e3, len(v)) for k, v in self.pairs.items()}
+    def merge_into(self, per_tag):
+        for tag, v in self.pairs.items():
+            per_tag[tag] = (sum(s.elapsed_time(e) for s, e in v) / len(v) * 1e3, len(v))
+
+
+def read_probe(lib):
+    """{tag: (mean_us, launches)} from the C-level HIP-event probe (include/binrec.h, brProbe*)."""
+    import ctypes
+    acc = {}
+    tag, ms = ctypes.c_int(0), ctypes.c_float(0.0)
+    for i in range(lib.brProbeCount()):
+        if lib.brProbeRead(i, ctypes.byref(tag), ctypes.byref(ms)) != 0:
+            raise RuntimeError(lib.brGetLastError().decode())
+        t = acc.setdefault(tag.value, [0.0, 0])
+        t[0] += ms.value * 1e3
+        t[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
 def make_batches(n, B, U, I, dev, seed, zipf):
@@ -199,69 +208,89 @@ def main():
     n_batches = min(args.steps + args.warmup, 32)
     batches = make_batches(n_batches, B, U, I, dev, 1234 + rank, args.zipf)
 
-    # ---- timed region, with HIP events around the kernels the roofline is quoted on ----------
-    probe = EventProbe({
-        "brAdamDenseSweep": lambda a: int(a[3]),          # table_rows
-        "brNeumfEmbedForward": None,
-        "brDenseForward": lambda a: (int(a[7]), int(a[8])),   # K, N
-        "brDenseBackward": lambda a: (int(a[8]), int(a[9])),
-        "brAdamRowsSorted": lambda a: int(a[3]),
-    })
+    # ---- timed region, with HIP events (recorded by the step driver on the launch stream) around
+    #      every kernel launch of the step: the roofline figures come from these ----------------------
+    lib = _lib.load()
+    TAG = {k[7:]: v for k, v in _lib.parse_enums().items() if k.startswith("BR_TAG_")}
     run_steps(eng, batches, args.warmup, row0, batch_total)   # warm-up outside the probe
-    _lib.set_probe(probe)
+    if lib.brProbeEnable(64 * args.steps) != 0:
+        raise RuntimeError(lib.brGetLastError().decode())
+    pyprobe = None
+    if world > 1:
+        users_rows = eng.local_rows("user_mf")
+        pyprobe = PyProbe({"brAdamDenseSweep": lambda a: TAG["SWEEP_USER"] if int(a[3]) == users_rows else TAG["SWEEP_ITEM"],
+                           "brAdamRowsSorted": lambda a: TAG["ADAM_ROWS_USER"] if int(a[3]) == users_rows else TAG["ADAM_ROWS_ITEM"],
+                           "brNeumfEmbedForward": lambda a: TAG["EMBED_FWD"], "brNeumfEmbedBackward": lambda a: TAG["EMBED_BWD"]})
+        _lib.set_probe(pyprobe)
     dt = timed(eng, batches, args.steps, 0, ctx, row0, batch_total)
     _lib.set_probe(None)
+    per_tag = read_probe(lib)
+    if pyprobe is not None:
+        pyprobe.merge_into(per_tag)
+    lib.brProbeEnable(0)
     eng.check_ids()
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     pairs_per_s = B * world * args.steps / dt
-    per_kernel = probe.mean_us()
 
-    n1 = eng.cfg.hidden[0]
+    n1, n2, n3 = eng.cfg.hidden
+    loc_users, loc_items = eng.local_rows("user_mf"), eng.local_rows("item_mf")
     kernels = {}
-    loc_users = eng.local_rows("user_mf")
-    for (name, key), (us, n) in per_kernel.items():
-        if name == "brAdamDenseSweep":
-            bytes_ = 6 * key * D * 4      # read+write theta, m, v of every row (6*4 B per element)
-            kernels[f"adam_dense_sweep[{key} rows]"] = {"us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
-                                                        "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
-        elif name == "brNeumfEmbedForward":
-            bytes_ = B * (4 * D * 4 + 8)  # 4 rows of D fp32 + 2 int32 ids per pair (1024 B + 8)
-            kernels["neumf_embed_fwd(gather4+dot+concat)"] = {"us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
-                                                               "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
-        elif name in ("brDenseForward", "brDenseBackward"):
-            K, N = key
-            flop = 2.0 * B * K * N * (1 if name == "brDenseForward" else 2)
-            tag = ("dense_fwd" if name == "brDenseForward" else "dense_bwd") + f"[{K}x{N}]"
-            kernels[tag] = {"us": us, "launches": n, "bound": "mfma", "achieved_TFLOPs": flop / us * 1e-6,
-                            "frac": flop / us * 1e-6 / MFMA_F32_PEAK_TFLOPS, "flop": flop}
-        elif name == "brAdamRowsSorted":
-            bytes_ = B * 7 * D * 4        # read g row + read/write theta, m, v of each touched row (upper bound: no duplicates)
-            kernels[f"adam_rows_sorted[{key} rows]"] = {"us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
-                                                        "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
+
+    def hbm(name, tag, bytes_):
+        if TAG[tag] in per_tag:
+            us, n = per_tag[TAG[tag]]
+            kernels[name] = {"us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
+                             "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
+
+    def mfma(name, tag, flop):
+        if TAG[tag] in per_tag:
+            us, n = per_tag[TAG[tag]]
+            kernels[name] = {"us": us, "launches": n, "bound": "mfma", "achieved_TFLOPs": flop / us * 1e-6,
+                             "frac": flop / us * 1e-6 / MFMA_F32_PEAK_TFLOPS, "flop": flop}
+
+    # algorithmic work per launch: gather 4*D*4 B + 8 B ids per pair; Adam sweep 6*4 B per
+    # table element; Adam rows: g row + read/write theta,m,v = 7*4 B per element of a touched row (upper bound: no dups)
+    hbm("neumf_embed_fwd(gather4+dot+concat)", "EMBED_FWD", B * (4 * D * 4 + 8))
+    hbm("neumf_embed_bwd", "EMBED_BWD", B * (4 * D * 4 + 8))
+    hbm(f"adam_dense_sweep[user {loc_users}x{2 * D}]", "SWEEP_USER", 6 * 4 * loc_users * 2 * D)
+    hbm(f"adam_dense_sweep[item {loc_items}x{2 * D}]", "SWEEP_ITEM", 6 * 4 * loc_items * 2 * D)
+    hbm("adam_rows_sorted[user]", "ADAM_ROWS_USER", B * 7 * 2 * D * 4)
+    hbm("adam_rows_sorted[item]", "ADAM_ROWS_ITEM", B * 7 * 2 * D * 4)
+    mfma(f"dense_fwd[{2 * D}x{n1}]", "FWD_L1", 2.0 * B * 2 * D * n1)
+    mfma(f"dense_fwd[{n1}x{n2}]", "FWD_L2", 2.0 * B * n1 * n2)
+    mfma(f"dense_fwd[{n2}x{n3}]", "FWD_L3", 2.0 * B * n2 * n3)
+    mfma(f"dense_bwd[{2 * D}x{n1}]", "BWD_L1", 4.0 * B * 2 * D * n1)
+    mfma(f"dense_bwd[{n1}x{n2}]", "BWD_L2", 4.0 * B * n1 * n2)
+    mfma(f"dense_bwd[{n2}x{n3}]", "BWD_L3", 4.0 * B * n2 * n3)
+    for name, tag in (("row_index_build[user]", "INDEX_USER"), ("row_index_build[item]", "INDEX_ITEM"), ("head+loss", "HEAD"),
+                      ("reduce_slabs (each)", "REDUCE"), ("bn/small (each)", "SMALL"), ("adam_flat", "ADAM_FLAT")):
+        if TAG[tag] in per_tag:
+            kernels[name] = {"us": per_tag[TAG[tag]][0], "launches": per_tag[TAG[tag]][1]}
+    gpu_us_per_step = sum(v["us"] * v["launches"] for v in kernels.values()) / args.steps
 
     # dominant kernel of the step
     if args.optimizer == "adam_dense":
-        dom = kernels.get(f"adam_dense_sweep[{loc_users} rows]")
-        dom_name = "adam_dense_sweep_kernel (user tables)"
+        dom_key, dom_name = f"adam_dense_sweep[user {loc_users}x{2 * D}]", "adam_dense_sweep_kernel"
     else:
-        dom = kernels.get(f"dense_bwd[{2 * D}x{n1}]")
-        dom_name = f"dense_bwd_kernel [{2 * D}x{n1}]"
+        dom_key, dom_name = f"dense_bwd[{2 * D}x{n1}]", "dense_bwd_kernel"
+    dom = kernels.get(dom_key)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom_name.split(" ")[0])
+            traffic = json.load(open(tpath)).get(dom_name)
         except Exception:  # noqa: BLE001
             traffic = None
     roofline = None
     if dom is not None:
         if dom["bound"] == "hbm":
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": dom["frac"], "traffic": traffic, "avg_launch_us": dom["us"], "algorithmic_bytes_per_launch": dom["bytes"]}
+            roofline = {"bound": "hbm", "kernel": f"{dom_name} ({dom_key})", "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": dom["frac"], "traffic": traffic, "avg_launch_us": dom["us"],
+                        "algorithmic_bytes_per_launch": dom["bytes"]}
         else:
-            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": dom["achieved_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "avg_launch_us": dom["us"],
-                        "algorithmic_flop_per_launch": dom["flop"]}
+            roofline = {"bound": "mfma", "kernel": f"{dom_name} ({dom_key})", "achieved": dom["achieved_TFLOPs"],
+                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                        "avg_launch_us": dom["us"], "algorithmic_flop_per_launch": dom["flop"]}
 
     lazy = None
     if not args.no_lazy and args.optimizer == "adam_dense":
@@ -291,7 +320,8 @@ def main():
                                    f"{'Zipf(1.05)' if args.zipf else 'uniform'} ids",
                        "global_batch": batch_total, "parallelism": "single GPU" if world == 1 else f"row-sharded tables x{world} + dp{world}",
                        "optimizer": args.optimizer},
-            "roofline": roofline, "cpu_baseline": cpu, "adam_lazy": lazy, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "adam_lazy": lazy, "gpu_kernel_us_per_step": gpu_us_per_step,
+            "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

@@ -26,6 +26,8 @@ def parse_header(path: str = HEADER) -> dict[str, tuple[object, list[object], li
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
+    src = re.sub(r"enum\s*\{.*?\}\s*;", " ", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"\b(const\s+char\s*\*|int64_t|int)\s+(br[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
@@ -48,6 +50,40 @@ def parse_header(path: str = HEADER) -> dict[str, tuple[object, list[object], li
 
 class BinrecError(RuntimeError):
     pass
+
+
+def parse_struct(name: str, path: str = HEADER):
+    """ctypes field list of `typedef struct name {...} name;` in the header (pointers -> c_void_p)."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    m = re.search(r"typedef\s+struct\s+" + name + r"\s*\{(.*?)\}\s*" + name + r"\s*;", src, flags=re.S)
+    if not m:
+        raise BinrecError(f"struct {name} not found in {path}")
+    fields = []
+    for decl in m.group(1).split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        if "*" in decl:
+            for nm in re.findall(r"\*\s*([A-Za-z_][A-Za-z0-9_]*)", decl):
+                fields.append((nm, ctypes.c_void_p))
+        else:
+            ty, names = decl.split(" ", 1)
+            for nm in names.split(","):
+                fields.append((nm.strip(), _SCALARS[ty]))
+    return fields
+
+
+def parse_enums(path: str = HEADER) -> dict:
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    out = {}
+    for body in re.findall(r"enum\s*\{(.*?)\}\s*;", src, flags=re.S):
+        for item in body.split(","):
+            if "=" in item:
+                k, v = item.split("=")
+                out[k.strip()] = int(v.strip(), 0)
+    return out
 
 
 _lib = None

@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void row_dot_bwd_kernel(const float* __restric
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void neumf_embed_fwd_kernel(
     const float* __restrict__ user_mlp, const float* __restrict__ item_mlp,
-    const float* __restrict__ user_mf, const float* __restrict__ item_mf, int64_t user_rows,
-    int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items, int dim,
-    int chunks, int lpr_log2, int64_t batch, int item_first, float* __restrict__ x0,
+    const float* __restrict__ user_mf, const float* __restrict__ item_mf, int64_t ldu, int64_t ldi,
+    int64_t user_rows, int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items,
+    int dim, int chunks, int lpr_log2, int64_t batch, int item_first, float* __restrict__ x0,
     float* __restrict__ dot, int* err) {
   using V = typename VecT<VEC>::type;
   const int lpr = 1 << lpr_log2;
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_kernel(
   const int uoff = item_first ? dim : 0, ioff = item_first ? 0 : dim;
   float s = 0.f;
   for (int c = lir; c < chunks; c += lpr) {
-    V um = uok ? vload<VEC>(user_mlp + u * dim + c * VEC) : vzero<VEC>();
-    V im = iok ? vload<VEC>(item_mlp + i * dim + c * VEC) : vzero<VEC>();
-    V uf = uok ? vload<VEC>(user_mf + u * dim + c * VEC) : vzero<VEC>();
-    V vf = iok ? vload<VEC>(item_mf + i * dim + c * VEC) : vzero<VEC>();
+    V um = uok ? vload<VEC>(user_mlp + u * ldu + c * VEC) : vzero<VEC>();
+    V im = iok ? vload<VEC>(item_mlp + i * ldi + c * VEC) : vzero<VEC>();
+    V uf = uok ? vload<VEC>(user_mf + u * ldu + c * VEC) : vzero<VEC>();
+    V vf = iok ? vload<VEC>(item_mf + i * ldi + c * VEC) : vzero<VEC>();
     if (live) {
       vstore<VEC>(xrow + uoff + c * VEC, um);
       vstore<VEC>(xrow + ioff + c * VEC, im);
@@ -115,11 +115,11 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_kernel(
 
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void neumf_embed_bwd_kernel(
-    const float* __restrict__ user_mf, const float* __restrict__ item_mf, int64_t user_rows,
-    int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items, int dim,
-    int chunks, int lpr_log2, int64_t batch, int item_first, const float* __restrict__ dx0,
+    const float* __restrict__ user_mf, const float* __restrict__ item_mf, int64_t ldu, int64_t ldi,
+    int64_t user_rows, int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items,
+    int dim, int chunks, int lpr_log2, int64_t batch, int item_first, const float* __restrict__ dx0,
     const float* __restrict__ ddot, float* __restrict__ g_user_mlp, float* __restrict__ g_item_mlp,
-    float* __restrict__ g_user_mf, float* __restrict__ g_item_mf) {
+    float* __restrict__ g_user_mf, float* __restrict__ g_item_mf, int64_t ldg) {
   using V = typename VecT<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,14 +131,14 @@ __global__ __launch_bounds__(256) void neumf_embed_bwd_kernel(
   const float g = ddot[b];
   const int uoff = item_first ? dim : 0, ioff = item_first ? 0 : dim;
   for (int c = lir; c < chunks; c += lpr) {
-    V uf = uok ? vload<VEC>(user_mf + u * dim + c * VEC) : vzero<VEC>();
-    V vf = iok ? vload<VEC>(item_mf + i * dim + c * VEC) : vzero<VEC>();
-    vstore<VEC>(g_user_mf + b * dim + c * VEC, vmul(vf, g));
-    vstore<VEC>(g_item_mf + b * dim + c * VEC, vmul(uf, g));
+    V uf = uok ? vload<VEC>(user_mf + u * ldu + c * VEC) : vzero<VEC>();
+    V vf = iok ? vload<VEC>(item_mf + i * ldi + c * VEC) : vzero<VEC>();
+    vstore<VEC>(g_user_mf + b * ldg + c * VEC, vmul(vf, g));
+    vstore<VEC>(g_item_mf + b * ldg + c * VEC, vmul(uf, g));
     if (g_user_mlp) {
       const float* xr = dx0 + b * (2 * (int64_t)dim);
-      vstore<VEC>(g_user_mlp + b * dim + c * VEC, vload<VEC>(xr + uoff + c * VEC));
-      vstore<VEC>(g_item_mlp + b * dim + c * VEC, vload<VEC>(xr + ioff + c * VEC));
+      vstore<VEC>(g_user_mlp + b * ldg + c * VEC, vload<VEC>(xr + uoff + c * VEC));
+      vstore<VEC>(g_item_mlp + b * ldg + c * VEC, vload<VEC>(xr + ioff + c * VEC));
     }
   }
 }
@@ -291,50 +291,53 @@ extern "C" int brRowDotBackward(const float* a, const float* b, const float* dou
 }
 
 extern "C" int brNeumfEmbedForward(const float* user_mlp, const float* item_mlp, const float* user_mf,
-                                   const float* item_mf, int64_t user_rows, int64_t item_rows,
-                                   const void* users, const void* items, int id_type, int dim, int64_t batch,
-                                   int item_first, float* x0, float* dot, int* err_flag, brStream stream) {
+                                   const float* item_mf, int64_t ld_user, int64_t ld_item, int64_t user_rows,
+                                   int64_t item_rows, const void* users, const void* items, int id_type, int dim,
+                                   int64_t batch, int item_first, float* x0, float* dot, int* err_flag, brStream stream) {
   BR_CHECK_ARG(user_mlp && item_mlp && user_mf && item_mf && x0 && dot, "brNeumfEmbedForward: null pointer");
   BR_CHECK_ARG(dim >= 1 && batch >= 0 && user_rows > 0 && item_rows > 0, "brNeumfEmbedForward: bad sizes");
+  BR_CHECK_ARG(ld_user >= dim && ld_item >= dim, "brNeumfEmbedForward: row strides < dim");
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brNeumfEmbedForward: bad id_type");
   if (batch == 0) return BR_OK;
-  const RowGeom g = row_geom(dim);
+  const RowGeom g = row_geom_ld(dim, (ld_user % 4 == 0 && ld_item % 4 == 0) ? 4 : (ld_user % 2 == 0 && ld_item % 2 == 0) ? 2 : 1);
   const unsigned grid = grid_for_rows(batch, g.lpr_log2);
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32) {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
-                               user_mlp, item_mlp, user_mf, item_mf, user_rows, item_rows, (const int32_t*)users,
+                               user_mlp, item_mlp, user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int32_t*)users,
                                (const int32_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag)));
   } else {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
-                               user_mlp, item_mlp, user_mf, item_mf, user_rows, item_rows, (const int64_t*)users,
+                               user_mlp, item_mlp, user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int64_t*)users,
                                (const int64_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag)));
   }
   BR_CHECK_LAUNCH("brNeumfEmbedForward");
   return BR_OK;
 }
 
-extern "C" int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t user_rows,
-                                    int64_t item_rows, const void* users, const void* items, int id_type,
-                                    int dim, int64_t batch, int item_first, const float* dx0, const float* ddot,
-                                    float* g_user_mlp, float* g_item_mlp, float* g_user_mf, float* g_item_mf,
-                                    brStream stream) {
+extern "C" int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t ld_user, int64_t ld_item,
+                                    int64_t user_rows, int64_t item_rows, const void* users, const void* items,
+                                    int id_type, int dim, int64_t batch, int item_first, const float* dx0,
+                                    const float* ddot, float* g_user_mlp, float* g_item_mlp, float* g_user_mf,
+                                    float* g_item_mf, int64_t ldg, brStream stream) {
   BR_CHECK_ARG(user_mf && item_mf && ddot && g_user_mf && g_item_mf, "brNeumfEmbedBackward: null pointer");
   BR_CHECK_ARG((g_user_mlp == nullptr) == (g_item_mlp == nullptr), "brNeumfEmbedBackward: g_*_mlp both or neither");
   BR_CHECK_ARG(!g_user_mlp || dx0, "brNeumfEmbedBackward: dx0 required for g_*_mlp");
+  BR_CHECK_ARG(ld_user >= dim && ld_item >= dim && ldg >= dim, "brNeumfEmbedBackward: row strides < dim");
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brNeumfEmbedBackward: bad id_type");
   if (batch == 0) return BR_OK;
-  const RowGeom g = row_geom(dim);
+  const int64_t ldmin = (ld_user % 4 == 0 && ld_item % 4 == 0 && ldg % 4 == 0) ? 4 : (ld_user % 2 == 0 && ld_item % 2 == 0 && ldg % 2 == 0) ? 2 : 1;
+  const RowGeom g = row_geom_ld(dim, ldmin);
   const unsigned grid = grid_for_rows(batch, g.lpr_log2);
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32) {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_bwd_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
-                               user_mf, item_mf, user_rows, item_rows, (const int32_t*)users, (const int32_t*)items, dim,
-                               g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf)));
+                               user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int32_t*)users, (const int32_t*)items,
+                               dim, g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf, ldg)));
   } else {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_bwd_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
-                               user_mf, item_mf, user_rows, item_rows, (const int64_t*)users, (const int64_t*)items, dim,
-                               g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf)));
+                               user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int64_t*)users, (const int64_t*)items,
+                               dim, g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf, ldg)));
   }
   BR_CHECK_LAUNCH("brNeumfEmbedBackward");
   return BR_OK;

@@ -1,15 +1,19 @@
 // T1-T4 + B1: the MLP tower on fp32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 fma chains, the
 // only MFMA form that meets the 1e-5 logit/loss tolerance; 157 TFLOP/s peak on MI355X).
 //
-// One workgroup = 4 waves = one 64-row batch tile (16 rows per wave), looping over tiles
-// (grid <= 256: one resident workgroup per CU, W staged into LDS once per workgroup).
-//   forward : y = act( T(x)·W + b ), BatchNorm column sums of y in the epilogue.
-//   backward: dz = actgrad(BN^-1-backward(dropout-backward(gy))) elementwise into LDS, then
-//             dx = dz·W^T (per-wave 16 x K), dW += T(x)^T·dz (K x N split over waves by 16-row
-//             strips of K) and db, accumulated in registers across the workgroup's tiles and
-//             written once as a per-workgroup slab (fixed-order reduce => reproducible).
-// K is contracted in a lane-permuted order (lane group g = lane>>4 owns k = 16j+4g..+3) so one
-// ds_read_b128 feeds four MFMA k-steps; A and B use the same permutation.
+// Structure (both kernels): one 512-thread workgroup (8 waves, 2 per SIMD) per CU walks batch tiles.
+//   * W never goes through LDS: every wave keeps the <= 32 fragment registers of the 16 weight
+//     columns (forward: n-tile, backward: k-tile) it owns for the whole launch.
+//   * The activation tiles are double-buffered in LDS; the raw global loads of tile t+1 are
+//     issued before the MFMA phase of tile t and land in registers (global -> reg -> LDS staging),
+//     BatchNorm-affine + Philox dropout are applied on the way in; one barrier per tile.
+//   * K is contracted in a lane-permuted order (lane group g = lane>>4 owns k = 16j+4g..+3) so one
+//     ds_read_b128 feeds four MFMA k-steps; A and B use the same permutation.
+//   forward : wave (n-tile nt, row group) : y[rows][16 cols] = act(T(x)·W + b) ; BN column sums.
+//   backward: dz = act'(y)·BN-backward(gy) elementwise into LDS; wave (k-tile kt, row group):
+//             dx[rows][16 cols of kt] = dz·W^T  and  dW[16 rows of kt][N] += T(x)^T·dz from the
+//             same LDS tiles; dW/db live in registers across the workgroup's tiles and leave as
+//             one slab per (workgroup, row group) -> fixed-order reduce (reproducible, no atomics).
 #include "common.h"
 #include "philox.h"
 
@@ -17,141 +21,196 @@ namespace br {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kTM = 64;          // rows per workgroup tile
+constexpr int kThreads = 512;
+constexpr int kFwdTM = 128;      // rows per forward tile  (8 row tiles of 16)
+constexpr int kBwdTM = 64;       // rows per backward tile (4 row tiles of 16)
 constexpr int kMaxT = 8;         // max 16-wide tiles along K or N (=> K,N <= 128)
-constexpr int kMaxSlabs = 256;
+constexpr int kMaxGrid = 256;    // one workgroup per CU
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
 struct InXform {       // T(x): BatchNorm affine of the producer + dropout, applied on load
-  const float* scale;  // (K) or null
+  const float* scale;  // (K) or null (global; the kernels stage scale|shift into LDS once)
   const float* shift;  // (K) or null
   DropoutCfg drop;
 };
 
-// stage a (kTM x K) tile of x through T() into LDS [kTM][ldx] (zero pad to Kp columns)
-__device__ __forceinline__ void stage_x_tile(float* Xs, int ldx, const float* __restrict__ x, int64_t ldg, int64_t row_base,
-                                             int64_t batch, int K, int Kp, const InXform& t, int64_t row0, bool vec_ok,
-                                             float ones_col_val, int ones_col) {
-  const int cq_n = Kp >> 2;
-  for (int idx = threadIdx.x; idx < kTM * cq_n; idx += blockDim.x) {
-    const int r = idx / cq_n, cq = idx - r * cq_n;
-    const int c = cq << 2;
-    const int64_t gr = row_base + r;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gr < batch && c < K) {
-      const float* src = x + gr * ldg + c;
-      if (vec_ok && c + 3 < K) {
-        const float4 q = *reinterpret_cast<const float4*>(src);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-      } else {
+// 8 consecutive floats of row gr starting at column c (zeros outside [0,K) x [0,batch))
+__device__ __forceinline__ void load8(float (&v)[8], const float* __restrict__ base, int64_t ld, int64_t gr, int64_t batch,
+                                      int c, int K, bool vec_ok) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (c + i < K) v[i] = src[i];
-      }
-      if (t.scale) {
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  if (gr >= batch || c >= K) return;
+  const float* src = base + gr * ld + c;
+  if (vec_ok && c + 7 < K) {
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (c + i < K) v[i] = v[i] * t.scale[c + i] + t.shift[c + i];
-      }
-      if (t.drop.thr) {
-        const Philox4 d = dropout_draw4(t.drop, row0 + gr, (uint32_t)cq);
-        v[0] = d.x >= t.drop.thr ? v[0] * t.drop.inv_keep : 0.f;
-        v[1] = d.y >= t.drop.thr ? v[1] * t.drop.inv_keep : 0.f;
-        v[2] = d.z >= t.drop.thr ? v[2] * t.drop.inv_keep : 0.f;
-        v[3] = d.w >= t.drop.thr ? v[3] * t.drop.inv_keep : 0.f;
-      }
-    }
-    if (ones_col >= 0 && gr < batch && c <= ones_col && ones_col < c + 4) v[ones_col - c] = ones_col_val;
-    *reinterpret_cast<float4*>(Xs + r * ldx + c) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int i = 0; i < 8; ++i) if (c + i < K) v[i] = src[i];
   }
 }
 
-// W (K x N row-major) -> LDS [Kp][ldw], zero padded
-__device__ __forceinline__ void stage_w(float* Ws, int ldw, const float* __restrict__ W, int K, int N, int Kp, int Np) {
-  for (int idx = threadIdx.x; idx < Kp * Np; idx += blockDim.x) {
-    const int k = idx / Np, n = idx - k * Np;
-    Ws[k * ldw + n] = (k < K && n < N) ? W[k * N + n] : 0.f;
+// T(): BN affine + dropout on one 8-column chunk; returns the keep bits
+// ss = LDS copy [scale (Kp) | shift (Kp)], zero padded, or null
+__device__ __forceinline__ uint32_t xform8(float (&v)[8], const InXform& t, const float* ss, int Kp, int64_t grow, int c, int K, bool live) {
+  if (!live) return 0u;
+  if (ss) {
+    const float4 s0 = *reinterpret_cast<const float4*>(ss + c), s1 = *reinterpret_cast<const float4*>(ss + c + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(ss + Kp + c), h1 = *reinterpret_cast<const float4*>(ss + Kp + c + 4);
+    v[0] = v[0] * s0.x + h0.x; v[1] = v[1] * s0.y + h0.y; v[2] = v[2] * s0.z + h0.z; v[3] = v[3] * s0.w + h0.w;
+    v[4] = v[4] * s1.x + h1.x; v[5] = v[5] * s1.y + h1.y; v[6] = v[6] * s1.z + h1.z; v[7] = v[7] * s1.w + h1.w;
   }
+  uint32_t bits = 0xFFu;
+  if (t.drop.thr) {
+    bits = dropout_keep8(t.drop, grow, (uint32_t)(c >> 3));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ((bits >> i) & 1u) ? v[i] * t.drop.inv_keep : 0.f;
+  }
+  return bits;
+}
+
+__device__ __forceinline__ void store8_lds(float* dst, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int NT>
-__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
-                                                         const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
-                                                         int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
-                                                         double* __restrict__ stats) {
+// NTP = n-tiles covered by the 8 waves (1,2,4,8): wave -> (n-tile = wave % NTP, row group = wave / NTP)
+template <int NTP>
+__global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
+                                                              int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
+                                                              double* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int Kp = (K + 15) & ~15, Np = NT * 16;
-  const int ldw = Np + 4, ldx = Kp + 4;
-  float* Ws = smem;
-  float* Xs = Ws + Kp * ldw;
-  __shared__ double red[2][kMaxT * 16];
+  constexpr int RGN = 8 / NTP;            // row groups; each wave owns NTP of the tile's 8 row tiles
+  const int Kp = (K + 15) & ~15, KJ = Kp >> 4;
+  const int ldx = Kp + 4;
+  float* Xb[2] = {smem, smem + kFwdTM * ldx};
+  float* ssb = smem + 2 * kFwdTM * ldx;          // [scale Kp | shift Kp]
+  const float* ss = tin.scale ? ssb : nullptr;
+  if (tin.scale)
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+      ssb[k] = k < K ? tin.scale[k] : 0.f;
+      ssb[Kp + k] = k < K ? tin.shift[k] : 0.f;
+    }
+  __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
+  const int nt = wave % NTP, rgp = wave / NTP;
+  const int ncol = nt * 16 + c16;
   const bool vec_ok = (ldx_g % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
-  stage_w(Ws, ldw, W, K, N, Kp, Np);
-  float bcol[NT], ssum[NT], ssq[NT];
+  // this wave's W fragments: bw[4j+s] = W[16j+4g+s][ncol]
+  float bw[32];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + c16;
-    bcol[nt] = (bias && n < N) ? bias[n] : 0.f;
-    ssum[nt] = 0.f; ssq[nt] = 0.f;
-  }
-  const int64_t n_tiles = (batch + kTM - 1) / kTM;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row_base = tile * kTM;
-    __syncthreads();  // previous tile's MFMA reads done (and Ws staged on the first pass)
-    stage_x_tile(Xs, ldx, x, ldx_g, row_base, batch, K, Kp, tin, row0, vec_ok, 0.f, -1);
-    __syncthreads();
-    f32x4 acc[NT];
+  for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xr = Xs + (wave * 16 + c16) * ldx + 4 * g;
-    for (int j = 0; j < Kp; j += 16) {
-      const float4 a4 = *reinterpret_cast<const float4*>(xr + j);
-      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-      const float* wr = Ws + (j + 4 * g) * ldw + c16;
+    for (int s = 0; s < 4; ++s) {
+      const int k = 16 * j + 4 * g + s;
+      bw[4 * j + s] = (k < K && ncol < N) ? W[k * N + ncol] : 0.f;
+    }
+  const float bcol = (bias && ncol < N) ? bias[ncol] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+
+  const int chunks_per_row = Kp >> 3;
+  const int n_chunks = kFwdTM * chunks_per_row;     // <= 2048 => <= 4 per thread
+  float pre[4][8];
+  const int64_t n_tiles = (batch + kFwdTM - 1) / kFwdTM;
+
+  auto load_tile = [&](int64_t tile) {
+    const int64_t row_base = tile * kFwdTM;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a[s], wr[s * ldw + nt * 16], acc[nt]);
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + kThreads * i;
+      if (idx < n_chunks) {
+        const int r = idx / chunks_per_row, c = (idx - r * chunks_per_row) << 3;
+        load8(pre[i], x, ldx_g, row_base + r, batch, c, K, vec_ok);
       }
     }
-    // epilogue: lane holds rows 4g..4g+3 of its wave's 16, column nt*16+c16
+  };
+  auto write_tile = [&](int64_t tile, float* Xs) {
+    const int64_t row_base = tile * kFwdTM;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + c16;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + kThreads * i;
+      if (idx < n_chunks) {
+        const int r = idx / chunks_per_row, c = (idx - r * chunks_per_row) << 3;
+        xform8(pre[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
+        store8_lds(Xs + r * ldx + c, pre[i]);
+      }
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  int cur = 0;
+  if (tile < n_tiles) {
+    load_tile(tile);
+    write_tile(tile, Xb[0]);
+  }
+  __syncthreads();
+  while (tile < n_tiles) {
+    const int64_t next = tile + gridDim.x;
+    if (next < n_tiles) load_tile(next);
+    // ---- MFMA: NTP row tiles of this wave's row group x its n-tile, two row tiles (two independent
+    //      accumulator chains) at a time; the row-tile loop stays rolled to bound live LDS reads ----
+    const float* Xs = Xb[cur];
+    const int64_t row_base = tile * kFwdTM;
+    constexpr int PAIR = NTP >= 2 ? 2 : 1;
+#pragma unroll 1
+    for (int i0 = 0; i0 < NTP; i0 += PAIR) {
+      f32x4 acc[PAIR];
+      const float* xr[PAIR];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gr = row_base + wave * 16 + 4 * g + r;
-        const float v = act_apply(acc[nt][r] + bcol[nt], act);
-        if (gr < batch && n < N) {
-          y[gr * ldy + n] = v;
-          ssum[nt] += v;
-          ssq[nt] += v * v;
+      for (int p = 0; p < PAIR; ++p) {
+        acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        xr[p] = Xs + ((rgp + RGN * (i0 + p)) * 16 + c16) * ldx + 4 * g;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < KJ) {
+#pragma unroll
+          for (int p = 0; p < PAIR; ++p) {
+            const float4 a4 = *reinterpret_cast<const float4*>(xr[p] + 16 * j);
+            acc[p] = mfma16(a4.x, bw[4 * j + 0], acc[p]);
+            acc[p] = mfma16(a4.y, bw[4 * j + 1], acc[p]);
+            acc[p] = mfma16(a4.z, bw[4 * j + 2], acc[p]);
+            acc[p] = mfma16(a4.w, bw[4 * j + 3], acc[p]);
+          }
+        }
+      }
+      // epilogue: lane holds rows 4g..4g+3 of each row tile, column ncol
+#pragma unroll
+      for (int p = 0; p < PAIR; ++p) {
+        const int rt = rgp + RGN * (i0 + p);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = row_base + rt * 16 + 4 * g + r;
+          const float v = act_apply(acc[p][r] + bcol, act);
+          if (gr < batch && ncol < N) {
+            y[gr * ldy + ncol] = v;
+            ssum += v;
+            ssq += v * v;
+          }
         }
       }
     }
+    if (next < n_tiles) write_tile(next, Xb[cur ^ 1]);
+    __syncthreads();
+    cur ^= 1;
+    tile = next;
   }
   if (stats) {
-    // lanes sharing a column: g = 0..3 -> xor 16, 32; then the 4 waves through LDS
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      double s = (double)ssum[nt], q = (double)ssq[nt];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (wave == 0 && g == 0) { red[0][nt * 16 + c16] = 0.0; red[1][nt * 16 + c16] = 0.0; }
-      ssum[nt] = 0.f;  // reuse below via doubles kept in registers
-      __syncthreads();
-      if (g == 0) { atomicAdd(&red[0][nt * 16 + c16], s); atomicAdd(&red[1][nt * 16 + c16], q); }
-      __syncthreads();
-    }
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-      atomicAdd(stats + n, red[0][n]);
-      atomicAdd(stats + N + n, red[1][n]);
+    double s = (double)ssum, q = (double)ssq;
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    if (g == 0 && ncol < N) {
+      atomicAdd(stats + ncol, s);
+      atomicAdd(stats + N + ncol, q);
     }
   }
 }
@@ -200,7 +259,7 @@ struct OutXform {            // what sits between this layer's y and its consume
   const float* mean;         // (N) BN batch mean, null => no BN
   const float* rstd;         // (N)
   const float* gamma;        // (N)
-  const double* sums;        // (2N): sum_r dh, sum_r dh*xhat
+  const double* sums;        // (2N): sum_r gy, sum_r gy*xhat
   float inv_batch;           // 1 / global batch
 };
 struct InBn {                // BN carried by the input (for the producer's backward sums)
@@ -208,27 +267,38 @@ struct InBn {                // BN carried by the input (for the producer's back
   const float* rstd;
 };
 
-template <int KT, int NT>
-__global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
-                                                         const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
-                                                         int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
-                                                         int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ slabs,
-                                                         double* __restrict__ in_sums) {
+// NT = n-tiles (1..8).  ktp_log2: KTP = pow2 >= KT k-tiles; wave -> (k-tile = wave % KTP, row group = wave / KTP)
+template <int NT>
+__global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
+                                                              const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
+                                                              int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
+                                                              int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ slabs,
+                                                              double* __restrict__ in_sums, int ktp_log2) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int Kp = KT * 16, Np = NT * 16;
-  constexpr int ldw = Np + 4, ldx = Kp + 4, ldz = Np + 4;
-  constexpr int STRIPS = (KT + 3) / 4;  // 16-row strips of K owned by one wave for dW
-  float* Ws = smem;                     // [Kp][ldw]   W[k][n]
-  float* Xs = Ws + Kp * ldw;            // [kTM][ldx]  T(x)
-  float* Zs = Xs + kTM * ldx;           // [kTM][ldz]  dz
-  float* Cs = Zs + kTM * ldz;           // [4][Np]     per-column constants of the out BN
-  __shared__ double redk[2][kMaxT * 16];
+  constexpr int Np = NT * 16, ldz = Np + 4;
+  const int KT = (K + 15) >> 4, Kp = KT << 4, ldx = Kp + 4;
+  const int KTP = 1 << ktp_log2, RGN = 8 >> ktp_log2;
+  const int mkld = (Kp >> 3);                       // mask bytes per row
+  const int buf_floats = kBwdTM * ldx + kBwdTM * ldz + ((kBwdTM * mkld + 3) >> 2);
+  float* Xb[2] = {smem, smem + buf_floats};
+  float* Cs = smem + 2 * buf_floats;                // [4][Np] per-column constants of the out BN
+  float* ssb = Cs + 4 * Np;                         // [scale Kp | shift Kp] of the in transform
+  const float* ss = tin.scale ? ssb : nullptr;
+  if (tin.scale)
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+      ssb[k] = k < K ? tin.scale[k] : 0.f;
+      ssb[Kp + k] = k < K ? tin.shift[k] : 0.f;
+    }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
+  const int kt = wave & (KTP - 1), rg = wave >> ktp_log2;
+  const bool kt_live = kt < KT;
+  const int kcol = kt * 16 + c16;
   const bool xvec = (ldx_g % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const bool gvec = (ldgy % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+  const bool yvec = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
 
-  stage_w(Ws, ldw, W, K, N, Kp, Np);
   for (int n = threadIdx.x; n < Np; n += blockDim.x) {
     float c1 = 1.f, c2 = 0.f, c3 = 0.f, mu = 0.f, rs = 0.f;
     if (to.mean && n < N) {
@@ -239,108 +309,139 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict_
     }
     Cs[0 * Np + n] = c1; Cs[1 * Np + n] = c2; Cs[2 * Np + n] = c3 * rs; Cs[3 * Np + n] = mu;
   }
-  f32x4 dW[STRIPS][NT];
+  // W^T fragments of this wave's k-tile: bwt[4j+s] = W[kcol][16j+4g+s]
+  float bwt[4 * NT];
 #pragma unroll
-  for (int s = 0; s < STRIPS; ++s)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dW[s][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float db_acc = 0.f;                // thread t < Np owns column t of db
-  float isum[KT], isq[KT];           // in-BN sums for column kt*16+c16
-  float imean[KT], irstd[KT];
+    for (int s = 0; s < 4; ++s) {
+      const int n = 16 * j + 4 * g + s;
+      bwt[4 * j + s] = (kt_live && kcol < K && n < N) ? W[(int64_t)kcol * N + n] : 0.f;
+    }
+  f32x4 dW[NT];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    isum[kt] = 0.f; isq[kt] = 0.f;
-    const int k = kt * 16 + c16;
-    imean[kt] = (ibn.mean && k < K) ? ibn.mean[k] : 0.f;
-    irstd[kt] = (ibn.mean && k < K) ? ibn.rstd[k] : 0.f;
+  for (int nt = 0; nt < NT; ++nt) dW[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db_acc = 0.f;                 // thread t < Np owns column t of db
+  float isum = 0.f, isq = 0.f;        // in-BN sums of column kcol
+  const float imean = (ibn.mean && kt_live && kcol < K) ? ibn.mean[kcol] : 0.f;
+  const float irstd = (ibn.mean && kt_live && kcol < K) ? ibn.rstd[kcol] : 0.f;
+
+  const int zc_row = Np >> 3, xc_row = Kp >> 3;
+  const int n_zc = kBwdTM * zc_row, n_xc = kBwdTM * xc_row;     // <= 1024 each => <= 2 per thread
+  float pgy[2][8], py[2][8], px[2][8];
+  const int64_t n_tiles = (batch + kBwdTM - 1) / kBwdTM;
+
+  auto load_tile = [&](int64_t tile) {
+    const int64_t row_base = tile * kBwdTM;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = threadIdx.x + kThreads * i;
+      if (idx < n_zc) {
+        const int r = idx / zc_row, c = (idx - r * zc_row) << 3;
+        load8(pgy[i], gy, ldgy, row_base + r, batch, c, N, gvec);
+        load8(py[i], y, ldy, row_base + r, batch, c, N, yvec);
+      }
+      if (idx < n_xc) {
+        const int r = idx / xc_row, c = (idx - r * xc_row) << 3;
+        load8(px[i], x, ldx_g, row_base + r, batch, c, K, xvec);
+      }
+    }
+  };
+  auto write_tile = [&](int64_t tile, float* buf) {
+    float* Xs = buf;
+    float* Zs = buf + kBwdTM * ldx;
+    uint8_t* Mk = reinterpret_cast<uint8_t*>(Zs + kBwdTM * ldz);
+    const int64_t row_base = tile * kBwdTM;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = threadIdx.x + kThreads * i;
+      if (idx < n_zc) {
+        const int r = idx / zc_row, c = (idx - r * zc_row) << 3;
+        const bool live = (row_base + r) < batch;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = c + e;
+          float da = pgy[i][e];
+          // da = gamma*rstd * (gy - mean(gy) - xhat*mean(gy*xhat)), xhat = (y-mu)*rstd
+          if (to.mean) da = Cs[n] * (pgy[i][e] - Cs[Np + n] - (py[i][e] - Cs[3 * Np + n]) * Cs[2 * Np + n]);
+          v[e] = (live && n < N) ? da * act_grad_from_out(py[i][e], act) : 0.f;
+        }
+        store8_lds(Zs + r * ldz + c, v);
+      }
+      if (idx < n_xc) {
+        const int r = idx / xc_row, c = (idx - r * xc_row) << 3;
+        const uint32_t bits = xform8(px[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
+        store8_lds(Xs + r * ldx + c, px[i]);
+        Mk[r * mkld + (c >> 3)] = (uint8_t)bits;
+      }
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  int cur = 0;
+  __syncthreads();   // Cs visible
+  if (tile < n_tiles) {
+    load_tile(tile);
+    write_tile(tile, Xb[0]);
   }
-
-  const int64_t n_tiles = (batch + kTM - 1) / kTM;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row_base = tile * kTM;
-    __syncthreads();
-    // ---- dz tile (elementwise): dropout^T -> BN^T -> act' -------------------------------
-    {
-      constexpr int cq_n = Np >> 2;
-      for (int idx = threadIdx.x; idx < kTM * cq_n; idx += blockDim.x) {
-        const int r = idx / cq_n, cq = idx - r * cq_n;
-        const int c = cq << 2;
-        const int64_t gr = row_base + r;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gr < batch && c < N) {
-          float gyv[4] = {0.f, 0.f, 0.f, 0.f}, yv[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  while (tile < n_tiles) {
+    const int64_t next = tile + gridDim.x;
+    if (next < n_tiles) load_tile(next);
+    const float* Xs = Xb[cur];
+    const float* Zs = Xs + kBwdTM * ldx;
+    const uint8_t* Mk = reinterpret_cast<const uint8_t*>(Zs + kBwdTM * ldz);
+    const int64_t row_base = tile * kBwdTM;
+    if (kt_live) {
+      // ---- dx[rows of my row tiles][k-tile] = dz · W^T ; contraction over n ----
+      if (gx) {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+          const int rt = rg + RGN * i;
+          if (rt < 4) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* zr = Zs + (rt * 16 + c16) * ldz + 4 * g;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (c + i < N) { gyv[i] = gy[gr * ldgy + c + i]; yv[i] = y[gr * ldy + c + i]; }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float da = gyv[i];
-            if (to.mean) {
-              const int n = c + i;
-              // da = gamma*rstd * (dh - mean(dh) - xhat*mean(dh*xhat)), xhat = (y-mu)*rstd
-              da = Cs[n] * (gyv[i] - Cs[Np + n] - (yv[i] - Cs[3 * Np + n]) * Cs[2 * Np + n]);
+            for (int j = 0; j < NT; ++j) {
+              const float4 a4 = *reinterpret_cast<const float4*>(zr + 16 * j);
+              acc = mfma16(a4.x, bwt[4 * j + 0], acc);
+              acc = mfma16(a4.y, bwt[4 * j + 1], acc);
+              acc = mfma16(a4.z, bwt[4 * j + 2], acc);
+              acc = mfma16(a4.w, bwt[4 * j + 3], acc);
             }
-            v[i] = (c + i < N) ? da * act_grad_from_out(yv[i], act) : 0.f;
-          }
-        }
-        *reinterpret_cast<float4*>(Zs + r * ldz + c) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-    stage_x_tile(Xs, ldx, x, ldx_g, row_base, batch, K, Kp, tin, row0, xvec, 0.f, -1);
-    __syncthreads();
-
-    // ---- dx = dz · W^T : wave owns rows wave*16.., all KT column tiles; contraction over n ----
-    if (gx) {
-      f32x4 acc[KT];
+            if (kcol < K) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* zr = Zs + (wave * 16 + c16) * ldz + 4 * g;
-      for (int j = 0; j < Np; j += 16) {
-        const float4 a4 = *reinterpret_cast<const float4*>(zr + j);
-        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          const float4 b4 = *reinterpret_cast<const float4*>(Ws + (kt * 16 + c16) * ldw + j + 4 * g);
-          acc[kt] = mfma16(a[0], b4.x, acc[kt]);
-          acc[kt] = mfma16(a[1], b4.y, acc[kt]);
-          acc[kt] = mfma16(a[2], b4.z, acc[kt]);
-          acc[kt] = mfma16(a[3], b4.w, acc[kt]);
-        }
-      }
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const int k = kt * 16 + c16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gr = row_base + wave * 16 + 4 * g + r;
-          if (gr < batch && k < K) {
-            // gx = gradient w.r.t. the producer's BN output h (dropout transposed here)
-            const float dh = acc[kt][r] * dropout_scale1(tin.drop, row0 + gr, (uint32_t)k);
-            gx[gr * ldgx + k] = dh;
-            if (ibn.mean) {
-              const float xhat = (x[gr * ldx_g + k] - imean[kt]) * irstd[kt];
-              isum[kt] += dh;
-              isq[kt] += dh * xhat;
+              for (int r = 0; r < 4; ++r) {
+                const int lr = rt * 16 + 4 * g + r;
+                const int64_t gr = row_base + lr;
+                if (gr < batch) {
+                  // gx = gradient w.r.t. the producer's BN output h (dropout transposed here)
+                  const bool keep = (Mk[lr * mkld + (kcol >> 3)] >> (kcol & 7)) & 1;
+                  const float dh = keep ? acc[r] * tin.drop.inv_keep : 0.f;
+                  gx[gr * ldgx + kcol] = dh;
+                  if (ibn.mean && keep) {
+                    const float xhat = (x[gr * ldx_g + kcol] - imean) * irstd;
+                    isum += dh;
+                    isq += dh * xhat;
+                  }
+                }
+              }
             }
           }
         }
       }
-    }
-    // ---- dW += T(x)^T · dz : wave owns K-strips {wave, wave+4}; contraction over the tile rows ----
-    for (int j = 0; j < kTM; j += 16) {
+      // ---- dW[k-tile rows][N] += T(x)^T · dz ; contraction over my row tiles' rows ----
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int rt = rg + RGN * i;
+        if (rt < 4) {
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int r = j + 4 * g + s4;
-        float bz[NT];
+          for (int s = 0; s < 4; ++s) {
+            const int r = rt * 16 + 4 * g + s;
+            const float a = Xs[r * ldx + kcol];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bz[nt] = Zs[r * ldz + nt * 16 + c16];
-#pragma unroll
-        for (int s = 0; s < STRIPS; ++s) {
-          const int strip = wave + 4 * s;
-          if (strip < KT) {
-            const float a = Xs[r * ldx + strip * 16 + c16];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) dW[s][nt] = mfma16(a, bz[nt], dW[s][nt]);
+            for (int nt = 0; nt < NT; ++nt) dW[nt] = mfma16(a, Zs[r * ldz + nt * 16 + c16], dW[nt]);
           }
         }
       }
@@ -348,55 +449,70 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict_
     // ---- db: thread t < Np sums column t of dz ----
     if (threadIdx.x < Np) {
       float sacc = 0.f;
-      for (int r = 0; r < kTM; ++r) sacc += Zs[r * ldz + threadIdx.x];
+#pragma unroll 8
+      for (int r = 0; r < kBwdTM; ++r) sacc += Zs[r * ldz + threadIdx.x];
       db_acc += sacc;
     }
+    if (next < n_tiles) write_tile(next, Xb[cur ^ 1]);
+    __syncthreads();
+    cur ^= 1;
+    tile = next;
   }
 
-  // ---- slab: [dW (K x N) | db (N)] of this workgroup ----
-  float* slab = slabs + (int64_t)blockIdx.x * ((int64_t)K * N + N);
+  // ---- slab (workgroup, row group): [dW (K x N) | db (N)] ----
+  const int64_t slab_elems = (int64_t)K * N + N;
+  if (kt_live) {
+    float* slab = slabs + ((int64_t)blockIdx.x * RGN + rg) * slab_elems;
 #pragma unroll
-  for (int s = 0; s < STRIPS; ++s) {
-    const int strip = wave + 4 * s;
-    if (strip < KT) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + c16;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = nt * 16 + c16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = strip * 16 + 4 * g + r;
-          if (k < K && n < N) slab[(int64_t)k * N + n] = dW[s][nt][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int k = kt * 16 + 4 * g + r;
+        if (k < K && n < N) slab[(int64_t)k * N + n] = dW[nt][r];
       }
     }
   }
-  if (threadIdx.x < N) slab[(int64_t)K * N + threadIdx.x] = db_acc;
-
-  if (in_sums && ibn.mean) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      double s = (double)isum[kt], q = (double)isq[kt];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (wave == 0 && g == 0) { redk[0][kt * 16 + c16] = 0.0; redk[1][kt * 16 + c16] = 0.0; }
-      __syncthreads();
-      if (g == 0) { atomicAdd(&redk[0][kt * 16 + c16], s); atomicAdd(&redk[1][kt * 16 + c16], q); }
-      __syncthreads();
-    }
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-      atomicAdd(in_sums + k, redk[0][k]);
-      atomicAdd(in_sums + K + k, redk[1][k]);
+  if ((int)threadIdx.x < N) {
+    for (int r = 0; r < RGN; ++r)
+      slabs[((int64_t)blockIdx.x * RGN + r) * slab_elems + (int64_t)K * N + threadIdx.x] = (r == 0) ? db_acc : 0.f;
+  }
+  if (in_sums && ibn.mean && kt_live) {
+    double s = (double)isum, q = (double)isq;
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    if (g == 0 && kcol < K) {
+      atomicAdd(in_sums + kcol, s);
+      atomicAdd(in_sums + K + kcol, q);
     }
   }
 }
 
-// fixed-order slab reduction: out[e] = sum_s slabs[s][e], s ascending (reproducible)
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int64_t elems, float* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
+// fixed-order slab reduction (reproducible): out[e] = sum over slabs, combined as 16 interleaved
+// partial sums (part p takes slabs p, p+16, ...) added in part order.  64 elements x 16 parts per
+// workgroup: every load is a coalesced 256-B row segment and 16 waves share the latency.
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int64_t elems, float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
   float acc = 0.f;
-  for (int s = 0; s < n_slabs; ++s) acc += slabs[(int64_t)s * elems + e];
-  out[e] = acc;
+  if (e < elems) {
+    int s = p;
+    for (; s + 48 < n_slabs; s += 64) {   // 4 independent loads in flight
+      const float a0 = slabs[(int64_t)s * elems + e], a1 = slabs[(int64_t)(s + 16) * elems + e];
+      const float a2 = slabs[(int64_t)(s + 32) * elems + e], a3 = slabs[(int64_t)(s + 48) * elems + e];
+      acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; s < n_slabs; s += 16) acc += slabs[(int64_t)s * elems + e];
+  }
+  part[p][lane] = acc;
+  __syncthreads();
+  if (p == 0 && e < elems) {
+    float r = part[0][lane];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) r += part[q][lane];
+    out[e] = r;
+  }
 }
 
 // ------------------------------------------------------------------------------------- head
@@ -502,10 +618,13 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
 using namespace br;
 
 static inline int tiles16(int v) { return (v + 15) / 16; }
-static inline unsigned mlp_grid(int64_t batch) {
-  int64_t t = ceil_div(batch, kTM);
-  return (unsigned)(t < kMaxSlabs ? (t < 1 ? 1 : t) : kMaxSlabs);
+static inline int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int log2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline unsigned grid_for(int64_t batch, int tm) {
+  int64_t t = ceil_div(batch, tm);
+  return (unsigned)(t < kMaxGrid ? (t < 1 ? 1 : t) : kMaxGrid);
 }
+constexpr int kMaxDynLds = 160 * 1024 - 2048;
 
 extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
                               int64_t batch, int K, int N, int act, const float* in_scale, const float* in_shift,
@@ -517,22 +636,22 @@ extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const
   BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
   BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
   if (batch == 0) return BR_OK;
-  const int NT = tiles16(N), Kp = tiles16(K) * 16;
-  const size_t shmem = ((size_t)Kp * (NT * 16 + 4) + (size_t)kTM * (Kp + 4)) * sizeof(float);
+  const int NTP = pow2_ge(tiles16(N)), Kp = tiles16(K) * 16;
+  const size_t shmem = ((size_t)2 * kFwdTM * (Kp + 4) + 2 * (size_t)Kp) * sizeof(float);
   InXform t{in_scale, in_shift, make_dropout(drop_p, seed, step, site)};
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = mlp_grid(batch);
-#define BR_FWD(NTv)                                                                                                   \
-  case NTv: {                                                                                                         \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
-    dense_fwd_kernel<NTv><<<grid, 256, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats);        \
+  const unsigned grid = grid_for(batch, kFwdTM);
+#define BR_FWD(NTv)                                                                                                      \
+  case NTv: {                                                                                                            \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds); \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    dense_fwd_kernel<NTv><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats);      \
   } break;
-  switch (NT) {
-    BR_FWD(1) BR_FWD(2) BR_FWD(3) BR_FWD(4) BR_FWD(5) BR_FWD(6) BR_FWD(7) BR_FWD(8)
+  switch (NTP) {
+    BR_FWD(1) BR_FWD(2) BR_FWD(4) BR_FWD(8)
     default: br::set_error("brDenseForward: unsupported N"); return BR_ERR_UNSUPPORTED;
   }
   BR_CHECK_LAUNCH("brDenseForward");
@@ -566,30 +685,17 @@ extern "C" int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta
 }
 
 extern "C" int brDenseBackwardSlabs(int64_t batch, int K, int N) {
-  (void)K; (void)N;
-  return (int)mlp_grid(batch);
-}
-
-template <int KT, int NT>
-static int launch_bwd(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy,
-                      const float* x, int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin,
-                      InBn ibn, int64_t row0, float* gx, int64_t ldgx, float* slabs, double* in_sums) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_bwd_kernel<KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    attr_set = true;
-  }
-  dense_bwd_kernel<KT, NT><<<grid, 256, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, slabs, in_sums);
-  return 0;
+  (void)N;
+  const int KTP = pow2_ge(tiles16(K < 1 ? 1 : K));
+  return (int)grid_for(batch, kBwdTM) * (8 / KTP);
 }
 
 extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
                                const float* W, int64_t batch, int K, int N, int act, const float* out_mean,
                                const float* out_rstd, const float* out_gamma, const double* bn_sums, double batch_total,
-                               const float* in_scale, const float* in_shift,
-                               const float* in_mean, const float* in_rstd, float in_drop_p, uint32_t in_site, uint64_t seed,
-                               uint32_t step, int64_t row0, float* gx, int64_t ldgx, float* dW_slabs, int n_slabs,
-                               double* in_bn_sums, brStream stream) {
+                               const float* in_scale, const float* in_shift, const float* in_mean, const float* in_rstd,
+                               float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0, float* gx,
+                               int64_t ldgx, float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream) {
   BR_CHECK_ARG(gy && y && x && W && dW_slabs && batch >= 0 && K >= 1 && N >= 1, "brDenseBackward: bad args");
   BR_CHECK_ARG(K <= kMaxT * 16 && N <= kMaxT * 16, "brDenseBackward: K=%d N=%d exceed %d", K, N, kMaxT * 16);
   BR_CHECK_ARG(ldgy >= N && ldy >= N && ldx >= K && (!gx || ldgx >= K), "brDenseBackward: bad leading dims");
@@ -600,27 +706,39 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
                "brDenseBackward: in BN pointers all or none");
   BR_CHECK_ARG(!in_mean || gx, "brDenseBackward: in BN sums need gx");
   if (batch == 0) return BR_OK;
-  const unsigned grid = mlp_grid(batch);
-  BR_CHECK_ARG(n_slabs == (int)grid, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %u", n_slabs, grid);
+  const unsigned grid = grid_for(batch, kBwdTM);
+  const int want = brDenseBackwardSlabs(batch, K, N);
+  BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
   const int KT = tiles16(K), NT = tiles16(N);
   const int Kp = KT * 16, Np = NT * 16;
-  const size_t shmem = ((size_t)Kp * (Np + 4) + (size_t)kTM * (Kp + 4) + (size_t)kTM * (Np + 4) + 4 * (size_t)Np) * sizeof(float);
+  const int ktp_log2 = log2i(pow2_ge(KT));
+  const size_t buf_floats = (size_t)kBwdTM * (Kp + 4) + (size_t)kBwdTM * (Np + 4) + (size_t)((kBwdTM * (Kp / 8) + 3) / 4);
+  const size_t shmem = (2 * buf_floats + 4 * (size_t)Np + 2 * (size_t)Kp) * sizeof(float);
   OutXform to{out_mean, out_rstd, out_gamma, bn_sums, (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch))};
   InXform tin{in_scale, in_shift, make_dropout(in_drop_p, seed, step, in_site)};
   InBn ibn{in_mean, in_rstd};
   hipStream_t s = (hipStream_t)stream;
-#define BR_BWD(KTv, NTv) \
-  if (KT == KTv && NT == NTv) { launch_bwd<KTv, NTv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dW_slabs, in_bn_sums); } else
-#define BR_BWD_ROW(KTv) BR_BWD(KTv, 1) BR_BWD(KTv, 2) BR_BWD(KTv, 3) BR_BWD(KTv, 4) BR_BWD(KTv, 5) BR_BWD(KTv, 6) BR_BWD(KTv, 7) BR_BWD(KTv, 8)
-  BR_BWD_ROW(1) BR_BWD_ROW(2) BR_BWD_ROW(3) BR_BWD_ROW(4) BR_BWD_ROW(5) BR_BWD_ROW(6) BR_BWD_ROW(7) BR_BWD_ROW(8)
-  { br::set_error("brDenseBackward: unsupported K/N"); return BR_ERR_UNSUPPORTED; }
+#define BR_BWD(NTv)                                                                                                      \
+  case NTv: {                                                                                                            \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)dense_bwd_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds); \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    dense_bwd_kernel<NTv><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, \
+                                                        dW_slabs, in_bn_sums, ktp_log2);                                 \
+  } break;
+  switch (NT) {
+    BR_BWD(1) BR_BWD(2) BR_BWD(3) BR_BWD(4) BR_BWD(5) BR_BWD(6) BR_BWD(7) BR_BWD(8)
+    default: br::set_error("brDenseBackward: unsupported N"); return BR_ERR_UNSUPPORTED;
+  }
   BR_CHECK_LAUNCH("brDenseBackward");
   return BR_OK;
 }
 
 extern "C" int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* out, brStream stream) {
   BR_CHECK_ARG(slabs && out && n_slabs >= 1 && slab_elems >= 1, "brReduceSlabs: bad args");
-  reduce_slabs_kernel<<<(unsigned)ceil_div(slab_elems, 256), 256, 0, (hipStream_t)stream>>>(slabs, n_slabs, slab_elems, out);
+  reduce_slabs_kernel<<<(unsigned)ceil_div(slab_elems, 64), 1024, 0, (hipStream_t)stream>>>(slabs, n_slabs, slab_elems, out);
   BR_CHECK_LAUNCH("brReduceSlabs");
   return BR_OK;
 }

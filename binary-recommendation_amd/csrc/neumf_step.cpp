@@ -1,0 +1,173 @@
+// brNeumfStepRun: the NeuMF step as one host call (launch sequencing only; see include/binrec.h).
+#include "common.h"
+
+#include <vector>
+
+// Optional launch probe (bench.py's roofline leg): HIP events recorded on the launch stream around
+// each inner call of the step driver.  Events are created in brProbeEnable (never in the launch
+// path); brProbeRead is called by the host after it synchronised the stream.
+namespace {
+struct Probe {
+  std::vector<hipEvent_t> ev;   // 2 per record
+  std::vector<int> tag;
+  int n = 0, cap = 0;
+};
+Probe g_probe;
+inline void probe_begin(int tag, hipStream_t s) {
+  if (g_probe.n < g_probe.cap) {
+    g_probe.tag[g_probe.n] = tag;
+    (void)hipEventRecord(g_probe.ev[2 * g_probe.n], s);
+  }
+}
+inline void probe_end(hipStream_t s) {
+  if (g_probe.n < g_probe.cap) {
+    (void)hipEventRecord(g_probe.ev[2 * g_probe.n + 1], s);
+    ++g_probe.n;
+  }
+}
+}  // namespace
+
+extern "C" int brProbeEnable(int capacity) {
+  for (hipEvent_t e : g_probe.ev) (void)hipEventDestroy(e);
+  g_probe.ev.clear(); g_probe.tag.clear(); g_probe.n = 0; g_probe.cap = 0;
+  if (capacity <= 0) return BR_OK;
+  g_probe.ev.resize(2 * (size_t)capacity);
+  g_probe.tag.resize((size_t)capacity);
+  for (auto& e : g_probe.ev)
+    if (hipEventCreate(&e) != hipSuccess) { br::set_error("brProbeEnable: hipEventCreate failed"); return BR_ERR_HIP; }
+  g_probe.cap = capacity;
+  return BR_OK;
+}
+extern "C" int brProbeCount(void) { return g_probe.n; }
+extern "C" int brProbeRead(int i, int* tag, float* ms) {
+  BR_CHECK_ARG(i >= 0 && i < g_probe.n && tag && ms, "brProbeRead: bad index");
+  *tag = g_probe.tag[i];
+  if (hipEventElapsedTime(ms, g_probe.ev[2 * i], g_probe.ev[2 * i + 1]) != hipSuccess) {
+    br::set_error("brProbeRead: events not complete (synchronise the stream first)");
+    return BR_ERR_HIP;
+  }
+  return BR_OK;
+}
+
+#define RUN(tag, call)             \
+  do {                             \
+    probe_begin(tag, hs);          \
+    int rc_ = (call);              \
+    probe_end(hs);                 \
+    if (rc_ != BR_OK) return rc_;  \
+  } while (0)
+
+extern "C" int64_t brNeumfStepSizeof(void) { return (int64_t)sizeof(brNeumfStep); }
+
+extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream) {
+  BR_CHECK_ARG(s != nullptr, "brNeumfStepRun: null struct");
+  const int64_t B = s->batch;
+  if (B == 0) return BR_OK;
+  hipStream_t hs = (hipStream_t)stream;
+  const int D = s->dim, n1 = s->n1, n2 = s->n2, n3 = s->n3;
+  BR_CHECK_ARG(B > 0 && D >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1 && n3 <= 32, "brNeumfStepRun: bad geometry");
+  const bool train = s->training != 0;
+  const float p = train ? s->dropout : 0.f;
+  const double bt = (double)(s->batch_total > 0 ? s->batch_total : B);
+  const float inv_b = (float)(1.0 / bt);
+  // dense parameter layout
+  float* th = s->theta;
+  float* gr = s->grad;
+  int64_t o = 0;
+  const int64_t oW1 = o; o += (int64_t)2 * D * n1;
+  const int64_t ob1 = o; o += n1;
+  const int64_t og1 = o; o += n1;
+  const int64_t obe1 = o; o += n1;
+  const int64_t oW2 = o; o += (int64_t)n1 * n2;
+  const int64_t ob2 = o; o += n2;
+  const int64_t og2 = o; o += n2;
+  const int64_t obe2 = o; o += n2;
+  const int64_t oW3 = o; o += (int64_t)n2 * n3;
+  const int64_t ob3 = o; o += n3;
+  const int64_t oW4 = o; o += n3 + 1;
+  const int64_t ob4 = o; o += 1;
+  const int64_t n_dense = o;
+  float* bn = s->bn;
+  float *scale1 = bn, *shift1 = bn + n1, *mean1 = bn + 2 * n1, *rstd1 = bn + 3 * n1;
+  float *scale2 = bn + 4 * n1, *shift2 = scale2 + n2, *mean2 = scale2 + 2 * n2, *rstd2 = scale2 + 3 * n2;
+  double *stats1 = s->dstat, *stats2 = stats1 + 2 * n1, *bsum1 = stats2 + 2 * n2, *bsum2 = bsum1 + 2 * n1;
+  float *mm1 = s->moving, *mv1 = mm1 + n1, *mm2 = mv1 + n1, *mv2 = mm2 + n2;
+  const int uoff = s->item_first ? D : 0, ioff = s->item_first ? 0 : D;
+  if (ph & BR_PH_FWD1) {
+    if (train) {
+      hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(4 * n1 + 4 * n2), hs);
+      if (e != hipSuccess) { br::set_error("brNeumfStepRun: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
+    }
+    if (ph & BR_PH_EMBED)
+      RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForward(s->user_tab, s->item_tab, s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows,
+                              s->users, s->items, s->id_type, D, B, s->item_first, s->x0, s->dot, s->err_flag, stream));
+    RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, n1, B, 2 * D, n1, s->act, nullptr, nullptr, p, s->seed,
+                       (uint32_t)s->step, 0, s->row0, train ? stats1 : nullptr, stream));
+  }
+  if (ph & BR_PH_FWD2) {
+    if (train)
+      RUN(BR_TAG_SMALL, brBnFinalize(stats1, bt, th + og1, th + obe1, s->bn_eps, s->bn_momentum, mm1, mv1, scale1, shift1, mean1, rstd1, n1, stream));
+    else
+      RUN(BR_TAG_SMALL, brBnInference(th + og1, th + obe1, mm1, mv1, s->bn_eps, scale1, shift1, n1, stream));
+    RUN(BR_TAG_FWD_L2, brDenseForward(s->a1, n1, th + oW2, th + ob2, s->a2, n2, B, n1, n2, s->act, scale1, shift1, p, s->seed, (uint32_t)s->step, 1,
+                       s->row0, train ? stats2 : nullptr, stream));
+  }
+  if (ph & BR_PH_FWD3) {
+    if (train)
+      RUN(BR_TAG_SMALL, brBnFinalize(stats2, bt, th + og2, th + obe2, s->bn_eps, s->bn_momentum, mm2, mv2, scale2, shift2, mean2, rstd2, n2, stream));
+    else
+      RUN(BR_TAG_SMALL, brBnInference(th + og2, th + obe2, mm2, mv2, s->bn_eps, scale2, shift2, n2, stream));
+    RUN(BR_TAG_FWD_L3, brDenseForward(s->a2, n2, th + oW3, th + ob3, s->a3, n3, B, n2, n3, s->act, scale2, shift2, p, s->seed, (uint32_t)s->step, 2,
+                       s->row0, nullptr, stream));
+    if (train) {
+      const int nsh = brHeadSlabs(B);
+      RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob, s->msums,
+                      s->da3, n3, s->ddot, s->hslabs, nsh, stream));
+      RUN(BR_TAG_REDUCE, brReduceSlabs(s->hslabs, nsh, n3 + 2, gr + oW4, stream));
+      const int ns3 = brDenseBackwardSlabs(B, n2, n3);
+      RUN(BR_TAG_BWD_L3, brDenseBackward(s->da3, n3, s->a3, n3, s->a2, n2, th + oW3, B, n2, n3, s->act, nullptr, nullptr, nullptr, nullptr, bt, scale2,
+                          shift2, mean2, rstd2, p, 2, s->seed, (uint32_t)s->step, s->row0, s->gh2, n2, s->slabs, ns3, bsum2, stream));
+      RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns3, (int64_t)n2 * n3 + n3, gr + oW3, stream));
+    } else {
+      RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob,
+                      s->labels ? s->msums : nullptr, nullptr, 0, nullptr, nullptr, 0, stream));
+    }
+  }
+  if (!train) return BR_OK;
+  if (ph & BR_PH_BWD2) {
+    const int ns2 = brDenseBackwardSlabs(B, n1, n2);
+    RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, n2, s->a2, n2, s->a1, n1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt, scale1, shift1,
+                        mean1, rstd1, p, 1, s->seed, (uint32_t)s->step, s->row0, s->gh1, n1, s->slabs, ns2, bsum1, stream));
+    RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns2, (int64_t)n1 * n2 + n2, gr + oW2, stream));
+  }
+  if (ph & BR_PH_BWD1) {
+    const int ns1 = brDenseBackwardSlabs(B, 2 * D, n1);
+    RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, n1, s->a1, n1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt, nullptr,
+                        nullptr, nullptr, nullptr, p, 0, s->seed, (uint32_t)s->step, s->row0, s->dx0, 2 * D, s->slabs, ns1, nullptr, stream));
+    RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns1, (int64_t)2 * D * n1 + n1, gr + oW1, stream));
+  }
+  if (ph & BR_PH_BNG) {
+    RUN(BR_TAG_SMALL, brBnParamGrads(bsum2, gr + og2, gr + obe2, n2, stream));
+    RUN(BR_TAG_SMALL, brBnParamGrads(bsum1, gr + og1, gr + obe1, n1, stream));
+  }
+  if (ph & BR_PH_OPT_TABLES) {
+    if (ph & BR_PH_EMBED)
+      RUN(BR_TAG_EMBED_BWD, brNeumfEmbedBackward(s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows, s->users, s->items, s->id_type, D,
+                               B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, stream));
+    RUN(BR_TAG_INDEX_USER, brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, stream));
+    RUN(BR_TAG_INDEX_ITEM, brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, stream));
+    uint8_t* um = s->adam_dense ? s->user_mark : nullptr;
+    uint8_t* im = s->adam_dense ? s->item_mark : nullptr;
+    RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSorted(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type, s->u_sorted_pos, B,
+                         s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
+    if (s->adam_dense)
+      RUN(BR_TAG_SWEEP_USER, brAdamDenseSweep(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
+    RUN(BR_TAG_ADAM_ROWS_ITEM, brAdamRowsSorted(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->i_sorted_ids, s->id_type, s->i_sorted_pos, B,
+                         s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
+    if (s->adam_dense)
+      RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
+  }
+  if (ph & BR_PH_OPT_DENSE)
+    RUN(BR_TAG_ADAM_FLAT, brAdamFlat(th, s->adam_m, s->adam_v, gr, n_dense, s->alpha_t, s->beta1, s->beta2, s->adam_eps, stream));
+  return BR_OK;
+}

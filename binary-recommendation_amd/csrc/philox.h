@@ -1,10 +1,13 @@
 // Philox4x32-10 counter RNG: the dropout-mask definition of this build.
 //
 // Keras' Dropout stream (trainers/NFC_plain.py:138,141,144; src/models/NeuMFModel.py:67,71,75)
-// is a stateful TF generator that cannot be reproduced, so masks here are a pure function:
-// element (global row r, col c) of dropout site `site` at optimizer step `step` is KEPT iff
-//   philox(key = (seed_lo, seed_hi), ctr = (r_lo, c >> 2, site, step))[c & 3] >= floor(p * 2^32)
-// (rows < 2^32 per step).  oracle/binrec_oracle.py::dropout_mask restates this bit-exactly.
+// is a stateful TF generator that cannot be reproduced, so masks here are a pure function.
+// One Philox call yields 4 x u32 = 8 x u16 draws for the 8 columns 8q..8q+7 of a row; element
+// (global row r, col c) of dropout site `site` at optimizer step `step` is KEPT iff
+//   u16 = (philox(key = (seed_lo, seed_hi), ctr = (r_lo, c >> 3, site, step))[(c >> 1) & 3] >> 16*(c & 1)) & 0xFFFF
+//   u16 >= floor(p * 65536)
+// (rows < 2^32 per step).  oracle/binrec_oracle.py::dropout_mask restates this bit-exactly and
+// pins the generator to the published Random123 known-answer vectors.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,10 +35,10 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
   return Philox4{c0, c1, c2, c3};
 }
 
-// threshold: draw < thr => dropped
+// threshold: u16 draw < thr => dropped
 __host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) {
-  double t = (double)p * 4294967296.0;
-  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  double t = (double)p * 65536.0;
+  if (t >= 65535.0) return 0xFFFFu;
   return (uint32_t)t;  // floor
 }
 
@@ -58,16 +61,24 @@ __host__ inline DropoutCfg make_dropout(float p, uint64_t seed, uint32_t step, u
   return c;
 }
 
-// 4 keep-flags for columns 4*cq .. 4*cq+3 of global row r.
-__device__ __forceinline__ Philox4 dropout_draw4(const DropoutCfg& c, int64_t r, uint32_t cq) {
-  return philox4x32_10((uint32_t)r, cq, c.site, c.step, c.k0, c.k1);
+// keep-bits (bit i = column 8*c8 + i kept) of the 8 columns of chunk c8 of global row r
+__device__ __forceinline__ uint32_t dropout_keep8(const DropoutCfg& c, int64_t r, uint32_t c8) {
+  if (c.thr == 0u) return 0xFFu;
+  const Philox4 d = philox4x32_10((uint32_t)r, c8, c.site, c.step, c.k0, c.k1);
+  uint32_t bits = 0;
+  bits |= ((d.x & 0xFFFFu) >= c.thr) ? 1u : 0u;
+  bits |= ((d.x >> 16) >= c.thr) ? 2u : 0u;
+  bits |= ((d.y & 0xFFFFu) >= c.thr) ? 4u : 0u;
+  bits |= ((d.y >> 16) >= c.thr) ? 8u : 0u;
+  bits |= ((d.z & 0xFFFFu) >= c.thr) ? 16u : 0u;
+  bits |= ((d.z >> 16) >= c.thr) ? 32u : 0u;
+  bits |= ((d.w & 0xFFFFu) >= c.thr) ? 64u : 0u;
+  bits |= ((d.w >> 16) >= c.thr) ? 128u : 0u;
+  return bits;
 }
 __device__ __forceinline__ float dropout_scale1(const DropoutCfg& c, int64_t r, uint32_t col) {
   if (c.thr == 0u) return 1.0f;
-  Philox4 d = dropout_draw4(c, r, col >> 2);
-  uint32_t lane = col & 3u;
-  uint32_t v = lane == 0 ? d.x : lane == 1 ? d.y : lane == 2 ? d.z : d.w;
-  return v >= c.thr ? c.inv_keep : 0.0f;
+  return ((dropout_keep8(c, r, col >> 3) >> (col & 7u)) & 1u) ? c.inv_keep : 0.0f;
 }
 
 }  // namespace br

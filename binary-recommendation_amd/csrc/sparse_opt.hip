@@ -67,13 +67,16 @@ __device__ __forceinline__ void adam_update(float& th, float& m, float& v, float
   adam_update1(th, m, v, g, h);
 }
 
+// Row gradients may come from two buffers: columns [0,split) from g0, [split,dim) from g1 (the fused
+// NeuMF tables [mlp | mf] take their MLP half from dx0 and their MF half from the embed backward).
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict__ table, float* __restrict__ M,
                                                                 float* __restrict__ Vv, int64_t table_rows, int dim,
                                                                 int chunks, int lpr_log2, const IdT* __restrict__ sid,
                                                                 const int32_t* __restrict__ spos, int64_t n,
-                                                                const float* __restrict__ g, int64_t ldg, AdamHp h,
-                                                                uint8_t* __restrict__ mark) {
+                                                                const float* __restrict__ g0, int64_t ldg0,
+                                                                const float* __restrict__ g1, int64_t ldg1, int split,
+                                                                AdamHp h, uint8_t* __restrict__ mark) {
   using V = typename VecT<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,10 +88,12 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict
   if ((uint64_t)row >= (uint64_t)table_rows) return;  // out-of-range ids were flagged by the forward
   if (mark && lir == 0) mark[row] = 1;
   for (int c = lir; c < chunks; c += lpr) {
-    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg + c * VEC);
-    for (int64_t j = i + 1; j < n && (int64_t)sid[j] == row; ++j)
-      acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg + c * VEC));
-    const int64_t off = row * dim + c * VEC;
+    const int col = c * VEC;
+    const float* g = col < split ? g0 + col : g1 + (col - split);
+    const int64_t ldg = col < split ? ldg0 : ldg1;
+    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg);
+    for (int64_t j = i + 1; j < n && (int64_t)sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg));
+    const int64_t off = row * dim + col;
     V th = vload<VEC>(table + off), m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
     adam_update(th, m, v, acc, h);
     vstore<VEC>(table + off, th);
@@ -290,23 +295,29 @@ extern "C" int brScatterAddRows(float* g_table, int64_t table_rows, const void* 
 
 extern "C" int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int dim, const void* sorted_ids,
                                 int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
-                                double alpha_t, double beta1, double beta2, double eps, uint8_t* mark, brStream stream) {
+                                const float* row_grads_hi, int64_t ldg_hi, int split, double alpha_t, double beta1,
+                                double beta2, double eps, uint8_t* mark, brStream stream) {
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdamRowsSorted: bad id_type");
   if (n == 0) return BR_OK;
-  BR_CHECK_ARG(table && m && v && sorted_ids && sorted_pos && row_grads && dim >= 1 && ldg >= dim && table_rows > 0,
-               "brAdamRowsSorted: bad args");
-  const RowGeom g = row_geom_ld(dim, ldg);
+  BR_CHECK_ARG(table && m && v && sorted_ids && sorted_pos && row_grads && dim >= 1 && table_rows > 0, "brAdamRowsSorted: bad args");
+  if (!row_grads_hi) { split = dim; ldg_hi = ldg; row_grads_hi = row_grads; }
+  BR_CHECK_ARG(split >= 1 && split <= dim && ldg >= split && ldg_hi >= dim - split, "brAdamRowsSorted: bad split / strides");
+  // widest vector (floats) that every row start of both sources and the split honour
+  const uintptr_t al = reinterpret_cast<uintptr_t>(row_grads) | reinterpret_cast<uintptr_t>(row_grads_hi);
+  int64_t ldmin = (ldg % 4 == 0 && ldg_hi % 4 == 0 && split % 4 == 0 && (al & 15) == 0) ? 4
+                  : (ldg % 2 == 0 && ldg_hi % 2 == 0 && split % 2 == 0 && (al & 7) == 0) ? 2 : 1;
+  const RowGeom g = row_geom_ld(dim, ldmin);
   const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
   const AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
                                table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int32_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, h, mark)));
+                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark)));
   else
     BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
                                table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int64_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, h, mark)));
+                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark)));
   BR_CHECK_LAUNCH("brAdamRowsSorted");
   return BR_OK;
 }

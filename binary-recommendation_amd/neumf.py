@@ -12,12 +12,13 @@ stream and (data-parallel) the RCCL collectives.  One training step is the launc
 """
 from __future__ import annotations
 
+import ctypes
 import dataclasses
 import math
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 DENSE_ORDER = ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "W3", "b3", "W4", "b4")
 TABLES = ("user_mlp", "item_mlp", "user_mf", "item_mf")
@@ -109,10 +110,17 @@ class NeuMFEngine:
         self.grad = _Flat(cfg.dense_shapes(), dev)
         self.adam_m = _Flat(cfg.dense_shapes(), dev)
         self.adam_v = _Flat(cfg.dense_shapes(), dev)
-        self.tab_m = {k: torch.zeros_like(v) for k, v in self.tables.items()}
-        self.tab_v = {k: torch.zeros_like(v) for k, v in self.tables.items()}
-        self.moving = {"mm1": torch.zeros(n1, device=dev), "mv1": torch.ones(n1, device=dev),
-                       "mm2": torch.zeros(n2, device=dev), "mv2": torch.ones(n2, device=dev)}
+        self.fused_m = {k: torch.zeros_like(v) for k, v in self.fused.items()}
+        self.fused_v = {k: torch.zeros_like(v) for k, v in self.fused.items()}
+        self.tab_m = {"user_mlp": self.fused_m["user"][:, :D], "user_mf": self.fused_m["user"][:, D:],
+                      "item_mlp": self.fused_m["item"][:, :D], "item_mf": self.fused_m["item"][:, D:]}
+        self.tab_v = {"user_mlp": self.fused_v["user"][:, :D], "user_mf": self.fused_v["user"][:, D:],
+                      "item_mlp": self.fused_v["item"][:, :D], "item_mf": self.fused_v["item"][:, D:]}
+        self.moving_buf = torch.zeros(2 * n1 + 2 * n2, device=dev)      # [mm1 | mv1 | mm2 | mv2]
+        self.moving = {"mm1": self.moving_buf[:n1], "mv1": self.moving_buf[n1:2 * n1],
+                       "mm2": self.moving_buf[2 * n1:2 * n1 + n2], "mv2": self.moving_buf[2 * n1 + n2:]}
+        self.moving["mv1"].fill_(1.0)
+        self.moving["mv2"].fill_(1.0)
         self.t = 0
         self._alloc(self.max_batch)
 
@@ -121,14 +129,25 @@ class NeuMFEngine:
         return self.num_user_rows if name.startswith("user") else self.num_item_rows
 
     def _init_tables(self, g, init_seed):
+        """HBM layout: ONE allocation per id stream, rows = [mlp (dim) | mf (dim)] (512 B at dim 64), so
+        a lookup touches one contiguous row instead of two; `self.tables` exposes the four reference
+        tables (NFC_plain.py:115-126) as column views."""
         D, dev = self.cfg.dim, self.device
-        for name in TABLES:
-            rows = self.local_rows(name)
-            if rows * D > (1 << 26):   # big tables: draw on the device (same distribution)
-                dg = torch.Generator(device=dev).manual_seed(init_seed + 7919 * (1 + TABLES.index(name)))
-                self.tables[name] = torch.rand(rows, D, generator=dg, device=dev, dtype=torch.float32).mul_(0.1).sub_(0.05)
+        self.fused = {}
+        for si, stream in enumerate(("user", "item")):
+            rows = self.local_rows(stream + "_mf")
+            if rows * 2 * D > (1 << 26):   # big tables: draw on the device (same distribution)
+                dg = torch.Generator(device=dev).manual_seed(init_seed + 7919 * (1 + si))
+                t = torch.rand(rows, 2 * D, generator=dg, device=dev, dtype=torch.float32).mul_(0.1).sub_(0.05)
             else:
-                self.tables[name] = (torch.rand(rows, D, generator=g) * 0.1 - 0.05).to(dev)
+                t = (torch.rand(rows, 2 * D, generator=g) * 0.1 - 0.05).to(dev)
+            self.fused[stream] = t
+        self._make_views()
+
+    def _make_views(self):
+        D = self.cfg.dim
+        self.tables = {"user_mlp": self.fused["user"][:, :D], "user_mf": self.fused["user"][:, D:],
+                       "item_mlp": self.fused["item"][:, :D], "item_mf": self.fused["item"][:, D:]}
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, B):
@@ -140,7 +159,7 @@ class NeuMFEngine:
         self.logit, self.prob = f(B), f(B)
         self.da3, self.ddot = f(B, n3), f(B)
         self.gh2, self.gh1, self.dx0 = f(B, n2), f(B, n1), f(B, 2 * D)
-        self.g_user_mf, self.g_item_mf = f(B, D), f(B, D)
+        self.g_user, self.g_item = f(B, 2 * D), f(B, 2 * D)      # fused [mlp | mf] row gradients per stream
         # per-step double scratch: [stats1 2n1 | stats2 2n2 | bsum1 2n1 | bsum2 2n2]
         self.dstat = torch.zeros(4 * n1 + 4 * n2, dtype=torch.float64, device=dev)
         o = 0
@@ -149,14 +168,73 @@ class NeuMFEngine:
         self.bsum1 = self.dstat[o:o + 2 * n1]; o += 2 * n1
         self.bsum2 = self.dstat[o:o + 2 * n2]
         self.msums = torch.zeros(4, dtype=torch.float64, device=dev)   # loss, se, ae, correct (epoch)
-        self.bn = {k: f(n) for k, n in (("scale1", n1), ("shift1", n1), ("mean1", n1), ("rstd1", n1),
-                                        ("scale2", n2), ("shift2", n2), ("mean2", n2), ("rstd2", n2))}
-        self.ns1 = ops.dense_backward_slabs(B, 2 * D, n1)
-        self.slabs = f(max(self.ns1, 1) * max(2 * D * n1 + n1, n1 * n2 + n2, n2 * n3 + n3))
+        self.bn_buf = f(4 * n1 + 4 * n2)      # [scale1|shift1|mean1|rstd1|scale2|shift2|mean2|rstd2]
+        self.bn, o = {}, 0
+        for k, n in (("scale1", n1), ("shift1", n1), ("mean1", n1), ("rstd1", n1), ("scale2", n2), ("shift2", n2), ("mean2", n2), ("rstd2", n2)):
+            self.bn[k] = self.bn_buf[o:o + n]; o += n
+        layers = ((2 * D, n1), (n1, n2), (n2, n3))
+        self.slabs = f(max(ops.dense_backward_slabs(B, k, n) * (k * n + n) for k, n in layers))
         self.nsh = ops.head_slabs(B)
         self.hslabs = f(self.nsh * (n3 + 2))
         self.err = ops.new_err_flag(dev)
         self._alloc_sparse(B)
+        self._build_step_struct()
+
+    # ------------------------------------------------------------------ C step driver
+    def _build_step_struct(self):
+        """brNeumfStep (include/binrec.h): every pointer the fused step driver needs, filled once."""
+        lib = _lib.load()
+
+        class Step(ctypes.Structure):
+            _fields_ = _lib.parse_struct("brNeumfStep")
+        if ctypes.sizeof(Step) != lib.brNeumfStepSizeof():
+            raise _lib.BinrecError("brNeumfStep layout mismatch between include/binrec.h and libbinrec_hip.so")
+        cfg = self.cfg
+        st = Step()
+        st.user_rows, st.item_rows = self.local_rows("user_mf"), self.local_rows("item_mf")
+        st.dim, (st.n1, st.n2, st.n3) = cfg.dim, cfg.hidden
+        st.act, st.loss = ops.ACT[cfg.act], ops.LOSS[cfg.loss]
+        st.item_first, st.mf_first = cfg.item_first, cfg.mf_first
+        st.id_type = ops.I64 if self.id_dtype == torch.int64 else ops.I32
+        st.adam_dense = 1 if cfg.optimizer == "adam_dense" else 0
+        st.dropout, st.bn_eps, st.bn_momentum = cfg.dropout, cfg.bn_eps, cfg.bn_momentum
+        st.seed = cfg.seed
+        st.beta1, st.beta2, st.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
+        P = lambda t: t.data_ptr()
+        st.user_tab, st.user_m, st.user_v = P(self.fused["user"]), P(self.fused_m["user"]), P(self.fused_v["user"])
+        st.item_tab, st.item_m, st.item_v = P(self.fused["item"]), P(self.fused_m["item"]), P(self.fused_v["item"])
+        if st.adam_dense:
+            st.user_mark, st.item_mark = P(self.user_mark), P(self.item_mark)
+        st.theta, st.grad, st.adam_m, st.adam_v = P(self.theta.buf), P(self.grad.buf), P(self.adam_m.buf), P(self.adam_v.buf)
+        st.moving = P(self.moving_buf)
+        for k in ("x0", "dot", "a1", "a2", "a3", "logit", "prob", "da3", "ddot", "gh2", "gh1", "dx0", "g_user", "g_item"):
+            setattr(st, k, P(getattr(self, k)))
+        st.bn, st.dstat, st.msums = P(self.bn_buf), P(self.dstat), P(self.msums)
+        st.slabs, st.hslabs, st.err_flag = P(self.slabs), P(self.hslabs), P(self.err)
+        self._bind_indexes(st)
+        self.step_struct = st
+        self.PH = {k[6:]: v for k, v in _lib.parse_enums().items() if k.startswith("BR_PH_")}
+
+    def _bind_indexes(self, st):
+        ui, ii = self.user_index, self.item_index
+        st.u_sorted_ids, st.u_sorted_pos, st.u_ws, st.u_ws_bytes = ui.sorted_ids.data_ptr(), ui.sorted_pos.data_ptr(), ui.ws.data_ptr(), ui.ws_bytes
+        st.i_sorted_ids, st.i_sorted_pos, st.i_ws, st.i_ws_bytes = ii.sorted_ids.data_ptr(), ii.sorted_pos.data_ptr(), ii.ws.data_ptr(), ii.ws_bytes
+
+    def _run(self, phases: int):
+        _lib.check(_lib.load().brNeumfStepRun(ctypes.byref(self.step_struct), phases, ops._stream()), "brNeumfStepRun")
+
+    def _set_batch(self, users, items, labels, B, training, row0, batch_total):
+        st = self.step_struct
+        for t in (users, items):
+            if t.dtype != self.id_dtype or not t.is_cuda or not t.is_contiguous():
+                raise TypeError(f"ids must be contiguous {self.id_dtype} device tensors")
+        if labels is not None and (labels.dtype != torch.float32 or not labels.is_contiguous()):
+            raise TypeError("labels must be contiguous float32")
+        st.batch, st.batch_total, st.row0 = B, batch_total, row0
+        st.users, st.items = users.data_ptr(), items.data_ptr()
+        st.labels = labels.data_ptr() if labels is not None else None
+        st.training, st.step = int(training), self.t
+        st.alpha_t = ops.adam_alpha(self.cfg.lr, max(self.t, 1), self.cfg.beta1, self.cfg.beta2)
 
     def _alloc_sparse(self, B):
         dev = self.device
@@ -166,154 +244,117 @@ class NeuMFEngine:
             self.user_mark = torch.zeros(self.local_rows("user_mf"), dtype=torch.uint8, device=dev)
             self.item_mark = torch.zeros(self.local_rows("item_mf"), dtype=torch.uint8, device=dev)
 
-    # ------------------------------------------------------------------ forward (shared)
-    def _forward(self, users, items, B, training, row0, batch_total):
-        cfg, th, bn = self.cfg, self.theta, self.bn
-        p = cfg.dropout if training else 0.0
-        x0, a1, a2, a3 = self.x0[:B], self.a1[:B], self.a2[:B], self.a3[:B]
-        self._embed_forward(users, items, B)
-        step = self.t
-        ops.dense_forward(x0, th.view("W1"), th.view("b1"), a1, cfg.act, drop_p=p, seed=cfg.seed, step=step, site=0,
-                          row0=row0, stats=self.stats1 if training else None)
-        if training:
-            if self.dist is not None and cfg.sync_bn:
-                self.dist.all_reduce_sum(self.stats1)
-            ops.bn_finalize(self.stats1, batch_total, th.view("g1"), th.view("be1"), cfg.bn_eps, cfg.bn_momentum,
-                            self.moving["mm1"], self.moving["mv1"], bn["scale1"], bn["shift1"], bn["mean1"], bn["rstd1"])
-        else:
-            ops.bn_inference(th.view("g1"), th.view("be1"), self.moving["mm1"], self.moving["mv1"], cfg.bn_eps,
-                             bn["scale1"], bn["shift1"])
-        ops.dense_forward(a1, th.view("W2"), th.view("b2"), a2, cfg.act, bn["scale1"], bn["shift1"], drop_p=p,
-                          seed=cfg.seed, step=step, site=1, row0=row0, stats=self.stats2 if training else None)
-        if training:
-            if self.dist is not None and cfg.sync_bn:
-                self.dist.all_reduce_sum(self.stats2)
-            ops.bn_finalize(self.stats2, batch_total, th.view("g2"), th.view("be2"), cfg.bn_eps, cfg.bn_momentum,
-                            self.moving["mm2"], self.moving["mv2"], bn["scale2"], bn["shift2"], bn["mean2"], bn["rstd2"])
-        else:
-            ops.bn_inference(th.view("g2"), th.view("be2"), self.moving["mm2"], self.moving["mv2"], cfg.bn_eps,
-                             bn["scale2"], bn["shift2"])
-        ops.dense_forward(a2, th.view("W3"), th.view("b3"), a3, cfg.act, bn["scale2"], bn["shift2"], drop_p=p,
-                          seed=cfg.seed, step=step, site=2, row0=row0)
+    sharded = False   # the row-sharded subclass runs its own embed exchange (parallel.py)
 
     def _embed_forward(self, users, items, B):
-        """G1+M1+T1: 4 lookups, GMF dot, MLP concat -> x0, dot (one launch)."""
-        t = self.tables
-        ops.neumf_embed_forward(t["user_mlp"], t["item_mlp"], t["user_mf"], t["item_mf"], users, items,
-                                self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
+        raise NotImplementedError   # only the sharded subclass routes the embed block through Python
 
     # ------------------------------------------------------------------ one optimizer step
     def train_step(self, users, items, labels, row0: int = 0, batch_total: int | None = None):
-        """users/items: device int ids (B,), labels: device float32 (B,).  No host sync."""
-        cfg, th, gr, bn = self.cfg, self.theta, self.grad, self.bn
+        """users/items: device int ids (B,), labels: device float32 (B,).  One brNeumfStepRun call on a
+        single GPU (no host sync); with a process group the phases are interleaved with the BatchNorm /
+        dense-gradient all-reduces and, when row-sharded, the embedding exchange."""
+        cfg, PH = self.cfg, self.PH
         B = users.shape[0]
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch {self.max_batch}")
         if B == 0:
             return
         batch_total = B if batch_total is None else batch_total
-        D, (n1, n2, n3) = cfg.dim, cfg.hidden
         self.t += 1
-        step, p, seed = self.t, cfg.dropout, cfg.seed
-        self.dstat.zero_()
-        self._forward(users, items, B, True, row0, batch_total)
-        a1, a2, a3, x0 = self.a1[:B], self.a2[:B], self.a3[:B], self.x0[:B]
-        inv_b = 1.0 / batch_total
-        nsh = ops.head_slabs(B)
-        ops.neumf_head(a3, self.dot[:B], labels, th.view("W4"), th.view("b4"), cfg.mf_first, cfg.loss, inv_b,
-                       logit=self.logit[:B], prob=self.prob[:B], sums=self.msums, da3=self.da3[:B], ddot=self.ddot[:B],
-                       slabs=self.hslabs, n_slabs=nsh)
-        ops.reduce_slabs(self.hslabs, nsh, n3 + 2, gr.slice("W4", "b4"))
-        ns = ops.dense_backward_slabs(B, 0, 0)
-        # layer 3: no BN after it; its input carries BN2 + dropout site 2
-        ops.dense_backward(self.da3[:B], a3, a2, th.view("W3"), cfg.act, self.slabs, ns, gx=self.gh2[:B],
-                           in_scale=bn["scale2"], in_shift=bn["shift2"], in_bn=(bn["mean2"], bn["rstd2"]), in_drop_p=p,
-                           in_site=2, seed=seed, step=step, row0=row0, in_bn_sums=self.bsum2, batch_total=batch_total)
-        ops.reduce_slabs(self.slabs, ns, n2 * n3 + n3, gr.slice("W3", "b3"))
-        if self.dist is not None and cfg.sync_bn:
-            self.dist.all_reduce_sum(self.bsum2)
-        # layer 2
-        ops.dense_backward(self.gh2[:B], a2, a1, th.view("W2"), cfg.act, self.slabs, ns, gx=self.gh1[:B],
-                           out_bn=(bn["mean2"], bn["rstd2"], th.view("g2")), bn_sums=self.bsum2, batch_total=batch_total,
-                           in_scale=bn["scale1"], in_shift=bn["shift1"], in_bn=(bn["mean1"], bn["rstd1"]), in_drop_p=p,
-                           in_site=1, seed=seed, step=step, row0=row0, in_bn_sums=self.bsum1)
-        ops.reduce_slabs(self.slabs, ns, n1 * n2 + n2, gr.slice("W2", "b2"))
-        if self.dist is not None and cfg.sync_bn:
-            self.dist.all_reduce_sum(self.bsum1)
-        # layer 1: input = raw concat with dropout site 0, no BN below
-        ops.dense_backward(self.gh1[:B], a1, x0, th.view("W1"), cfg.act, self.slabs, ns, gx=self.dx0[:B],
-                           out_bn=(bn["mean1"], bn["rstd1"], th.view("g1")), bn_sums=self.bsum1, batch_total=batch_total,
-                           in_drop_p=p, in_site=0, seed=seed, step=step, row0=row0)
-        ops.reduce_slabs(self.slabs, ns, 2 * D * n1 + n1, gr.slice("W1", "b1"))
+        self._set_batch(users, items, labels, B, True, row0, batch_total)
+        if self.dist is None:
+            self._run(PH["ALL"])
+            return
+        d, sync = self.dist, cfg.sync_bn
+        emb = 0 if self.sharded else PH["EMBED"]
+        if self.sharded:
+            self._embed_forward(users, items, B)
+        self._run(PH["FWD1"] | emb)
+        if sync:
+            d.all_reduce_sum(self.stats1)
+        self._run(PH["FWD2"])
+        if sync:
+            d.all_reduce_sum(self.stats2)
+        self._run(PH["FWD3"])
+        if sync:
+            d.all_reduce_sum(self.bsum2)
+        self._run(PH["BWD2"])
+        if sync:
+            d.all_reduce_sum(self.bsum1)
+        self._run(PH["BWD1"])
         # dgamma/dbeta are the BN-backward column sums.  With sync_bn those sums are already global,
         # so they are written AFTER the dense all-reduce; per-replica BN sums are local like the rest.
-        synced = self.dist is not None and cfg.sync_bn
-        if not synced:
-            ops.bn_param_grads(self.bsum2, gr.view("g2"), gr.view("be2"))
-            ops.bn_param_grads(self.bsum1, gr.view("g1"), gr.view("be1"))
-        if self.dist is not None:
-            self.dist.all_reduce_sum(self.grad.buf)
-        if synced:
-            ops.bn_param_grads(self.bsum2, gr.view("g2"), gr.view("be2"))
-            ops.bn_param_grads(self.bsum1, gr.view("g1"), gr.view("be1"))
-        self._embed_backward_apply(users, items, B)
-        a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
-        ops.adam_flat(self.theta.buf, self.adam_m.buf, self.adam_v.buf, self.grad.buf, a, beta1=cfg.beta1, beta2=cfg.beta2,
-                      eps=cfg.adam_eps)
+        if not sync:
+            self._run(PH["BNG"])
+        d.all_reduce_sum(self.grad.buf)
+        if sync:
+            self._run(PH["BNG"])
+        if self.sharded:
+            self._embed_backward_apply(users, items, B)
+        else:
+            self._run(PH["OPT_TABLES"] | PH["EMBED"])
+        self._run(PH["OPT_DENSE"])
 
     def row_grad_views(self, B):
-        """name -> (tensor, row stride): the MLP tables' row gradients are the halves of dx0."""
+        """name -> (tensor, row stride): the MLP halves are views of dx0, the MF halves of g_user / g_item."""
         D = self.cfg.dim
         uo, io = (D, 0) if self.cfg.item_first else (0, D)
         dx0 = self.dx0[:B]
         return {"user_mlp": (dx0[:, uo:uo + D], 2 * D), "item_mlp": (dx0[:, io:io + D], 2 * D),
-                "user_mf": (self.g_user_mf[:B], D), "item_mf": (self.g_item_mf[:B], D)}
+                "user_mf": (self.g_user[:B, D:], 2 * D), "item_mf": (self.g_item[:B, D:], 2 * D)}
 
     def _embed_backward_apply(self, users, items, B):
-        """B1 row gradients of the 4 tables, S1 dedup index, O1 Adam on the tables."""
-        cfg, t = self.cfg, self.tables
+        """B1 row gradients of the 4 tables, S1 dedup index, O1 Adam on the (fused) tables."""
+        cfg, t, D = self.cfg, self.tables, self.cfg.dim
         ops.neumf_embed_backward(t["user_mf"], t["item_mf"], users, items, cfg.item_first, None, self.ddot[:B],
-                                 self.g_user_mf[:B], self.g_item_mf[:B])
+                                 self.g_user[:B, D:], self.g_item[:B, D:])
         self.user_index.build(users, self.num_user_rows)
         self.item_index.build(items, self.num_item_rows)
-        self._adam_tables(self.row_grad_views(B))
+        rg = self.row_grad_views(B)
+        self._adam_tables({"user": (rg["user_mlp"][0], 2 * D, rg["user_mf"][0], 2 * D),
+                           "item": (rg["item_mlp"][0], 2 * D, rg["item_mf"][0], 2 * D)})
 
     def _adam_tables(self, rg):
-        """rg: name -> (row_grads, row stride) aligned with the positions the indexes were built on."""
-        cfg = self.cfg
+        """rg: stream -> (mlp-half grads, stride, mf-half grads, stride), aligned with the positions the
+        indexes were built on.  One launch per fused table (+ the dense sweep in Keras mode)."""
+        cfg, D = self.cfg, self.cfg.dim
         a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
         hp = dict(beta1=cfg.beta1, beta2=cfg.beta2, eps=cfg.adam_eps)
         dense = cfg.optimizer == "adam_dense"
-        for name in TABLES:
-            idx = self.user_index if name.startswith("user") else self.item_index
-            mark = (self.user_mark if name.startswith("user") else self.item_mark) if dense else None
-            g, ldg = rg[name]
-            ops.adam_rows_sorted(self.tables[name], self.tab_m[name], self.tab_v[name], idx, g, ldg, a, mark=mark, **hp)
+        for stream in ("user", "item"):
+            idx = self.user_index if stream == "user" else self.item_index
+            mark = (self.user_mark if stream == "user" else self.item_mark) if dense else None
+            g0, ld0, g1, ld1 = rg[stream]
+            ops.adam_rows_sorted(self.fused[stream], self.fused_m[stream], self.fused_v[stream], idx, g0, ld0, a, mark=mark,
+                                 row_grads_hi=g1, ldg_hi=ld1, split=D if g1 is not None else 0, **hp)
             if dense:
-                ops.adam_dense_sweep(self.tables[name], self.tab_m[name], self.tab_v[name], a, mark=mark, **hp)
+                ops.adam_dense_sweep(self.fused[stream], self.fused_m[stream], self.fused_v[stream], a, mark=mark, **hp)
 
     # ------------------------------------------------------------------ inference
+    def _infer(self, users, items, labels, n):
+        PH = self.PH
+        self._set_batch(users, items, labels, n, False, 0, n)
+        if self.sharded:
+            self._embed_forward(users, items, n)
+            self._run(PH["FWD1"] | PH["FWD2"] | PH["FWD3"])
+        else:
+            self._run(PH["FWD1"] | PH["FWD2"] | PH["FWD3"] | PH["EMBED"])
+
     def predict(self, users, items, out=None):
         """sigmoid output of the graph in inference mode (moving BN stats, no dropout)."""
         B = users.shape[0]
         if out is None:
             out = torch.empty(B, dtype=torch.float32, device=self.device)
-        cfg, th = self.cfg, self.theta
         for s in range(0, B, self.max_batch):
             e = min(B, s + self.max_batch)
-            n = e - s
-            self._forward(users[s:e], items[s:e], n, False, 0, n)
-            ops.neumf_head(self.a3[:n], self.dot[:n], None, th.view("W4"), th.view("b4"), cfg.mf_first, cfg.loss, 1.0,
-                           prob=out[s:e])
+            self._infer(users[s:e], items[s:e], None, e - s)
+            out[s:e].copy_(self.prob[:e - s])
         return out
 
     def evaluate_batch(self, users, items, labels):
         """inference-mode forward + loss/metric sums accumulated into self.msums (no grads)."""
-        cfg, th = self.cfg, self.theta
-        B = users.shape[0]
-        self._forward(users, items, B, False, 0, B)
-        ops.neumf_head(self.a3[:B], self.dot[:B], labels, th.view("W4"), th.view("b4"), cfg.mf_first, cfg.loss, 1.0 / B,
-                       logit=self.logit[:B], prob=self.prob[:B], sums=self.msums)
+        self._infer(users, items, labels, users.shape[0])
 
     def pop_metrics(self, n_samples: int) -> dict:
         """Host sync: mean loss / mse / mae / binary_accuracy since the last call (RModel.py:20)."""
@@ -328,8 +369,8 @@ class NeuMFEngine:
     # ------------------------------------------------------------------ state
     def state_dict(self) -> dict:
         sd = {"t": self.t, "theta": self.theta.buf, "adam_m": self.adam_m.buf, "adam_v": self.adam_v.buf}
-        for k in TABLES:
-            sd[k], sd[k + ".m"], sd[k + ".v"] = self.tables[k], self.tab_m[k], self.tab_v[k]
+        for k in ("user", "item"):
+            sd["table." + k], sd["table." + k + ".m"], sd["table." + k + ".v"] = self.fused[k], self.fused_m[k], self.fused_v[k]
         sd.update(self.moving)
         return sd
 
@@ -337,8 +378,8 @@ class NeuMFEngine:
         self.t = int(sd["t"])
         for k, dst in (("theta", self.theta.buf), ("adam_m", self.adam_m.buf), ("adam_v", self.adam_v.buf)):
             dst.copy_(sd[k])
-        for k in TABLES:
-            self.tables[k].copy_(sd[k]); self.tab_m[k].copy_(sd[k + ".m"]); self.tab_v[k].copy_(sd[k + ".v"])
+        for k in ("user", "item"):
+            self.fused[k].copy_(sd["table." + k]); self.fused_m[k].copy_(sd["table." + k + ".m"]); self.fused_v[k].copy_(sd["table." + k + ".v"])
         for k in self.moving:
             self.moving[k].copy_(sd[k])
 

@@ -97,28 +97,35 @@ def row_dot_backward(a, b, dout, da=None, db=None):
 
 
 def neumf_embed_forward(user_mlp, item_mlp, user_mf, item_mf, users, items, item_first, x0, dot, err_flag=None):
+    """Tables may be separate (row stride = dim) or column views of fused [rows][mlp|mf] allocations."""
     u, ut = _ids(users, "users"); i, it = _ids(items, "items")
     id_type = _same_id_type(ut, it)
     dim = user_mlp.shape[1]
     batch = x0.shape[0]
-    check(_lib.load().brNeumfEmbedForward(_f32(user_mlp, "user_mlp").data_ptr(), _f32(item_mlp, "item_mlp").data_ptr(),
-                                          _f32(user_mf, "user_mf").data_ptr(), _f32(item_mf, "item_mf").data_ptr(),
-                                          user_mlp.shape[0], item_mlp.shape[0], _p(u), _p(i), id_type, dim, batch,
-                                          int(item_first), _f32(x0, "x0").data_ptr(), _f32(dot, "dot").data_ptr(),
-                                          _p(err_flag), _stream()), "brNeumfEmbedForward")
+    if user_mlp.stride(0) != user_mf.stride(0) or item_mlp.stride(0) != item_mf.stride(0):
+        raise ValueError("mlp/mf tables of one stream must share a row stride")
+    check(_lib.load().brNeumfEmbedForward(user_mlp.data_ptr(), item_mlp.data_ptr(), user_mf.data_ptr(), item_mf.data_ptr(),
+                                          user_mlp.stride(0), item_mlp.stride(0), user_mlp.shape[0], item_mlp.shape[0],
+                                          _p(u), _p(i), id_type, dim, batch, int(item_first), _f32(x0, "x0").data_ptr(),
+                                          _f32(dot, "dot").data_ptr(), _p(err_flag), _stream()), "brNeumfEmbedForward")
 
 
 def neumf_embed_backward(user_mf, item_mf, users, items, item_first, dx0, ddot, g_user_mf, g_item_mf,
                          g_user_mlp=None, g_item_mlp=None):
+    """g_* may be (B, dim) buffers or column views of fused (B, 2*dim) buffers (shared row stride)."""
     u, ut = _ids(users, "users"); i, it = _ids(items, "items")
     id_type = _same_id_type(ut, it)
     dim = user_mf.shape[1]
     batch = ddot.shape[0]
-    check(_lib.load().brNeumfEmbedBackward(_f32(user_mf, "user_mf").data_ptr(), _f32(item_mf, "item_mf").data_ptr(),
+    ldg = g_user_mf.stride(0)
+    for t in (g_item_mf, g_user_mlp, g_item_mlp):
+        if t is not None and t.stride(0) != ldg:
+            raise ValueError("row-gradient outputs must share a row stride")
+    check(_lib.load().brNeumfEmbedBackward(user_mf.data_ptr(), item_mf.data_ptr(), user_mf.stride(0), item_mf.stride(0),
                                            user_mf.shape[0], item_mf.shape[0], _p(u), _p(i), id_type, dim, batch,
                                            int(item_first), _p(dx0), _f32(ddot, "ddot").data_ptr(), _p(g_user_mlp),
-                                           _p(g_item_mlp), _f32(g_user_mf, "g_user_mf").data_ptr(),
-                                           _f32(g_item_mf, "g_item_mf").data_ptr(), _stream()), "brNeumfEmbedBackward")
+                                           _p(g_item_mlp), g_user_mf.data_ptr(), g_item_mf.data_ptr(), ldg, _stream()),
+          "brNeumfEmbedBackward")
 
 
 # ------------------------------------------------------------------------------ L3 BPR
@@ -179,11 +186,13 @@ def scatter_add_rows(g_table, ids, rows, err_flag=None):
 
 
 # ------------------------------------------------------------------------------ O1 / O2
-def adam_rows_sorted(table, m, v, index: RowIndex, row_grads, ldg, alpha_t, beta1=0.9, beta2=0.999, eps=1e-7, mark=None):
+def adam_rows_sorted(table, m, v, index: RowIndex, row_grads, ldg, alpha_t, beta1=0.9, beta2=0.999, eps=1e-7, mark=None,
+                     row_grads_hi=None, ldg_hi=0, split=0):
     check(_lib.load().brAdamRowsSorted(_f32(table, "table").data_ptr(), _f32(m, "m").data_ptr(), _f32(v, "v").data_ptr(),
                                        table.shape[0], table.shape[1], index.sorted_ids.data_ptr(), index.id_type,
-                                       index.sorted_pos.data_ptr(), index.n, row_grads.data_ptr(), int(ldg), float(alpha_t),
-                                       float(beta1), float(beta2), float(eps), _p(mark), _stream()), "brAdamRowsSorted")
+                                       index.sorted_pos.data_ptr(), index.n, row_grads.data_ptr(), int(ldg), _p(row_grads_hi),
+                                       int(ldg_hi), int(split), float(alpha_t), float(beta1), float(beta2), float(eps),
+                                       _p(mark), _stream()), "brAdamRowsSorted")
 
 
 def adam_dense_sweep(table, m, v, alpha_t, beta1=0.9, beta2=0.999, eps=1e-7, mark=None):

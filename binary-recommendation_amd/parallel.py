@@ -144,6 +144,8 @@ def make_sharded_engine(base_cls):
     from .neumf import TABLES
 
     class ShardedNeuMFEngine(base_cls):
+        sharded = True
+
         def __init__(self, cfg, num_user_rows, num_item_rows, device, max_batch, ctx: DistCtx, **kw):
             self.ctx = ctx
             self.full_tables = kw.pop("full_tables", None)   # tests: {name: full (rows, D) tensor} to slice
@@ -155,11 +157,14 @@ def make_sharded_engine(base_cls):
             return max(1, shard_rows(total, self.ctx.rank, self.ctx.world))
 
         def _init_tables(self, g, init_seed):
-            if self.full_tables is not None:
-                for name in TABLES:
-                    self.tables[name] = self.full_tables[name][self.ctx.rank::self.ctx.world].contiguous().to(self.device)
-                    if self.tables[name].shape[0] == 0:
-                        self.tables[name] = torch.zeros(1, self.cfg.dim, device=self.device)
+            if self.full_tables is not None:     # tests: slice the rows this rank owns out of global tables
+                D = self.cfg.dim
+                self.fused = {}
+                for stream in ("user", "item"):
+                    full = torch.cat([self.full_tables[stream + "_mlp"], self.full_tables[stream + "_mf"]], dim=1)
+                    t = full[self.ctx.rank::self.ctx.world].contiguous().to(self.device)
+                    self.fused[stream] = t if t.shape[0] else torch.zeros(1, 2 * D, device=self.device)
+                self._make_views()
                 return
             super()._init_tables(g, init_seed + 104729 * self.ctx.rank)
 
@@ -176,41 +181,39 @@ def make_sharded_engine(base_cls):
                 self._idx_cap = int(n * 1.25) + 64
                 self.user_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
                 self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
+                if hasattr(self, "step_struct"):
+                    self._bind_indexes(self.step_struct)
 
         def _embed_forward(self, users, items, B):
-            D, t = self.cfg.dim, self.tables
+            D = self.cfg.dim
             xu, xi = self.xu.plan(users), self.xi.plan(items)
-            xu.exchange_counts(xi)
-            ru, ri = xu.send_ids(), xi.send_ids()
-            # owner-side G1: gather the requested rows of both tables of each stream in one launch
-            gu = ops.gather_rows([t["user_mlp"], t["user_mf"]], [ru, ru], err_flag=self.err) if ru.numel() else \
-                [torch.empty(0, D, device=self.device)] * 2
-            gi = ops.gather_rows([t["item_mlp"], t["item_mf"]], [ri, ri], err_flag=self.err) if ri.numel() else \
-                [torch.empty(0, D, device=self.device)] * 2
-            self.r_user_mlp, self.r_user_mf = xu.return_rows(gu[0]), xu.return_rows(gu[1])
-            self.r_item_mlp, self.r_item_mf = xi.return_rows(gi[0]), xi.return_rows(gi[1])
+            xu.exchange_counts(xi)                     # the step's one host sync (variable split sizes)
+            ru, ri = xu.send_ids(), xi.send_ids()      # all-to-all #1
+            empty = torch.empty(0, 2 * D, device=self.device)
+            # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64)
+            gu = ops.gather_rows([self.fused["user"]], [ru], err_flag=self.err)[0] if ru.numel() else empty
+            gi = ops.gather_rows([self.fused["item"]], [ri], err_flag=self.err)[0] if ri.numel() else empty
+            self.r_user, self.r_item = xu.return_rows(gu), xi.return_rows(gi)      # all-to-all #2
             self.pos_u = xu.inv.to(self.id_dtype)
             self.pos_i = xi.inv.to(self.id_dtype)
             # requester-side: same fused embed kernel, "tables" = received rows, ids = bucket slots
-            ops.neumf_embed_forward(self.r_user_mlp, self.r_item_mlp, self.r_user_mf, self.r_item_mf, self.pos_u,
+            ops.neumf_embed_forward(self.r_user[:, :D], self.r_item[:, :D], self.r_user[:, D:], self.r_item[:, D:], self.pos_u,
                                     self.pos_i, self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
 
         def _embed_backward_apply(self, users, items, B):
             cfg, D = self.cfg, self.cfg.dim
-            f = lambda: torch.empty(B, D, dtype=torch.float32, device=self.device)
-            g_umlp, g_imlp = f(), f()
-            ops.neumf_embed_backward(self.r_user_mf, self.r_item_mf, self.pos_u, self.pos_i, cfg.item_first, self.dx0[:B],
-                                     self.ddot[:B], self.g_user_mf[:B], self.g_item_mf[:B], g_umlp, g_imlp)
+            gu, gi = self.g_user[:B], self.g_item[:B]
+            # fused per-pair row gradients [mlp | mf] (the MLP halves are copied out of dx0 here)
+            ops.neumf_embed_backward(self.r_user[:, D:], self.r_item[:, D:], self.pos_u, self.pos_i, cfg.item_first,
+                                     self.dx0[:B], self.ddot[:B], gu[:, D:], gi[:, D:], gu[:, :D], gi[:, :D])
             xu, xi = self.xu, self.xi
-            ou, oi = xu.order.to(self.id_dtype), xi.order.to(self.id_dtype)
-            # batch order -> bucket order (one fused gather per stream), then all-to-all #3
-            bu = ops.gather_rows([g_umlp, self.g_user_mf[:B]], [ou, ou])
-            bi = ops.gather_rows([g_imlp, self.g_item_mf[:B]], [oi, oi])
-            rg = {"user_mlp": (xu.send_row_grads(bu[0]), D), "user_mf": (xu.send_row_grads(bu[1]), D),
-                  "item_mlp": (xi.send_row_grads(bi[0]), D), "item_mf": (xi.send_row_grads(bi[1]), D)}
+            # batch order -> bucket order, then all-to-all #3 to the owners
+            bu = ops.gather_rows([gu], [xu.order.to(self.id_dtype)])[0]
+            bi = ops.gather_rows([gi], [xi.order.to(self.id_dtype)])[0]
+            ou, oi = xu.send_row_grads(bu), xi.send_row_grads(bi)
             self._grow_index(max(xu.n_recv, xi.n_recv))
             self.user_index.build(xu.recv_local, self.local_rows("user_mf"))
             self.item_index.build(xi.recv_local, self.local_rows("item_mf"))
-            self._adam_tables(rg)
+            self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
 
     return ShardedNeuMFEngine

@@ -60,20 +60,25 @@ int brRowDotBackward(const float* a, const float* b, const float* dout, float* d
 
 /* ---- G1+M1+T1 fused for NeuMF: 4 lookups, GMF dot, MLP concat ------------------------------
  * NFC_plain.py:115-126,137,148 (item_first=1) / NeuMFModel.py:58-66,79 (item_first=0).
- * x0[b] = concat(first_mlp[b], second_mlp[b]) (B x 2*dim), dot[b] = user_mf[u]·item_mf[i]. */
+ * x0[b] = concat(first_mlp[b], second_mlp[b]) (B x 2*dim), dot[b] = user_mf[u]·item_mf[i].
+ * ld_user / ld_item = row strides (floats) of the user / item tables: `dim` for four separate
+ * tables, 2*dim when a stream's MLP and MF tables are stored interleaved as one [rows][mlp|mf]
+ * allocation (then user_mf = user_mlp + dim): one 512-B row instead of two 256-B rows per id. */
 int brNeumfEmbedForward(const float* user_mlp, const float* item_mlp, const float* user_mf,
-                        const float* item_mf, int64_t user_rows, int64_t item_rows,
-                        const void* users, const void* items, int id_type, int dim, int64_t batch,
-                        int item_first, float* x0, float* dot, int* err_flag, brStream stream);
+                        const float* item_mf, int64_t ld_user, int64_t ld_item, int64_t user_rows,
+                        int64_t item_rows, const void* users, const void* items, int id_type,
+                        int dim, int64_t batch, int item_first, float* x0, float* dot,
+                        int* err_flag, brStream stream);
 /* B1 for the same block: per-pair row gradients (IndexedSlices values, [TF-sem]).
- * dx0: (B x 2*dim) gradient w.r.t. the (pre-dropout) concat; ddot: (B).
+ * dx0: (B x 2*dim) gradient w.r.t. the concat; ddot: (B).
  * g_user_mf[b] = ddot[b]*item_mf[i_b], g_item_mf[b] = ddot[b]*user_mf[u_b];
- * g_*_mlp = the two halves of dx0 in concat order.  Outputs are (B x dim) each. */
-int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t user_rows,
-                         int64_t item_rows, const void* users, const void* items, int id_type,
-                         int dim, int64_t batch, int item_first, const float* dx0,
-                         const float* ddot, float* g_user_mlp, float* g_item_mlp,
-                         float* g_user_mf, float* g_item_mf, brStream stream);
+ * g_*_mlp (optional, both or neither) = the two halves of dx0 in concat order.
+ * All outputs have row stride ldg (dim, or 2*dim for fused [mlp|mf] gradient buffers). */
+int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t ld_user,
+                         int64_t ld_item, int64_t user_rows, int64_t item_rows, const void* users,
+                         const void* items, int id_type, int dim, int64_t batch, int item_first,
+                         const float* dx0, const float* ddot, float* g_user_mlp, float* g_item_mlp,
+                         float* g_user_mf, float* g_item_mf, int64_t ldg, brStream stream);
 
 /* ---- L3: BPR triplet step — BPRModel.py:49-74,124-144; bpr.py:141-157 -----------------------
  * x = u·p - u·n ; l = 1 - sigmoid(x) ; loss = mean(l).  One fused launch: 3 gathers, 2 dots,
@@ -111,13 +116,17 @@ int brScatterAddRows(float* g_table, int64_t table_rows, const void* ids, int id
  * two halves of a (B x 2*dim) dx0 buffer serve as the MLP tables' row gradients in place).
  * m = b1*m+(1-b1)*g ; v = b2*v+(1-b2)*g^2 ; theta -= alpha_t*m/(sqrt(v)+eps)   (eps outside).
  * brAdamRowsSorted: touched rows only; g = ordered segment sum (dedup BEFORE the square).
+ *   row_grads_hi non-NULL: columns [split, dim) of a row's gradient come from row_grads_hi
+ *   (stride ldg_hi), columns [0, split) from row_grads: a fused [mlp|mf] table takes its MLP half
+ *   straight from the (B x 2*dim) input gradient and its MF half from the embed backward.
  *   mark (uint8[table_rows]) non-NULL: set mark[row]=1 for touched rows (for the sweep).
  * brAdamDenseSweep: every row NOT marked gets the g=0 update (m,v decay + theta step): with
  *   brAdamRowsSorted before it this is exactly Keras' non-lazy sparse Adam; it clears marks. */
 int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int dim,
                      const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
-                     const float* row_grads, int64_t ldg, double alpha_t, double beta1,
-                     double beta2, double eps, uint8_t* mark, brStream stream);
+                     const float* row_grads, int64_t ldg, const float* row_grads_hi,
+                     int64_t ldg_hi, int split, double alpha_t, double beta1, double beta2,
+                     double eps, uint8_t* mark, brStream stream);
 int brAdamDenseSweep(float* table, float* m, float* v, int64_t table_rows, int dim,
                      double alpha_t, double beta1, double beta2, double eps, uint8_t* mark,
                      brStream stream);
@@ -218,6 +227,69 @@ int brInBatchSoftmaxGrad(const float* Q, const float* C, const void* q_pos_ids,
  * (strict '>' in __topk, topKmetrics.py:59,68).  out_scores/out_index: (U x k). */
 int brTopKRows(const float* scores, int64_t n_users, int64_t n_items, int k, float* out_scores,
                int32_t* out_index, brStream stream);
+
+/* ---- fused step driver: the whole NeuMF training / inference step from ONE host call ----------
+ * trainers/NFC_plain.py:165 `model.fit` step, src/models/RModel.py:130.  Pure launch sequencing
+ * over the entry points above (no new arithmetic): removes ~35 Python->C transitions per step so
+ * the host stays ahead of the GPU.  The caller fills the struct once, then per step updates
+ * users/items/labels/batch/step/alpha_t.  `phases` selects segments so a data-parallel host can
+ * interleave its collectives (BatchNorm sums, dense-gradient all-reduce, row exchange):
+ *   FWD1 zero scratch, [EMBED] embed forward, dense L1 (+ BN1 sums)
+ *   FWD2 BN1 finalize, dense L2 (+ BN2 sums)
+ *   FWD3 BN2 finalize, dense L3, head (+ loss/metric sums, head grads), backward L3 (+ BN2-bwd sums)
+ *   BWD2 backward L2 (+ BN1-bwd sums)        BWD1 backward L1
+ *   BNG  gamma/beta grads from the BN-backward sums
+ *   OPT_TABLES [EMBED] embed backward, dedup index, Adam rows (+ dense sweep)   OPT_DENSE Adam on theta
+ * EMBED: include the table-side embed forward/backward (single GPU); cleared by the row-sharded
+ * host, which runs its own exchange and calls brNeumfEmbedForward/Backward on the received rows.
+ * Dense parameter layout (theta/grad/adam_m/adam_v, floats):
+ *   [W1 2*dim x n1 | b1 n1 | g1 n1 | be1 n1 | W2 n1 x n2 | b2 n2 | g2 n2 | be2 n2 | W3 n2 x n3 | b3 n3 | W4 n3+1 | b4 1] */
+enum {
+  BR_PH_FWD1 = 1, BR_PH_FWD2 = 2, BR_PH_FWD3 = 4, BR_PH_BWD2 = 8, BR_PH_BWD1 = 16, BR_PH_BNG = 32,
+  BR_PH_OPT_TABLES = 64, BR_PH_OPT_DENSE = 128, BR_PH_EMBED = 256,
+  BR_PH_ALL = 511
+};
+typedef struct brNeumfStep {
+  int64_t batch, batch_total, row0, user_rows, item_rows;
+  int32_t dim, n1, n2, n3, act, loss, item_first, mf_first, id_type, adam_dense, training, step;
+  float dropout, bn_eps, bn_momentum, pad0;
+  uint64_t seed;
+  double alpha_t, beta1, beta2, adam_eps;
+  const void* users;
+  const void* items;
+  const float* labels;                     /* may be NULL in inference */
+  float* user_tab; float* user_m; float* user_v;   /* fused [rows][mlp|mf] (row = 2*dim floats) */
+  float* item_tab; float* item_m; float* item_v;
+  uint8_t* user_mark; uint8_t* item_mark;          /* [rows], adam_dense only */
+  float* theta; float* grad; float* adam_m; float* adam_v;
+  float* moving;                           /* [mm1 n1 | mv1 n1 | mm2 n2 | mv2 n2] */
+  float* x0; float* dot; float* a1; float* a2; float* a3; float* logit; float* prob;
+  float* da3; float* ddot; float* gh2; float* gh1; float* dx0; float* g_user; float* g_item;
+  float* bn;                               /* [scale1|shift1|mean1|rstd1] n1 each, then the same for layer 2 */
+  double* dstat;                           /* [stats1 2n1 | stats2 2n2 | bsum1 2n1 | bsum2 2n2], zeroed in FWD1 */
+  double* msums;                           /* [loss, sum sq err, sum abs err, #correct] accumulated */
+  float* slabs; float* hslabs;
+  int* err_flag;
+  void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;
+  void* i_sorted_ids; int32_t* i_sorted_pos; void* i_ws; int64_t i_ws_bytes;
+} brNeumfStep;
+int64_t brNeumfStepSizeof(void);
+int brNeumfStepRun(const brNeumfStep* s, uint32_t phases, brStream stream);
+
+/* Optional launch probe for measurement (bench.py roofline leg): HIP events on the launch stream
+ * around every inner launch of brNeumfStepRun, tagged BR_TAG_*.  brProbeEnable(capacity) creates
+ * the events (capacity 0 disables and frees them); after synchronising the stream the host reads
+ * record i with brProbeRead (elapsed ms of that launch).  Process-global, not thread-safe. */
+enum {
+  BR_TAG_EMBED_FWD = 1, BR_TAG_FWD_L1 = 2, BR_TAG_FWD_L2 = 3, BR_TAG_FWD_L3 = 4, BR_TAG_HEAD = 5,
+  BR_TAG_BWD_L3 = 6, BR_TAG_BWD_L2 = 7, BR_TAG_BWD_L1 = 8, BR_TAG_EMBED_BWD = 9,
+  BR_TAG_INDEX_USER = 10, BR_TAG_INDEX_ITEM = 11, BR_TAG_ADAM_ROWS_USER = 12, BR_TAG_SWEEP_USER = 13,
+  BR_TAG_ADAM_ROWS_ITEM = 14, BR_TAG_SWEEP_ITEM = 15, BR_TAG_ADAM_FLAT = 16, BR_TAG_REDUCE = 17,
+  BR_TAG_SMALL = 18
+};
+int brProbeEnable(int capacity);
+int brProbeCount(void);
+int brProbeRead(int i, int* tag, float* ms);
 
 #ifdef __cplusplus
 }

@@ -33,9 +33,11 @@ import numpy as np
 # Philox4x32-10 counter RNG: the dropout-mask definition shared (bit-exactly)
 # with csrc/philox.h.  Keras' own dropout stream (NFC_plain.py:138,141,144;
 # NeuMFModel.py:67,71,75) is a stateful TF generator that cannot be reproduced,
-# so the build defines its own: element (row r, col c) of dropout site `site`
-# at optimizer step `step` is KEPT iff
-#     philox(key=(seed_lo, seed_hi), ctr=(r, c>>2, site, step))[c & 3] >= floor(p * 2^32)
+# so the build defines its own: one Philox call yields 4 x u32 = 8 x u16 draws
+# for the 8 columns 8q..8q+7 of a row.  Element (row r, col c) of dropout site
+# `site` at optimizer step `step` is KEPT iff
+#   u16 = (philox(key=(seed_lo, seed_hi), ctr=(r, c>>3, site, step))[(c>>1)&3] >> (16*(c&1))) & 0xFFFF
+#   u16 >= floor(p * 65536)
 # ----------------------------------------------------------------------------
 PHILOX_M0 = np.uint64(0xD2511F53)
 PHILOX_M1 = np.uint64(0xCD9E8D57)
@@ -69,8 +71,8 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def dropout_threshold(p: float) -> int:
-    """u32 draw < threshold  => element dropped."""
-    return int(np.floor(float(p) * 4294967296.0))
+    """u16 draw < threshold  => element dropped."""
+    return min(int(np.floor(float(p) * 65536.0)), 0xFFFF)
 
 
 def dropout_mask(seed: int, step: int, site: int, nrows: int, ncols: int, p: float, row0: int = 0):
@@ -80,13 +82,15 @@ def dropout_mask(seed: int, step: int, site: int, nrows: int, ncols: int, p: flo
         return np.ones((nrows, ncols), dtype=bool)
     r = (np.arange(nrows, dtype=np.uint64) + np.uint64(row0))[:, None]
     c = np.arange(ncols, dtype=np.uint64)[None, :]
-    out = philox4x32_10(r, c >> np.uint64(2), np.uint64(site), np.uint64(step),
+    out = philox4x32_10(r, c >> np.uint64(3), np.uint64(site), np.uint64(step),
                         seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    lane = (c & np.uint64(3)).astype(np.int64)
-    lane = np.broadcast_to(lane, (nrows, ncols))
+    word = ((c >> np.uint64(1)) & np.uint64(3)).astype(np.int64)
+    word = np.broadcast_to(word, (nrows, ncols))
     stacked = np.stack(out, axis=-1)  # (nrows, ncols, 4)
-    draw = np.take_along_axis(stacked, lane[..., None], axis=-1)[..., 0]
-    return draw >= np.uint32(min(dropout_threshold(p), 0xFFFFFFFF))
+    w32 = np.take_along_axis(stacked, word[..., None], axis=-1)[..., 0].astype(np.uint32)
+    half = np.broadcast_to((c & np.uint64(1)).astype(np.uint32), (nrows, ncols))
+    draw = (w32 >> (np.uint32(16) * half)) & np.uint32(0xFFFF)
+    return draw >= np.uint32(dropout_threshold(p))
 
 
 # ----------------------------------------------------------------------------
@@ -346,13 +350,26 @@ def neumf_step_grads(spec, p, users, items, labels, masks=None, dt=np.float64):
     D = spec.dim
     rg = {spec.mlp_concat[0] + "_mlp": dx0[:, :D], spec.mlp_concat[1] + "_mlp": dx0[:, D:],
           "user_mf": ddot[:, None] * c["e"]["item_mf"], "item_mf": ddot[:, None] * c["e"]["user_mf"]}
-    # |summand| totals of every dense gradient: the scale fp32 rounding is relative to (several of
-    # these sums cancel almost completely, e.g. the pre-BN biases), used as test tolerances only.
+    # Magnitude propagation ("what fp32 rounding is relative to"): the same backward with every
+    # subtraction replaced by a sum of absolute values.  Several true gradients cancel almost
+    # completely (BN-backward removes mean and slope; pre-BN biases), so tests bound the error by
+    # 1e-5 x these magnitudes instead of by the cancelled result.  Test tolerances only.
     A = np.abs
+
+    def bn_abs(dh_abs, gamma, bn):
+        _mu, _var, rstd, xhat = bn
+        return A(gamma * rstd) * (dh_abs + dh_abs.mean(0) + A(xhat) * (dh_abs * A(xhat)).mean(0))
+
+    dz3_abs = A(dz3)
+    dh2_abs = undrop(dz3_abs @ A(f(p["W3"])).T, 2)
+    dz2_abs = bn_abs(dh2_abs, f(p["g2"]), c["bn2"]) * act_bwd_from_out(c["a2"], spec.act)
+    dh1_abs = undrop(dz2_abs @ A(f(p["W2"])).T, 1)
+    dz1_abs = bn_abs(dh1_abs, f(p["g1"]), c["bn1"]) * act_bwd_from_out(c["a1"], spec.act)
     c["gabs"] = {"W4": A(c["comb"]).T @ A(dz), "b4": np.array([A(dz).sum()]),
-                 "W3": A(c["x2d"]).T @ A(dz3), "b3": A(dz3).sum(0), "g2": A(dh2 * c["bn2"][3]).sum(0), "be2": A(dh2).sum(0),
-                 "W2": A(c["x1d"]).T @ A(dz2), "b2": A(dz2).sum(0), "g1": A(dh1 * c["bn1"][3]).sum(0), "be1": A(dh1).sum(0),
-                 "W1": A(c["x0d"]).T @ A(dz1), "b1": A(dz1).sum(0)}
+                 "W3": A(c["x2d"]).T @ dz3_abs, "b3": dz3_abs.sum(0), "g2": (dh2_abs * A(c["bn2"][3])).sum(0), "be2": dh2_abs.sum(0),
+                 "W2": A(c["x1d"]).T @ dz2_abs, "b2": dz2_abs.sum(0), "g1": (dh1_abs * A(c["bn1"][3])).sum(0), "be1": dh1_abs.sum(0),
+                 "W1": A(c["x0d"]).T @ dz1_abs, "b1": dz1_abs.sum(0)}
+    c["rg_abs"] = undrop(dz1_abs @ A(f(p["W1"])).T, 0)
     mom = dt(spec.bn_momentum)
     new_stats = {"mm1": f(p["mm1"]) * mom + c["bn1"][0] * (1 - mom), "mv1": f(p["mv1"]) * mom + c["bn1"][1] * (1 - mom),
                  "mm2": f(p["mm2"]) * mom + c["bn2"][0] * (1 - mom), "mv2": f(p["mv2"]) * mom + c["bn2"][1] * (1 - mom)}

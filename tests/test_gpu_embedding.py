@@ -92,6 +92,16 @@ def test_neumf_embed_block(dev, dim, item_first):
     g = [torch.empty(B, dim, device=dev) for _ in range(4)]
     ops.neumf_embed_backward(ufd, vfd, ud, idd, item_first, torch.from_numpy(dx0).to(dev), torch.from_numpy(dd).to(dev),
                              g[2], g[3], g[0], g[1])
+    # fused layout: tables [rows][mlp|mf], gradients [B][mlp|mf] (row stride 2*dim everywhere)
+    fu = torch.cat([umd, ufd], dim=1).contiguous(); fi = torch.cat([imd, vfd], dim=1).contiguous()
+    x0f = torch.empty(B, 2 * dim, device=dev); dotf = torch.empty(B, device=dev)
+    ops.neumf_embed_forward(fu[:, :dim], fi[:, :dim], fu[:, dim:], fi[:, dim:], ud, idd, item_first, x0f, dotf)
+    assert torch.equal(x0f, x0) and torch.equal(dotf, dot)
+    gu, gi = torch.zeros(B, 2 * dim, device=dev), torch.zeros(B, 2 * dim, device=dev)
+    ops.neumf_embed_backward(fu[:, dim:], fi[:, dim:], ud, idd, item_first, torch.from_numpy(dx0).to(dev), torch.from_numpy(dd).to(dev),
+                             gu[:, dim:], gi[:, dim:], gu[:, :dim], gi[:, :dim])
+    assert torch.equal(gu[:, :dim], g[0]) and torch.equal(gi[:, :dim], g[1])
+    assert torch.equal(gu[:, dim:], g[2]) and torch.equal(gi[:, dim:], g[3])
     uo, io = (dim, 0) if item_first else (0, dim)
     assert np.array_equal(g[0].cpu().numpy(), dx0[:, uo:uo + dim])
     assert np.array_equal(g[1].cpu().numpy(), dx0[:, io:io + dim])

@@ -83,6 +83,27 @@ def test_adam_sparse_tf_form(dev, dim, lazy):
     np.testing.assert_allclose(vd.cpu().numpy(), v64, rtol=1e-5, atol=2e-6 * np.abs(v64).max())
 
 
+def test_adam_rows_split_sources(dev):
+    """Fused [mlp|mf] table: columns [0,D) take gradients from one buffer, [D,2D) from another."""
+    ops = _ops()
+    rng = np.random.default_rng(17)
+    rows, n, D = 300, 700, 32
+    th = rng.uniform(-0.05, 0.05, size=(rows, 2 * D)).astype(np.float32)
+    td = lambda a: torch.from_numpy(a.copy()).to(dev)
+    ids = _dup_ids(rng, n, rows)
+    big = rng.normal(scale=1e-2, size=(n, 2 * D + 6)).astype(np.float32)   # strided source for the low half
+    hi = rng.normal(scale=1e-2, size=(n, D)).astype(np.float32)
+    thd, md, vd = td(th), torch.zeros(rows, 2 * D, device=dev), torch.zeros(rows, 2 * D, device=dev)
+    idx = ops.RowIndex(n, torch.int32, dev).build(td(ids).int(), rows)
+    bigd = td(big)
+    a = ops.adam_alpha(0.005, 1)
+    ops.adam_rows_sorted(thd, md, vd, idx, bigd[:, 2:2 + D], bigd.stride(0), a, row_grads_hi=td(hi), ldg_hi=D, split=D)
+    g = np.concatenate([big[:, 2:2 + D], hi], axis=1)
+    ref, m64, v64 = O.adam_sparse_tf(th, np.zeros_like(th), np.zeros_like(th), ids, g, 0.005, 1, lazy=True, dt=np.float64)
+    np.testing.assert_allclose(thd.cpu().numpy(), ref, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), v64, rtol=1e-5, atol=2e-6 * np.abs(v64).max())
+
+
 def test_adam_flat_and_adagrad(dev):
     ops = _ops()
     rng = np.random.default_rng(8)
