@@ -1,12 +1,15 @@
 // T1-T4 + B1: the MLP tower on fp32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 fma chains, the
 // only MFMA form that meets the 1e-5 logit/loss tolerance; 157 TFLOP/s peak on MI355X).
 //
-// Structure (both kernels): one 512-thread workgroup (8 waves, 2 per SIMD) per CU walks batch tiles.
+// Structure (both kernels): 512-thread workgroups (8 waves), TWO resident per CU (4 waves per SIMD,
+// <= 128 VGPRs) so one workgroup's load / epilogue phases overlap the other's MFMA phase — a single
+// barrier-synchronised workgroup per CU left the matrix pipe idle 2/3 of the time (rocprofv3 PMC:
+// SQ_VALU_MFMA_BUSY_CYCLES = 32 % of the kernel, round-1 profile).
 //   * W never goes through LDS: every wave keeps the <= 32 fragment registers of the 16 weight
 //     columns (forward: n-tile, backward: k-tile) it owns for the whole launch.
-//   * The activation tiles are double-buffered in LDS; the raw global loads of tile t+1 are
-//     issued before the MFMA phase of tile t and land in registers (global -> reg -> LDS staging),
-//     BatchNorm-affine + Philox dropout are applied on the way in; one barrier per tile.
+//   * One LDS image of the current batch tile; the raw global loads of tile t+1 are issued before
+//     the MFMA phase of tile t and wait in registers (global -> reg -> LDS staging); BatchNorm-affine
+//     + Philox dropout are applied on the way in.
 //   * K is contracted in a lane-permuted order (lane group g = lane>>4 owns k = 16j+4g..+3) so one
 //     ds_read_b128 feeds four MFMA k-steps; A and B use the same permutation.
 //   forward : wave (n-tile nt, row group) : y[rows][16 cols] = act(T(x)·W + b) ; BN column sums.
@@ -14,6 +17,8 @@
 //             dx[rows][16 cols of kt] = dz·W^T  and  dW[16 rows of kt][N] += T(x)^T·dz from the
 //             same LDS tiles; dW/db live in registers across the workgroup's tiles and leave as
 //             one slab per (workgroup, row group) -> fixed-order reduce (reproducible, no atomics).
+// Column statistics (BatchNorm sums) leave as double atomics into BR_STAT_REPLICAS replicas
+// (replica = workgroup % 8) so no address takes more than grid/8 serialised adds.
 #include "common.h"
 #include "philox.h"
 
@@ -22,10 +27,13 @@ namespace br {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kThreads = 512;
-constexpr int kFwdTM = 128;      // rows per forward tile  (8 row tiles of 16)
-constexpr int kBwdTM = 64;       // rows per backward tile (4 row tiles of 16)
 constexpr int kMaxT = 8;         // max 16-wide tiles along K or N (=> K,N <= 128)
-constexpr int kMaxGrid = 256;    // one workgroup per CU
+constexpr int kMaxGrid = 512;    // two workgroups per CU
+constexpr int kRep = BR_STAT_REPLICAS;
+
+// rows per tile: every one of the 8 waves must own at least one 16-row tile
+__host__ __device__ constexpr int fwd_tm(int ntp) { return 16 * ((8 / ntp) > 4 ? (8 / ntp) : 4); }   // 64 (128 when N <= 16)
+__host__ __device__ constexpr int bwd_tm(int ktp) { return 16 * ((8 / ktp) > 2 ? (8 / ktp) : 2); }   // 32 (64 / 128 for K <= 32 / 16)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -80,24 +88,27 @@ __device__ __forceinline__ void store8_lds(float* dst, const float (&v)[8]) {
 
 // ------------------------------------------------------------------------------------ forward
 // NTP = n-tiles covered by the 8 waves (1,2,4,8): wave -> (n-tile = wave % NTP, row group = wave / NTP)
-template <int NTP>
-__global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
-                                                              const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
-                                                              int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
-                                                              double* __restrict__ stats) {
+// KJ  = K tiles of 16 (compile-time so the k-loop has no branches and LDS reads hoist freely)
+template <int NTP, int KJ>
+__global__ __launch_bounds__(kThreads, 4) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
+                                                                 int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
+                                                                 double* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int RGN = 8 / NTP;            // row groups; each wave owns NTP of the tile's 8 row tiles
-  const int Kp = (K + 15) & ~15, KJ = Kp >> 4;
-  const int ldx = Kp + 4;
-  float* Xb[2] = {smem, smem + kFwdTM * ldx};
-  float* ssb = smem + 2 * kFwdTM * ldx;          // [scale Kp | shift Kp]
+  constexpr int RGN = 8 / NTP;            // row groups
+  constexpr int TM = fwd_tm(NTP);         // rows per tile
+  constexpr int RT = TM / 16 / RGN;       // row tiles per wave (4, 2, 1, 1)
+  constexpr int Kp = KJ * 16, ldx = Kp + 4;
+  constexpr int CPR = Kp / 8;             // 8-float chunks per row
+  constexpr int MAXC = (TM * CPR + kThreads - 1) / kThreads;
+  float* Xs = smem;
+  float* ssb = smem + TM * ldx;           // [scale Kp | shift Kp]
   const float* ss = tin.scale ? ssb : nullptr;
   if (tin.scale)
     for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
       ssb[k] = k < K ? tin.scale[k] : 0.f;
       ssb[Kp + k] = k < K ? tin.shift[k] : 0.f;
     }
-  __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
@@ -106,9 +117,9 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const float* __rest
   const bool vec_ok = (ldx_g % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
   // this wave's W fragments: bw[4j+s] = W[16j+4g+s][ncol]
-  float bw[32];
+  float bw[4 * KJ];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < KJ; ++j)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k = 16 * j + 4 * g + s;
@@ -117,29 +128,27 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const float* __rest
   const float bcol = (bias && ncol < N) ? bias[ncol] : 0.f;
   float ssum = 0.f, ssq = 0.f;
 
-  const int chunks_per_row = Kp >> 3;
-  const int n_chunks = kFwdTM * chunks_per_row;     // <= 2048 => <= 4 per thread
-  float pre[4][8];
-  const int64_t n_tiles = (batch + kFwdTM - 1) / kFwdTM;
+  float pre[MAXC][8];
+  const int64_t n_tiles = (batch + TM - 1) / TM;
 
   auto load_tile = [&](int64_t tile) {
-    const int64_t row_base = tile * kFwdTM;
+    const int64_t row_base = tile * TM;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int idx = threadIdx.x + kThreads * i;
-      if (idx < n_chunks) {
-        const int r = idx / chunks_per_row, c = (idx - r * chunks_per_row) << 3;
+      if (idx < TM * CPR) {
+        const int r = idx / CPR, c = (idx - r * CPR) << 3;
         load8(pre[i], x, ldx_g, row_base + r, batch, c, K, vec_ok);
       }
     }
   };
-  auto write_tile = [&](int64_t tile, float* Xs) {
-    const int64_t row_base = tile * kFwdTM;
+  auto write_tile = [&](int64_t tile) {
+    const int64_t row_base = tile * TM;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int idx = threadIdx.x + kThreads * i;
-      if (idx < n_chunks) {
-        const int r = idx / chunks_per_row, c = (idx - r * chunks_per_row) << 3;
+      if (idx < TM * CPR) {
+        const int r = idx / CPR, c = (idx - r * CPR) << 3;
         xform8(pre[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
         store8_lds(Xs + r * ldx + c, pre[i]);
       }
@@ -147,61 +156,47 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const float* __rest
   };
 
   int64_t tile = blockIdx.x;
-  int cur = 0;
-  if (tile < n_tiles) {
-    load_tile(tile);
-    write_tile(tile, Xb[0]);
-  }
+  if (tile < n_tiles) load_tile(tile);
+  __syncthreads();                 // scale|shift staged
+  if (tile < n_tiles) write_tile(tile);
   __syncthreads();
   while (tile < n_tiles) {
     const int64_t next = tile + gridDim.x;
     if (next < n_tiles) load_tile(next);
-    // ---- MFMA: NTP row tiles of this wave's row group x its n-tile, two row tiles (two independent
-    //      accumulator chains) at a time; the row-tile loop stays rolled to bound live LDS reads ----
-    const float* Xs = Xb[cur];
-    const int64_t row_base = tile * kFwdTM;
-    constexpr int PAIR = NTP >= 2 ? 2 : 1;
-#pragma unroll 1
-    for (int i0 = 0; i0 < NTP; i0 += PAIR) {
-      f32x4 acc[PAIR];
-      const float* xr[PAIR];
+    // ---- MFMA: RT row tiles (independent accumulator chains) x this wave's n-tile ----
+    const int64_t row_base = tile * TM;
+    f32x4 acc[RT];
 #pragma unroll
-      for (int p = 0; p < PAIR; ++p) {
-        acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        xr[p] = Xs + ((rgp + RGN * (i0 + p)) * 16 + c16) * ldx + 4 * g;
+    for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const float4 a4 = *reinterpret_cast<const float4*>(Xs + ((rgp + RGN * i) * 16 + c16) * ldx + 16 * j + 4 * g);
+        acc[i] = mfma16(a4.x, bw[4 * j + 0], acc[i]);
+        acc[i] = mfma16(a4.y, bw[4 * j + 1], acc[i]);
+        acc[i] = mfma16(a4.z, bw[4 * j + 2], acc[i]);
+        acc[i] = mfma16(a4.w, bw[4 * j + 3], acc[i]);
       }
+    }
+    // ---- epilogue: lane holds rows 4g..4g+3 of each of its row tiles, column ncol ----
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < KJ) {
+    for (int i = 0; i < RT; ++i) {
+      const int rt = rgp + RGN * i;
 #pragma unroll
-          for (int p = 0; p < PAIR; ++p) {
-            const float4 a4 = *reinterpret_cast<const float4*>(xr[p] + 16 * j);
-            acc[p] = mfma16(a4.x, bw[4 * j + 0], acc[p]);
-            acc[p] = mfma16(a4.y, bw[4 * j + 1], acc[p]);
-            acc[p] = mfma16(a4.z, bw[4 * j + 2], acc[p]);
-            acc[p] = mfma16(a4.w, bw[4 * j + 3], acc[p]);
-          }
-        }
-      }
-      // epilogue: lane holds rows 4g..4g+3 of each row tile, column ncol
-#pragma unroll
-      for (int p = 0; p < PAIR; ++p) {
-        const int rt = rgp + RGN * (i0 + p);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gr = row_base + rt * 16 + 4 * g + r;
-          const float v = act_apply(acc[p][r] + bcol, act);
-          if (gr < batch && ncol < N) {
-            y[gr * ldy + ncol] = v;
-            ssum += v;
-            ssq += v * v;
-          }
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gr = row_base + rt * 16 + 4 * g + r;
+        const float v = act_apply(acc[i][r] + bcol, act);
+        if (gr < batch && ncol < N) {
+          y[gr * ldy + ncol] = v;
+          ssum += v;
+          ssq += v * v;
         }
       }
     }
-    if (next < n_tiles) write_tile(next, Xb[cur ^ 1]);
+    __syncthreads();               // everyone done reading the LDS image
+    if (next < n_tiles) write_tile(next);
     __syncthreads();
-    cur ^= 1;
     tile = next;
   }
   if (stats) {
@@ -209,8 +204,9 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const float* __rest
     s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
     q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
     if (g == 0 && ncol < N) {
-      atomicAdd(stats + ncol, s);
-      atomicAdd(stats + N + ncol, q);
+      double* rep = stats + (size_t)(blockIdx.x % kRep) * 2 * N;
+      atomicAdd(rep + ncol, s);
+      atomicAdd(rep + N + ncol, q);
     }
   }
 }
@@ -222,8 +218,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double batc
                                    float* __restrict__ mean, float* __restrict__ rstd, int N) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const double mu = stats[n] / batch_total;
-  double var = stats[N + n] / batch_total - mu * mu;  // biased batch variance [TF-sem]
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < kRep; ++r) { s1 += stats[(size_t)r * 2 * N + n]; s2 += stats[(size_t)r * 2 * N + N + n]; }
+  const double mu = s1 / batch_total;
+  double var = s2 / batch_total - mu * mu;  // biased batch variance [TF-sem]
   if (var < 0.0) var = 0.0;
   const float muf = (float)mu, varf = (float)var;
   const float rs = 1.0f / sqrtf(varf + eps);
@@ -250,8 +248,10 @@ __global__ void bn_inference_kernel(const float* __restrict__ gamma, const float
 __global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int N) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  dbeta[n] = (float)sums[n];
-  dgamma[n] = (float)sums[N + n];
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < kRep; ++r) { s1 += sums[(size_t)r * 2 * N + n]; s2 += sums[(size_t)r * 2 * N + N + n]; }
+  dbeta[n] = (float)s1;
+  dgamma[n] = (float)s2;
 }
 
 // ----------------------------------------------------------------------------------- backward
@@ -267,21 +267,24 @@ struct InBn {                // BN carried by the input (for the producer's back
   const float* rstd;
 };
 
-// NT = n-tiles (1..8).  ktp_log2: KTP = pow2 >= KT k-tiles; wave -> (k-tile = wave % KTP, row group = wave / KTP)
-template <int NT>
-__global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
-                                                              const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
-                                                              int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
-                                                              int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ slabs,
-                                                              double* __restrict__ in_sums, int ktp_log2) {
+// NT = n-tiles (1..8); KTP = pow2 >= number of k-tiles: wave -> (k-tile = wave % KTP, row group = wave / KTP)
+template <int NT, int KTP>
+__global__ __launch_bounds__(kThreads, 4) void dense_bwd_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
+                                                                 const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
+                                                                 int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
+                                                                 int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ slabs,
+                                                                 double* __restrict__ in_sums) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int Np = NT * 16, ldz = Np + 4;
+  constexpr int RGN = 8 / KTP;                      // row groups
+  constexpr int TM = bwd_tm(KTP);                   // rows per tile
+  constexpr int RT = TM / 16 / RGN;                 // row tiles per wave (2, 1, 1, 1)
   const int KT = (K + 15) >> 4, Kp = KT << 4, ldx = Kp + 4;
-  const int KTP = 1 << ktp_log2, RGN = 8 >> ktp_log2;
-  const int mkld = (Kp >> 3);                       // mask bytes per row
-  const int buf_floats = kBwdTM * ldx + kBwdTM * ldz + ((kBwdTM * mkld + 3) >> 2);
-  float* Xb[2] = {smem, smem + buf_floats};
-  float* Cs = smem + 2 * buf_floats;                // [4][Np] per-column constants of the out BN
+  const int mkld = Kp >> 3;                         // mask bytes per row
+  float* Xs = smem;                                 // [TM][ldx]   T(x)
+  float* Zs = Xs + TM * ldx;                        // [TM][ldz]   dz
+  uint8_t* Mk = reinterpret_cast<uint8_t*>(Zs + TM * ldz);   // [TM][mkld] dropout keep bits
+  float* Cs = Zs + TM * ldz + ((TM * mkld + 3) >> 2);        // [4][Np] per-column constants of the out BN
   float* ssb = Cs + 4 * Np;                         // [scale Kp | shift Kp] of the in transform
   const float* ss = tin.scale ? ssb : nullptr;
   if (tin.scale)
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __rest
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
-  const int kt = wave & (KTP - 1), rg = wave >> ktp_log2;
+  const int kt = wave % KTP, rg = wave / KTP;
   const bool kt_live = kt < KT;
   const int kcol = kt * 16 + c16;
   const bool xvec = (ldx_g % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
@@ -302,10 +305,12 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __rest
   for (int n = threadIdx.x; n < Np; n += blockDim.x) {
     float c1 = 1.f, c2 = 0.f, c3 = 0.f, mu = 0.f, rs = 0.f;
     if (to.mean && n < N) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int r = 0; r < kRep; ++r) { s1 += to.sums[(size_t)r * 2 * N + n]; s2 += to.sums[(size_t)r * 2 * N + N + n]; }
       rs = to.rstd[n]; mu = to.mean[n];
       c1 = to.gamma[n] * rs;
-      c2 = (float)(to.sums[n] * (double)to.inv_batch);
-      c3 = (float)(to.sums[N + n] * (double)to.inv_batch);
+      c2 = (float)(s1 * (double)to.inv_batch);
+      c3 = (float)(s2 * (double)to.inv_batch);
     }
     Cs[0 * Np + n] = c1; Cs[1 * Np + n] = c2; Cs[2 * Np + n] = c3 * rs; Cs[3 * Np + n] = mu;
   }
@@ -326,49 +331,56 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __rest
   const float imean = (ibn.mean && kt_live && kcol < K) ? ibn.mean[kcol] : 0.f;
   const float irstd = (ibn.mean && kt_live && kcol < K) ? ibn.rstd[kcol] : 0.f;
 
-  const int zc_row = Np >> 3, xc_row = Kp >> 3;
-  const int n_zc = kBwdTM * zc_row, n_xc = kBwdTM * xc_row;     // <= 1024 each => <= 2 per thread
-  float pgy[2][8], py[2][8], px[2][8];
-  const int64_t n_tiles = (batch + kBwdTM - 1) / kBwdTM;
+  constexpr int ZCR = Np / 8;                       // dz chunks per row
+  constexpr int MAXZ = (TM * ZCR + kThreads - 1) / kThreads;
+  constexpr int MAXX = (TM * (kMaxT * 16 / 8) + kThreads - 1) / kThreads;   // bound for Kp <= 128
+  const int xc_row = Kp >> 3, n_xc = TM * xc_row;
+  float pz[MAXZ][8], px[MAXX][8];     // dz is formed at load time: one register set instead of gy + y
+  const int64_t n_tiles = (batch + TM - 1) / TM;
 
   auto load_tile = [&](int64_t tile) {
-    const int64_t row_base = tile * kBwdTM;
+    const int64_t row_base = tile * TM;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MAXZ; ++i) {
       const int idx = threadIdx.x + kThreads * i;
-      if (idx < n_zc) {
-        const int r = idx / zc_row, c = (idx - r * zc_row) << 3;
-        load8(pgy[i], gy, ldgy, row_base + r, batch, c, N, gvec);
-        load8(py[i], y, ldy, row_base + r, batch, c, N, yvec);
+      if (idx < TM * ZCR) {
+        const int r = idx / ZCR, c = (idx - r * ZCR) << 3;
+        const bool live = (row_base + r) < batch;
+        float vg[8], vy[8];
+        load8(vg, gy, ldgy, row_base + r, batch, c, N, gvec);
+        load8(vy, y, ldy, row_base + r, batch, c, N, yvec);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = c + e;
+          float da = vg[e];
+          // da = gamma*rstd * (gy - mean(gy) - xhat*mean(gy*xhat)), xhat = (y-mu)*rstd
+          if (to.mean) da = Cs[n] * (vg[e] - Cs[Np + n] - (vy[e] - Cs[3 * Np + n]) * Cs[2 * Np + n]);
+          pz[i][e] = (live && n < N) ? da * act_grad_from_out(vy[e], act) : 0.f;
+        }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXX; ++i) {
+      const int idx = threadIdx.x + kThreads * i;
       if (idx < n_xc) {
         const int r = idx / xc_row, c = (idx - r * xc_row) << 3;
         load8(px[i], x, ldx_g, row_base + r, batch, c, K, xvec);
       }
     }
   };
-  auto write_tile = [&](int64_t tile, float* buf) {
-    float* Xs = buf;
-    float* Zs = buf + kBwdTM * ldx;
-    uint8_t* Mk = reinterpret_cast<uint8_t*>(Zs + kBwdTM * ldz);
-    const int64_t row_base = tile * kBwdTM;
+  auto write_tile = [&](int64_t tile) {
+    const int64_t row_base = tile * TM;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MAXZ; ++i) {
       const int idx = threadIdx.x + kThreads * i;
-      if (idx < n_zc) {
-        const int r = idx / zc_row, c = (idx - r * zc_row) << 3;
-        const bool live = (row_base + r) < batch;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int n = c + e;
-          float da = pgy[i][e];
-          // da = gamma*rstd * (gy - mean(gy) - xhat*mean(gy*xhat)), xhat = (y-mu)*rstd
-          if (to.mean) da = Cs[n] * (pgy[i][e] - Cs[Np + n] - (py[i][e] - Cs[3 * Np + n]) * Cs[2 * Np + n]);
-          v[e] = (live && n < N) ? da * act_grad_from_out(py[i][e], act) : 0.f;
-        }
-        store8_lds(Zs + r * ldz + c, v);
+      if (idx < TM * ZCR) {
+        const int r = idx / ZCR, c = (idx - r * ZCR) << 3;
+        store8_lds(Zs + r * ldz + c, pz[i]);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXX; ++i) {
+      const int idx = threadIdx.x + kThreads * i;
       if (idx < n_xc) {
         const int r = idx / xc_row, c = (idx - r * xc_row) << 3;
         const uint32_t bits = xform8(px[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
@@ -379,52 +391,47 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __rest
   };
 
   int64_t tile = blockIdx.x;
-  int cur = 0;
-  __syncthreads();   // Cs visible
-  if (tile < n_tiles) {
-    load_tile(tile);
-    write_tile(tile, Xb[0]);
-  }
+  __syncthreads();   // Cs, scale|shift visible
+  if (tile < n_tiles) load_tile(tile);
+  if (tile < n_tiles) write_tile(tile);
   __syncthreads();
   while (tile < n_tiles) {
     const int64_t next = tile + gridDim.x;
     if (next < n_tiles) load_tile(next);
-    const float* Xs = Xb[cur];
-    const float* Zs = Xs + kBwdTM * ldx;
-    const uint8_t* Mk = reinterpret_cast<const uint8_t*>(Zs + kBwdTM * ldz);
-    const int64_t row_base = tile * kBwdTM;
+    const int64_t row_base = tile * TM;
     if (kt_live) {
       // ---- dx[rows of my row tiles][k-tile] = dz · W^T ; contraction over n ----
       if (gx) {
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-          const int rt = rg + RGN * i;
-          if (rt < 4) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float* zr = Zs + (rt * 16 + c16) * ldz + 4 * g;
+        f32x4 acc[RT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const float4 a4 = *reinterpret_cast<const float4*>(zr + 16 * j);
-              acc = mfma16(a4.x, bwt[4 * j + 0], acc);
-              acc = mfma16(a4.y, bwt[4 * j + 1], acc);
-              acc = mfma16(a4.z, bwt[4 * j + 2], acc);
-              acc = mfma16(a4.w, bwt[4 * j + 3], acc);
-            }
-            if (kcol < K) {
+        for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int lr = rt * 16 + 4 * g + r;
-                const int64_t gr = row_base + lr;
-                if (gr < batch) {
-                  // gx = gradient w.r.t. the producer's BN output h (dropout transposed here)
-                  const bool keep = (Mk[lr * mkld + (kcol >> 3)] >> (kcol & 7)) & 1;
-                  const float dh = keep ? acc[r] * tin.drop.inv_keep : 0.f;
-                  gx[gr * ldgx + kcol] = dh;
-                  if (ibn.mean && keep) {
-                    const float xhat = (x[gr * ldx_g + kcol] - imean) * irstd;
-                    isum += dh;
-                    isq += dh * xhat;
-                  }
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            const float4 a4 = *reinterpret_cast<const float4*>(Zs + ((rg + RGN * i) * 16 + c16) * ldz + 16 * j + 4 * g);
+            acc[i] = mfma16(a4.x, bwt[4 * j + 0], acc[i]);
+            acc[i] = mfma16(a4.y, bwt[4 * j + 1], acc[i]);
+            acc[i] = mfma16(a4.z, bwt[4 * j + 2], acc[i]);
+            acc[i] = mfma16(a4.w, bwt[4 * j + 3], acc[i]);
+          }
+        }
+        if (kcol < K) {
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int lr = (rg + RGN * i) * 16 + 4 * g + r;
+              const int64_t gr = row_base + lr;
+              if (gr < batch) {
+                // gx = gradient w.r.t. the producer's BN output h (dropout transposed here)
+                const bool keep = (Mk[lr * mkld + (kcol >> 3)] >> (kcol & 7)) & 1;
+                const float dh = keep ? acc[i][r] * tin.drop.inv_keep : 0.f;
+                gx[gr * ldgx + kcol] = dh;
+                if (ibn.mean && keep) {
+                  const float xhat = (x[gr * ldx_g + kcol] - imean) * irstd;
+                  isum += dh;
+                  isq += dh * xhat;
                 }
               }
             }
@@ -432,17 +439,14 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __rest
         }
       }
       // ---- dW[k-tile rows][N] += T(x)^T · dz ; contraction over my row tiles' rows ----
-#pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int rt = rg + RGN * i;
-        if (rt < 4) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int r = rt * 16 + 4 * g + s;
-            const float a = Xs[r * ldx + kcol];
+      for (int i = 0; i < RT; ++i) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) dW[nt] = mfma16(a, Zs[r * ldz + nt * 16 + c16], dW[nt]);
-          }
+        for (int s = 0; s < 4; ++s) {
+          const int r = (rg + RGN * i) * 16 + 4 * g + s;
+          const float a = Xs[r * ldx + kcol];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) dW[nt] = mfma16(a, Zs[r * ldz + nt * 16 + c16], dW[nt]);
         }
       }
     }
@@ -450,12 +454,12 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __rest
     if (threadIdx.x < Np) {
       float sacc = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < kBwdTM; ++r) sacc += Zs[r * ldz + threadIdx.x];
+      for (int r = 0; r < TM; ++r) sacc += Zs[r * ldz + threadIdx.x];
       db_acc += sacc;
     }
-    if (next < n_tiles) write_tile(next, Xb[cur ^ 1]);
+    __syncthreads();               // everyone done reading the LDS images
+    if (next < n_tiles) write_tile(next);
     __syncthreads();
-    cur ^= 1;
     tile = next;
   }
 
@@ -482,8 +486,9 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const float* __rest
     s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
     q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
     if (g == 0 && kcol < K) {
-      atomicAdd(in_sums + kcol, s);
-      atomicAdd(in_sums + K + kcol, q);
+      double* rep = in_sums + (size_t)(blockIdx.x % kRep) * 2 * K;
+      atomicAdd(rep + kcol, s);
+      atomicAdd(rep + K + kcol, q);
     }
   }
 }
@@ -619,12 +624,22 @@ using namespace br;
 
 static inline int tiles16(int v) { return (v + 15) / 16; }
 static inline int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-static inline int log2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline unsigned grid_for(int64_t batch, int tm) {
   int64_t t = ceil_div(batch, tm);
   return (unsigned)(t < kMaxGrid ? (t < 1 ? 1 : t) : kMaxGrid);
 }
-constexpr int kMaxDynLds = 160 * 1024 - 2048;
+constexpr int kMaxDynLds = 80 * 1024 - 1024;   // two workgroups per CU
+
+template <int NTP, int KJ>
+static void launch_fwd(unsigned grid, size_t shmem, hipStream_t s, const float* x, int64_t ldx, const float* W, const float* bias, float* y,
+                       int64_t ldy, int64_t batch, int K, int N, int act, InXform t, int64_t row0, double* stats) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NTP, KJ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  dense_fwd_kernel<NTP, KJ><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats);
+}
 
 extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
                               int64_t batch, int K, int N, int act, const float* in_scale, const float* in_shift,
@@ -636,20 +651,18 @@ extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const
   BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
   BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
   if (batch == 0) return BR_OK;
-  const int NTP = pow2_ge(tiles16(N)), Kp = tiles16(K) * 16;
-  const size_t shmem = ((size_t)2 * kFwdTM * (Kp + 4) + 2 * (size_t)Kp) * sizeof(float);
+  const int NTP = pow2_ge(tiles16(N)), KJ = tiles16(K), Kp = KJ * 16;
+  const int tm = fwd_tm(NTP);
+  const size_t shmem = ((size_t)tm * (Kp + 4) + 2 * (size_t)Kp) * sizeof(float);
   InXform t{in_scale, in_shift, make_dropout(drop_p, seed, step, site)};
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = grid_for(batch, kFwdTM);
-#define BR_FWD(NTv)                                                                                                      \
-  case NTv: {                                                                                                            \
-    static bool attr_set = false;                                                                                        \
-    if (!attr_set) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds); \
-      attr_set = true;                                                                                                   \
-    }                                                                                                                    \
-    dense_fwd_kernel<NTv><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats);      \
-  } break;
+  const unsigned grid = grid_for(batch, tm);
+#define BR_FWD_KJ(NTPv, KJv) case KJv: launch_fwd<NTPv, KJv>(grid, shmem, s, x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats); break;
+#define BR_FWD(NTPv)                                                                                            \
+  case NTPv:                                                                                                    \
+    switch (KJ) { BR_FWD_KJ(NTPv, 1) BR_FWD_KJ(NTPv, 2) BR_FWD_KJ(NTPv, 3) BR_FWD_KJ(NTPv, 4) BR_FWD_KJ(NTPv, 5) \
+                  BR_FWD_KJ(NTPv, 6) BR_FWD_KJ(NTPv, 7) BR_FWD_KJ(NTPv, 8) default: break; }                   \
+    break;
   switch (NTP) {
     BR_FWD(1) BR_FWD(2) BR_FWD(4) BR_FWD(8)
     default: br::set_error("brDenseForward: unsupported N"); return BR_ERR_UNSUPPORTED;
@@ -687,7 +700,19 @@ extern "C" int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta
 extern "C" int brDenseBackwardSlabs(int64_t batch, int K, int N) {
   (void)N;
   const int KTP = pow2_ge(tiles16(K < 1 ? 1 : K));
-  return (int)grid_for(batch, kBwdTM) * (8 / KTP);
+  return (int)grid_for(batch, bwd_tm(KTP)) * (8 / KTP);
+}
+
+template <int NT, int KTP>
+static void launch_bwd(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
+                       int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn, int64_t row0,
+                       float* gx, int64_t ldgx, float* slabs, double* in_sums) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dense_bwd_kernel<NT, KTP>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  dense_bwd_kernel<NT, KTP><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, slabs, in_sums);
 }
 
 extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
@@ -706,28 +731,22 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
                "brDenseBackward: in BN pointers all or none");
   BR_CHECK_ARG(!in_mean || gx, "brDenseBackward: in BN sums need gx");
   if (batch == 0) return BR_OK;
-  const unsigned grid = grid_for(batch, kBwdTM);
-  const int want = brDenseBackwardSlabs(batch, K, N);
-  BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
   const int KT = tiles16(K), NT = tiles16(N);
   const int Kp = KT * 16, Np = NT * 16;
-  const int ktp_log2 = log2i(pow2_ge(KT));
-  const size_t buf_floats = (size_t)kBwdTM * (Kp + 4) + (size_t)kBwdTM * (Np + 4) + (size_t)((kBwdTM * (Kp / 8) + 3) / 4);
-  const size_t shmem = (2 * buf_floats + 4 * (size_t)Np + 2 * (size_t)Kp) * sizeof(float);
+  const int KTP = pow2_ge(KT), tm = bwd_tm(KTP);
+  const unsigned grid = grid_for(batch, tm);
+  const int want = brDenseBackwardSlabs(batch, K, N);
+  BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
+  const size_t shmem = ((size_t)tm * (Kp + 4) + (size_t)tm * (Np + 4) + (size_t)((tm * (Kp / 8) + 3) / 4) + 4 * (size_t)Np + 2 * (size_t)Kp) * sizeof(float);
   OutXform to{out_mean, out_rstd, out_gamma, bn_sums, (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch))};
   InXform tin{in_scale, in_shift, make_dropout(in_drop_p, seed, step, in_site)};
   InBn ibn{in_mean, in_rstd};
   hipStream_t s = (hipStream_t)stream;
-#define BR_BWD(NTv)                                                                                                      \
-  case NTv: {                                                                                                            \
-    static bool attr_set = false;                                                                                        \
-    if (!attr_set) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void*)dense_bwd_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds); \
-      attr_set = true;                                                                                                   \
-    }                                                                                                                    \
-    dense_bwd_kernel<NTv><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, \
-                                                        dW_slabs, in_bn_sums, ktp_log2);                                 \
-  } break;
+#define BR_BWD_K(NTv, KTPv) case KTPv: launch_bwd<NTv, KTPv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dW_slabs, in_bn_sums); break;
+#define BR_BWD(NTv) \
+  case NTv:         \
+    switch (KTP) { BR_BWD_K(NTv, 1) BR_BWD_K(NTv, 2) BR_BWD_K(NTv, 4) BR_BWD_K(NTv, 8) default: break; } \
+    break;
   switch (NT) {
     BR_BWD(1) BR_BWD(2) BR_BWD(3) BR_BWD(4) BR_BWD(5) BR_BWD(6) BR_BWD(7) BR_BWD(8)
     default: br::set_error("brDenseBackward: unsupported N"); return BR_ERR_UNSUPPORTED;

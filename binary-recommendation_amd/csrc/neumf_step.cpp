@@ -90,12 +90,13 @@ extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream
   float* bn = s->bn;
   float *scale1 = bn, *shift1 = bn + n1, *mean1 = bn + 2 * n1, *rstd1 = bn + 3 * n1;
   float *scale2 = bn + 4 * n1, *shift2 = scale2 + n2, *mean2 = scale2 + 2 * n2, *rstd2 = scale2 + 3 * n2;
-  double *stats1 = s->dstat, *stats2 = stats1 + 2 * n1, *bsum1 = stats2 + 2 * n2, *bsum2 = bsum1 + 2 * n1;
+  constexpr int R = BR_STAT_REPLICAS;   // every BN-sum buffer is [R][2N]
+  double *stats1 = s->dstat, *stats2 = stats1 + R * 2 * n1, *bsum1 = stats2 + R * 2 * n2, *bsum2 = bsum1 + R * 2 * n1;
   float *mm1 = s->moving, *mv1 = mm1 + n1, *mm2 = mv1 + n1, *mv2 = mm2 + n2;
   const int uoff = s->item_first ? D : 0, ioff = s->item_first ? 0 : D;
   if (ph & BR_PH_FWD1) {
     if (train) {
-      hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(4 * n1 + 4 * n2), hs);
+      hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(BR_STAT_REPLICAS * (4 * n1 + 4 * n2)), hs);
       if (e != hipSuccess) { br::set_error("brNeumfStepRun: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
     }
     if (ph & BR_PH_EMBED)

@@ -160,13 +160,15 @@ class NeuMFEngine:
         self.da3, self.ddot = f(B, n3), f(B)
         self.gh2, self.gh1, self.dx0 = f(B, n2), f(B, n1), f(B, 2 * D)
         self.g_user, self.g_item = f(B, 2 * D), f(B, 2 * D)      # fused [mlp | mf] row gradients per stream
-        # per-step double scratch: [stats1 2n1 | stats2 2n2 | bsum1 2n1 | bsum2 2n2]
-        self.dstat = torch.zeros(4 * n1 + 4 * n2, dtype=torch.float64, device=dev)
+        # per-step double scratch: [stats1 | stats2 | bsum1 | bsum2], each [BR_STAT_REPLICAS][2n] (the kernels
+        # spread their column-sum atomics over 8 replicas; consumers add them)
+        R = ops.STAT_REPLICAS
+        self.dstat = torch.zeros(R * (4 * n1 + 4 * n2), dtype=torch.float64, device=dev)
         o = 0
-        self.stats1 = self.dstat[o:o + 2 * n1]; o += 2 * n1
-        self.stats2 = self.dstat[o:o + 2 * n2]; o += 2 * n2
-        self.bsum1 = self.dstat[o:o + 2 * n1]; o += 2 * n1
-        self.bsum2 = self.dstat[o:o + 2 * n2]
+        self.stats1 = self.dstat[o:o + R * 2 * n1]; o += R * 2 * n1
+        self.stats2 = self.dstat[o:o + R * 2 * n2]; o += R * 2 * n2
+        self.bsum1 = self.dstat[o:o + R * 2 * n1]; o += R * 2 * n1
+        self.bsum2 = self.dstat[o:o + R * 2 * n2]
         self.msums = torch.zeros(4, dtype=torch.float64, device=dev)   # loss, se, ae, correct (epoch)
         self.bn_buf = f(4 * n1 + 4 * n2)      # [scale1|shift1|mean1|rstd1|scale2|shift2|mean2|rstd2]
         self.bn, o = {}, 0

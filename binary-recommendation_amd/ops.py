@@ -16,6 +16,7 @@ from ._lib import check
 I32, I64 = 0, 1
 ACT = {"linear": 0, "sigmoid": 1, "relu": 2}
 LOSS = {"bce": 0, "mse": 1}
+STAT_REPLICAS = 8   # BR_STAT_REPLICAS: every BatchNorm column-sum buffer is double[8][2N]
 
 
 def _stream() -> int:

@@ -38,7 +38,7 @@ enum { BR_OK = 0, BR_ERR_ARG = -1, BR_ERR_HIP = -2, BR_ERR_UNSUPPORTED = -3, BR_
 enum { BR_IDS_I32 = 0, BR_IDS_I64 = 1 };
 enum { BR_ACT_LINEAR = 0, BR_ACT_SIGMOID = 1, BR_ACT_RELU = 2 };
 enum { BR_LOSS_BCE = 0, BR_LOSS_MSE = 1 };
-enum { BR_MAX_TABLES = 8, BR_SUM_SLOTS = 64 };
+enum { BR_MAX_TABLES = 8, BR_SUM_SLOTS = 64, BR_STAT_REPLICAS = 8 };
 
 const char* brGetLastError(void);
 int brVersion(void);
@@ -148,7 +148,10 @@ int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n, double lr
  * y = act( T(x)·W + bias ),  T(x)[r,k] = (x[r,k]*in_scale[k] + in_shift[k]) * keep(r,k)/(1-p)
  *   in_scale/in_shift (K) NULL => identity (they carry the previous layer's BatchNorm);
  *   drop_p == 0 => no dropout; keep(r,k) from Philox(seed, step, site, row0+r, k).
- * stats (double[2N], may be NULL): += column sums of y and y^2 (BatchNorm batch statistics).
+ * stats (double[BR_STAT_REPLICAS][2N], may be NULL): += column sums of y and y^2 (BatchNorm batch
+ *   statistics), spread over 8 replicas (workgroup % 8) so same-address atomics do not serialise;
+ *   consumers (brBnFinalize, brDenseBackward, brBnParamGrads) add the replicas.  The same layout
+ *   holds for every BN-sum buffer below (bn_sums, in_bn_sums).
  * x: (B x K) row stride ldx; W: (K x N) row-major; y: (B x N) row stride ldy. */
 int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
                    int64_t ldy, int64_t batch, int K, int N, int act, const float* in_scale,
@@ -266,7 +269,7 @@ typedef struct brNeumfStep {
   float* x0; float* dot; float* a1; float* a2; float* a3; float* logit; float* prob;
   float* da3; float* ddot; float* gh2; float* gh1; float* dx0; float* g_user; float* g_item;
   float* bn;                               /* [scale1|shift1|mean1|rstd1] n1 each, then the same for layer 2 */
-  double* dstat;                           /* [stats1 2n1 | stats2 2n2 | bsum1 2n1 | bsum2 2n2], zeroed in FWD1 */
+  double* dstat;                           /* [stats1 | stats2 | bsum1 | bsum2], each [BR_STAT_REPLICAS][2n]; zeroed in FWD1 */
   double* msums;                           /* [loss, sum sq err, sum abs err, #correct] accumulated */
   float* slabs; float* hslabs;
   int* err_flag;

@@ -20,7 +20,7 @@ res = {}
 for (K, N) in ((128, 100), (100, 50), (50, 10), (128, 64), (128, 128)):
     x = torch.randn(B, K, device=dev); W = torch.randn(K, N, device=dev) * 0.1; b = torch.zeros(N, device=dev)
     y = torch.empty(B, N, device=dev); sc = torch.ones(K, device=dev); sh = torch.zeros(K, device=dev)
-    stats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+    stats = torch.zeros(8 * 2 * N, dtype=torch.float64, device=dev)
     for tag, kw in (("linear,nodrop", dict(act="linear")), ("sigmoid,nodrop", dict(act="sigmoid")),
                     ("linear,drop", dict(act="linear", drop_p=0.2)), ("sigmoid,drop,bn,stats", dict(act="sigmoid", drop_p=0.2, in_scale=sc, in_shift=sh, stats=stats))):
         act = kw.pop("act")
@@ -29,7 +29,7 @@ for (K, N) in ((128, 100), (100, 50), (50, 10), (128, 64), (128, 128)):
     gy = torch.randn(B, N, device=dev); gx = torch.empty(B, K, device=dev)
     ns = ops.dense_backward_slabs(B, K, N); slabs = torch.empty(ns * (K * N + N), device=dev)
     mean = torch.zeros(N, device=dev); rstd = torch.ones(N, device=dev); gam = torch.ones(N, device=dev)
-    bns = torch.zeros(2 * N, dtype=torch.float64, device=dev); ins = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+    bns = torch.zeros(8 * 2 * N, dtype=torch.float64, device=dev); ins = torch.zeros(8 * 2 * K, dtype=torch.float64, device=dev)
     mi = torch.zeros(K, device=dev); ri = torch.ones(K, device=dev)
     for tag, kw in (("plain", dict(act="linear")), ("sigmoid,drop", dict(act="sigmoid", in_drop_p=0.2)),
                     ("full", dict(act="sigmoid", in_drop_p=0.2, out_bn=(mean, rstd, gam), bn_sums=bns, in_scale=sc, in_shift=sh, in_bn=(mi, ri), in_bn_sums=ins))):
