@@ -291,3 +291,39 @@ def neumf_head(a3, dot, labels, w4, b4, mf_first, loss, inv_batch, logit=None, p
 def bce_logits(z, y, inv_batch, prob=None, dz=None, sums=None):
     check(_lib.load().brBceLogits(z.data_ptr(), y.data_ptr(), z.shape[0], float(inv_batch), _p(prob), _p(dz), _p(sums),
                                   _stream()), "brBceLogits")
+
+
+# ------------------------------------------------------------------------------ L4 in-batch softmax / E1 scoring + top-k
+SUM_SLOTS = 64   # BR_SUM_SLOTS
+
+
+def inbatch_softmax_lse(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, loss_sum):
+    qi, qt = _ids(q_pos_ids, "q_pos_ids"); ci, ct = _ids(cand_ids, "cand_ids")
+    id_type = _same_id_type(qt, ct) if qi is not None else I32
+    check(_lib.load().brInBatchSoftmaxLse(_f32(Q, "Q").data_ptr(), _f32(C, "C").data_ptr(), _p(qi), _p(ci), id_type, Q.shape[0], C.shape[0],
+                                          Q.shape[1], int(diag_offset), _f32(row_lse, "row_lse").data_ptr(), loss_sum.data_ptr(), _stream()),
+          "brInBatchSoftmaxLse")
+
+
+def inbatch_softmax_grad(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, dQ=None, dC=None):
+    qi, qt = _ids(q_pos_ids, "q_pos_ids"); ci, ct = _ids(cand_ids, "cand_ids")
+    id_type = _same_id_type(qt, ct) if qi is not None else I32
+    check(_lib.load().brInBatchSoftmaxGrad(_f32(Q, "Q").data_ptr(), _f32(C, "C").data_ptr(), _p(qi), _p(ci), id_type, Q.shape[0], C.shape[0],
+                                           Q.shape[1], int(diag_offset), row_lse.data_ptr(), _p(dQ), _p(dC), _stream()), "brInBatchSoftmaxGrad")
+
+
+def score_matrix(Q, C, out=None):
+    if out is None:
+        out = torch.empty(Q.shape[0], C.shape[0], dtype=torch.float32, device=Q.device)
+    check(_lib.load().brScoreMatrix(_f32(Q, "Q").data_ptr(), _f32(C, "C").data_ptr(), Q.shape[0], C.shape[0], Q.shape[1], out.data_ptr(),
+                                    out.stride(0), _stream()), "brScoreMatrix")
+    return out
+
+
+def topk_rows(scores, k):
+    """stable top-k per row: descending, ties keep the lower column (topKmetrics.py:59,68)."""
+    U, I = scores.shape
+    os_ = torch.empty(U, k, dtype=torch.float32, device=scores.device)
+    oi = torch.empty(U, k, dtype=torch.int32, device=scores.device)
+    check(_lib.load().brTopKRows(_f32(scores, "scores").data_ptr(), U, I, int(k), os_.data_ptr(), oi.data_ptr(), _stream()), "brTopKRows")
+    return os_, oi

@@ -1,0 +1,155 @@
+"""TwoTower retrieval model on the HIP hot path — trainers/twoTower.py:19-111.
+
+  userTower = StringLookup -> Embedding(nbrUser+2, embedDim) -> Dense(semb)      (twoTower.py:33-40)
+  itemTower = StringLookup -> Embedding(nbrItem+2, embedDim) -> Dense(semb)      (twoTower.py:35-41)
+  computeLossTfrs : tfrs.tasks.Retrieval(loss=None) with candidate_ids = batch item ids
+                    = in-batch softmax, accidental hits masked, SUM reduction [TF-sem]  (:47,82-83)
+  computeLossRdZero: sigmoid(Dot(q, c)) vs RATING_TYPE, BinaryCrossentropy                (:85-87)
+  train_step: GradientTape over both towers, optimizer.apply_gradients                      (:89-102)
+  optimizer : getOptimizer("Adagrad", 0.1) (twoTower.py:209,278-279; helper file missing in the
+              reference) => Keras Adagrad, initial accumulator 0.1, eps 1e-7 [TF-sem]
+StringLookup is host-side vocabulary mapping: index 0 = mask, 1 = OOV, vocabulary from 2 (hence +2 rows).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+class StringLookup:
+    """tf.keras StringLookup(vocabulary=...) [TF-sem TF 2.3]: '' -> 0, OOV -> 1, vocabulary[i] -> i + 2."""
+
+    def __init__(self, vocabulary):
+        self.index = {str(v): i + 2 for i, v in enumerate(vocabulary)}
+
+    def __call__(self, keys, device=None, dtype=torch.int32):
+        idx = [0 if k == "" else self.index.get(str(k), 1) for k in keys]
+        return torch.tensor(idx, dtype=dtype, device=device)
+
+
+class TwoTowerEngine:
+    def __init__(self, embed_dim: int, nbr_item: int, nbr_user: int, semb: int, device, max_batch: int, lr: float = 0.1,
+                 optimizer: str = "Adagrad", rd_zero: bool = False, id_dtype=torch.int32, init_seed: int = 0):
+        assert optimizer in ("Adagrad", "Adam")
+        if embed_dim > 128 or semb > 128:
+            raise ValueError("embedDim and semb <= 128 in this build")
+        dev = self.device = torch.device(device)
+        self.E, self.S, self.max_batch, self.lr, self.optimizer, self.rd_zero, self.id_dtype = embed_dim, semb, int(max_batch), lr, optimizer, rd_zero, id_dtype
+        g = torch.Generator(device="cpu").manual_seed(init_seed)
+        E, S, B = embed_dim, semb, self.max_batch
+        self.user_emb = (torch.rand(nbr_user + 2, E, generator=g) * 0.1 - 0.05).to(dev)
+        self.item_emb = (torch.rand(nbr_item + 2, E, generator=g) * 0.1 - 0.05).to(dev)
+        # dense params flat: [Wu (E x S) | bu (S) | Wi (E x S) | bi (S)]  ([W|b] adjacent: slab layout)
+        lim = math.sqrt(6.0 / (E + S))
+        self.theta = torch.zeros(2 * (E * S + S), device=dev)
+        self.grad = torch.zeros_like(self.theta)
+        for o in (0, E * S + S):
+            self.theta[o:o + E * S].copy_(((torch.rand(E * S, generator=g) * 2 - 1) * lim).to(dev))
+        acc0 = 0.1 if optimizer == "Adagrad" else 0.0
+        mk = lambda t: torch.full_like(t, acc0)
+        self.user_acc, self.item_acc, self.theta_acc = mk(self.user_emb), mk(self.item_emb), mk(self.theta)
+        if optimizer == "Adam":
+            self.user_v, self.item_v, self.theta_v = (torch.zeros_like(t) for t in (self.user_emb, self.item_emb, self.theta))
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.eu, self.ei, self.q, self.c = f(B, E), f(B, E), f(B, S), f(B, S)
+        self.dq, self.dc, self.deu, self.dei = f(B, S), f(B, S), f(B, E), f(B, E)
+        self.lse, self.z, self.dz, self.prob = f(B), f(B), f(B), f(B)
+        self.loss_slots = torch.zeros(ops.SUM_SLOTS, dtype=torch.float64, device=dev)
+        self.ns = ops.dense_backward_slabs(B, E, S)
+        self.slabs = f(self.ns * (E * S + S))
+        self.user_index, self.item_index = ops.RowIndex(B, id_dtype, dev), ops.RowIndex(B, id_dtype, dev)
+        self.err = ops.new_err_flag(dev)
+        self.t, self.n_seen = 0, 0
+
+    # views
+    def W(self, tower):
+        o = 0 if tower == "user" else self.E * self.S + self.S
+        return self.theta[o:o + self.E * self.S].view(self.E, self.S), self.theta[o + self.E * self.S:o + self.E * self.S + self.S]
+
+    def _gW(self, tower):
+        o = 0 if tower == "user" else self.E * self.S + self.S
+        return self.grad[o:o + self.E * self.S + self.S]
+
+    def compute_emb(self, users, items, B):
+        """computeEmb (twoTower.py:77-80): (q, c) = towers(user ids), towers(item ids)."""
+        ops.gather_rows([self.user_emb, self.item_emb], [users, items], [self.eu[:B], self.ei[:B]], err_flag=self.err)
+        Wu, bu = self.W("user"); Wi, bi = self.W("item")
+        ops.dense_forward(self.eu[:B], Wu, bu, self.q[:B], "linear")
+        ops.dense_forward(self.ei[:B], Wi, bi, self.c[:B], "linear")
+        return self.q[:B], self.c[:B]
+
+    def item_tower(self, items):
+        """itemTower over arbitrary ids (setCandidates, twoTower.py:64-69)."""
+        n = items.shape[0]
+        e = ops.gather_rows([self.item_emb], [items])[0]
+        out = torch.empty(n, self.S, device=self.device)
+        Wi, bi = self.W("item")
+        ops.dense_forward(e, Wi, bi, out, "linear")
+        return out
+
+    def user_tower(self, users):
+        n = users.shape[0]
+        e = ops.gather_rows([self.user_emb], [users])[0]
+        out = torch.empty(n, self.S, device=self.device)
+        Wu, bu = self.W("user")
+        ops.dense_forward(e, Wu, bu, out, "linear")
+        return out
+
+    def train_step(self, users, items, labels=None):
+        """train_step (twoTower.py:89-102). labels only for rd_zero (RATING_TYPE)."""
+        B = users.shape[0]
+        if B == 0:
+            return
+        if B > self.max_batch:
+            raise ValueError("batch exceeds max_batch")
+        self.t += 1
+        q, c = self.compute_emb(users, items, B)
+        dq, dc = self.dq[:B], self.dc[:B]
+        if self.rd_zero:
+            ops.row_dot(q, c, self.z[:B])
+            ops.bce_logits(self.z[:B], labels, 1.0 / B, prob=self.prob[:B], dz=self.dz[:B], sums=self.loss_slots)
+            ops.row_dot_backward(q, c, self.dz[:B], dq, dc)
+        else:
+            ops.inbatch_softmax_lse(q, c, items, items, 0, self.lse[:B], self.loss_slots)
+            ops.inbatch_softmax_grad(q, c, items, items, 0, self.lse[:B], dq, dc)
+        E, S = self.E, self.S
+        ns = ops.dense_backward_slabs(B, E, S)
+        for tower, g_out, e_in, d_e in (("user", dq, self.eu[:B], self.deu[:B]), ("item", dc, self.ei[:B], self.dei[:B])):
+            Wt, _ = self.W(tower)
+            y = self.q[:B] if tower == "user" else self.c[:B]
+            ops.dense_backward(g_out, y, e_in, Wt, "linear", self.slabs, ns, gx=d_e)
+            ops.reduce_slabs(self.slabs, ns, E * S + S, self._gW(tower))
+        self.user_index.build(users, self.user_emb.shape[0])
+        self.item_index.build(items, self.item_emb.shape[0])
+        if self.optimizer == "Adagrad":
+            ops.adagrad_rows_sorted(self.user_emb, self.user_acc, self.user_index, self.deu[:B], E, self.lr)
+            ops.adagrad_rows_sorted(self.item_emb, self.item_acc, self.item_index, self.dei[:B], E, self.lr)
+            ops.adagrad_flat(self.theta, self.theta_acc, self.grad, self.lr)
+        else:
+            a = ops.adam_alpha(self.lr, self.t)
+            ops.adam_rows_sorted(self.user_emb, self.user_acc, self.user_v, self.user_index, self.deu[:B], E, a)
+            ops.adam_rows_sorted(self.item_emb, self.item_acc, self.item_v, self.item_index, self.dei[:B], E, a)
+            ops.adam_flat(self.theta, self.theta_acc, self.theta_v, self.grad, a)
+        self.n_seen += B if self.rd_zero else 1
+
+    def test_step(self, users, items):
+        """test_step (twoTower.py:104-111): the retrieval loss without an update."""
+        B = users.shape[0]
+        q, c = self.compute_emb(users, items, B)
+        ops.inbatch_softmax_lse(q, c, items, items, 0, self.lse[:B], self.loss_slots)
+        self.n_seen += 1
+
+    def pop_loss(self) -> float:
+        """Host sync: mean over steps of the step loss (softmax: SUM over the batch per step, as TFRS
+        reports it; rd_zero: mean BCE)."""
+        s = float(self.loss_slots.sum().item())
+        n = max(1, self.n_seen)
+        self.loss_slots.zero_()
+        self.n_seen = 0
+        return s / n
+
+    def check_ids(self):
+        ops.raise_if_flag(self.err)

@@ -213,7 +213,7 @@ int brBceLogits(const float* z, const float* y, int64_t batch, float inv_batch, 
 /* ---- L4: in-batch softmax (tfrs.tasks.Retrieval, twoTower.py:47,82-83) [TF-sem] --------------
  * S = Q C^T (Bq x Bc), accidental hits (cand_ids[j]==q_pos_ids[i], j != diag) masked, loss =
  * SUM_i [logsumexp_j S_ij - S_i,diag(i)].  Streaming (the Bq x Bc matrix is never stored).
- * Pass 1 (brInBatchSoftmaxLse): row_lse (Bq), loss_sum (double) +=.
+ * Pass 1 (brInBatchSoftmaxLse): row_lse (Bq), loss_sum (double[BR_SUM_SLOTS], slot = workgroup & 63) +=.
  * Pass 2 (brInBatchSoftmaxGrad): dQ = (P - I) C, dC += (P - I)^T Q.
  * diag_offset: column of C holding query i's positive = i + diag_offset (data-parallel ranks
  * all-gather C; rank r's queries sit at offset r*Bq). */
@@ -224,6 +224,11 @@ int brInBatchSoftmaxGrad(const float* Q, const float* C, const void* q_pos_ids,
                          const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
                          int64_t diag_offset, const float* row_lse, float* dQ, float* dC,
                          brStream stream);
+
+/* scores[q][c] = Q[q]·C[c] (n_q x n_c, row stride ld_scores): candidate scoring for top-k
+ * (TwoTower BruteForce, twoTower.py:64-69,229-230; bpr_predict, src/models/bpr.py:122-133). */
+int brScoreMatrix(const float* Q, const float* C, int64_t n_q, int64_t n_c, int dim, float* scores,
+                  int64_t ld_scores, brStream stream);
 
 /* ---- E1: full-catalogue scoring + stable top-k — topKmetrics.py:17-72, twoTower.py:64-69 -----
  * scores (U x I) row-major -> top-k per user, descending, ties keep the LOWER item position
