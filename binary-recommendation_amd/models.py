@@ -1,0 +1,318 @@
+"""The reference's model surface (src/models/*, trainers/{NFC_plain,twoTower}.py) re-exposed on top of
+the HIP engines: same names, argument meaning and return conventions, so a trainer script switches by
+changing its import.  Only the hot path is re-implemented; REST, SMB `DataStore`, model plots, Neptune
+and SavedModel export are out of scope.
+
+  KerasLikeNeuMF   <- the Keras `Model` built at NFC_plain.py:107-155 / NeuMFModel.py:53-100
+                      fit / predict / evaluate / save / load (NFC_plain.py:165-183, RModel.py:130-147)
+  RModel, NeuMFModel, BPRModel <- src/models/RModel.py, NeuMFModel.py, BPRModel.py
+  TwoTowerModel    <- trainers/twoTower.py:19-111 (computeEmb / computeLoss / train_step / test_step /
+                      setCandidates / call)
+Broken call sites of the reference (`strategy` NameError, BPR arity, ...) are not reproduced.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import data as _data
+from . import ops
+from .bpr import BPREngine
+from .neumf import NeuMFConfig, NeuMFEngine
+from .two_tower import StringLookup, TwoTowerEngine
+
+
+class History:
+    """keras.callbacks.History stand-in: `.history[name]` = per-epoch list (RModel.py:103-106)."""
+
+    def __init__(self):
+        self.history = {}
+
+    def add(self, logs: dict):
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(v)
+
+
+def _to_dev(a, device, dtype):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(a)), device=device).to(dtype).contiguous()
+
+
+class KerasLikeNeuMF:
+    METRICS = ["mse", "mae", "binary_accuracy"]   # RModel.METRICS (RModel.py:20)
+
+    def __init__(self, engine: NeuMFEngine, user_first_inputs: bool = True):
+        self.engine = engine
+        self.user_first_inputs = user_first_inputs   # Model([customer_input, material_input]) (NFC_plain.py:154)
+
+    def _xy(self, x, y=None):
+        e = self.engine
+        if isinstance(x, dict):
+            u = x.get("user", x.get("customer-input")); i = x.get("item", x.get("material-input"))
+        else:
+            u, i = (x[0], x[1]) if self.user_first_inputs else (x[1], x[0])
+        u, i = _to_dev(u, e.device, e.id_dtype), _to_dev(i, e.device, e.id_dtype)
+        yy = None if y is None else _to_dev(y, e.device, torch.float32)
+        return u.view(-1), i.view(-1), None if yy is None else yy.view(-1)
+
+    def fit(self, x, y=None, epochs=1, batch_size=None, shuffle=True, verbose=0, callbacks=None, validation_data=None,
+            seed=0, orders=None):
+        """model.fit([users, items], labels, epochs, batch_size, shuffle) (NFC_plain.py:165).  Per epoch the
+        sample order is re-drawn (Keras shuffle=True); metrics are read back once per epoch."""
+        e = self.engine
+        u, i, yy = self._xy(x, y)
+        n = u.shape[0]
+        bs = int(batch_size or 32)
+        if bs > e.max_batch:
+            raise ValueError(f"batch_size {bs} > engine max_batch {e.max_batch}")
+        hist = History()
+        g = torch.Generator(device=e.device).manual_seed(seed)
+        for ep in range(epochs):
+            if orders is not None:       # caller-supplied sample order per epoch (reproducible comparisons)
+                perm = _to_dev(orders[ep], e.device, torch.int64)
+                uu, ii, ll = u[perm], i[perm], yy[perm]
+            elif shuffle:
+                perm = torch.randperm(n, device=e.device, generator=g)
+                uu, ii, ll = u[perm], i[perm], yy[perm]
+            else:
+                uu, ii, ll = u, i, yy
+            for s in range(0, n, bs):
+                e.train_step(uu[s:s + bs], ii[s:s + bs], ll[s:s + bs])
+            e.check_ids()
+            logs = e.pop_metrics(n)
+            if validation_data is not None:
+                vl = self.evaluate(validation_data[0], validation_data[1], batch_size=bs)
+                logs.update({"val_loss": vl[0], "val_mse": vl[1], "val_mae": vl[2], "val_binary_accuracy": vl[3]})
+            hist.add(logs)
+            for cb in callbacks or []:
+                cb.on_epoch_end(ep, logs)
+            if verbose:
+                print(f"Epoch {ep + 1}/{epochs} - " + " - ".join(f"{k}: {v:.6f}" for k, v in logs.items()))
+        return hist
+
+    def predict(self, x, batch_size=None, verbose=0):
+        u, i, _ = self._xy(x)
+        return self.engine.predict(u, i).cpu().numpy().reshape(-1, 1)
+
+    def evaluate(self, x, y, batch_size=None, verbose=0, callbacks=None, steps=None):
+        """-> [loss, mse, mae, binary_accuracy] (model.evaluate, NFC_plain.py:183; RModel.py:147)."""
+        e = self.engine
+        u, i, yy = self._xy(x, y)
+        bs = min(int(batch_size or e.max_batch), e.max_batch)
+        e.msums.zero_()
+        n = u.shape[0] if steps is None else min(u.shape[0], steps * bs)
+        loss_acc = 0.0
+        for s in range(0, n, bs):
+            m = min(n, s + bs) - s
+            e.evaluate_batch(u[s:s + m], i[s:s + m], yy[s:s + m])
+        mt = e.pop_metrics(n)
+        return [mt["loss"], mt["mse"], mt["mae"], mt["binary_accuracy"]]
+
+    def save(self, path):
+        """model.save(path) (NFC_plain.py:166, RModel.py:139): tables, dense params, BN moving stats and
+        optimizer slots as one safetensors-style torch file (not a TF SavedModel)."""
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        sd = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in self.engine.state_dict().items()}
+        torch.save(sd, path)
+
+    def load_weights(self, path):
+        self.engine.load_state_dict(torch.load(path, map_location=self.engine.device, weights_only=True))
+
+    def summary(self):
+        c = self.engine.cfg
+        print(f"NeuMF-{c.variant}: dim {c.dim}, tower {2 * c.dim}->{'->'.join(map(str, c.hidden))}->1, loss {c.loss}, {c.optimizer}")
+
+
+class RModel:
+    """src/models/RModel.py: hyper-parameters, paths and the train() orchestration."""
+    CUSTOMER_ID = "CUSTOMER_ID"
+    PRODUCT_ID = "PRODUCT_ID"
+    METRICS = ["mse", "mae", "binary_accuracy"]
+
+    def __init__(self, moduleName, device="cuda:0"):
+        self.modelName = moduleName
+        self.checkpointPath = "checkpoints/{}/cp".format(self.modelName)
+        self.numFactor, self._epochs, self._batchSize, self._validationSteps, self._testSize = 32, 10, 1024, 20, 0.2
+        self._model = None
+        self.device = device
+
+    epochs = property(lambda s: s._epochs, lambda s, v: setattr(s, "_epochs", v))
+    batchSize = property(lambda s: s._batchSize, lambda s, v: setattr(s, "_batchSize", v))
+    testSize = property(lambda s: s._testSize, lambda s, v: setattr(s, "_testSize", v))
+    validationSteps = property(lambda s: s._validationSteps, lambda s, v: setattr(s, "_validationSteps", v))
+    model = property(lambda s: s._model, lambda s, v: setattr(s, "_model", v))
+
+    def compileModel(self, distributedConfig, numUser, numItem, numFactor):
+        print("placeholder")
+        return None
+
+    def readyToTrain(self):
+        return True
+
+    def isMaster(self, taskType, taskId) -> bool:
+        return taskType is None or taskType == "chief" or (taskType == "worker" and taskId == 0)
+
+    def getNumberOfWorkers(self, distributedConfig) -> int:
+        return len(distributedConfig["cluster"]["worker"])
+
+    def restoreFromLatestCheckPoint(self):
+        self.model.load_weights(self.checkpointPath)
+
+
+class NeuMFModel(RModel):
+    """src/models/NeuMFModel.py."""
+
+    def __init__(self, device="cuda:0", max_batch=65536, optimizer="adam_dense"):
+        super().__init__("NeuMFModel", device)
+        self.max_batch, self.optimizer = max_batch, optimizer
+
+    def readData(self, path, rowLimit):
+        import pandas as pd
+        df = pd.read_csv(path, nrows=rowLimit)
+        df = df.drop(columns=[c for c in ("MATERIAL", "QUANTITY") if c in df.columns])
+        return int(df.PRODUCT_ID.max()) + 1, int(df.CUSTOMER_ID.max()) + 1, df
+
+    def compileModel(self, distributedConfig, numUser: int, numItem: int, numFactor: int):
+        """NeuMFModel.py:53-100: relu tower F -> F/2 -> F/4, Dot GMF, MSE, Adam(1e-3)."""
+        cfg = NeuMFConfig(variant="B", dim=numFactor, optimizer=self.optimizer)
+        self.model = KerasLikeNeuMF(NeuMFEngine(cfg, numUser, numItem, self.device, self.max_batch, id_dtype=torch.int32))
+        return self.model
+
+    def bootstrapDataset(self, df, negRatio=3.0, batchSize=128, shuffle=True, seed=0):
+        """NeuMFModel.py:102-123 -> dict(user, item, label, batch_size) instead of a tf.data.Dataset."""
+        u, i, y = _data.bootstrap_dataset(df[self.CUSTOMER_ID].to_numpy(), df[self.PRODUCT_ID].to_numpy(), negRatio, seed)
+        return {"user": u, "item": i, "label": y, "batch_size": batchSize, "shuffle": shuffle}
+
+    def prepareToTrain(self, distributedConfig, path, rowLimit):
+        from sklearn.model_selection import train_test_split
+        numItem, numUser, df = self.readData(path, rowLimit)
+        trainSplit, testSplit = train_test_split(df, test_size=self.testSize)
+        self._products = testSplit.PRODUCT_ID.unique().tolist()
+        self._users = testSplit.CUSTOMER_ID.unique().tolist()
+        bs = 128 if distributedConfig is None else self.batchSize     # NeuMFModel.py:43-48
+        trainDs, testDs = self.bootstrapDataset(trainSplit, batchSize=bs), self.bootstrapDataset(testSplit, batchSize=bs, shuffle=False)
+        self.compileModel(distributedConfig, numUser, numItem, self.numFactor)
+        return trainDs, testDs, trainSplit
+
+    def train(self, path, rowLimit, metricDict: dict = {}, distributedConfig=None):
+        """RModel.train (RModel.py:115-150) -> {'result': 'completed', 'metrics': [...]}."""
+        from sklearn.model_selection import train_test_split
+        trainDs, testDs, trainSplit = self.prepareToTrain(distributedConfig, path, rowLimit)
+        self.model.fit({"user": trainDs["user"], "item": trainDs["item"]}, trainDs["label"], epochs=self.epochs,
+                       batch_size=trainDs["batch_size"], shuffle=trainDs["shuffle"],
+                       validation_data=({"user": testDs["user"], "item": testDs["item"]}, testDs["label"]))
+        os.makedirs(os.path.dirname(self.checkpointPath), exist_ok=True)
+        self.model.save(self.checkpointPath)
+        _, val = train_test_split(trainSplit, test_size=0.2)
+        v = self.bootstrapDataset(val, shuffle=False)
+        metrics = self.model.evaluate({"user": v["user"], "item": v["item"]}, v["label"], batch_size=v["batch_size"], steps=self.validationSteps)
+        return {"result": "completed", "metrics": metrics}
+
+    def getPredictableUsers(self) -> list:
+        return list(self._users)
+
+    def predictForUser(self, customerId, numberOfItem=5):
+        """NeuMFModel.py:133-150: scores of the test-split products for one customer, best first
+        (the reference sorts the *string* scores; here the float scores)."""
+        items = np.asarray(self._products)
+        p = self.model.predict({"user": np.full(len(items), customerId), "item": items}).reshape(-1)
+        order = np.argsort(-p, kind="stable")[:numberOfItem]
+        return [(str(items[j]), str(p[j])) for j in order]
+
+
+class BPRModel(RModel):
+    """src/models/BPRModel.py: shared item embedding, triplet loss 1 - sigmoid(u.p - u.n), Adam(1e-3), batch 64."""
+
+    def __init__(self, device="cuda:0", max_batch=65536, optimizer="adam_dense"):
+        super().__init__("BPRModel", device)
+        self.max_batch, self.optimizer = max_batch, optimizer
+
+    def compileModel(self, distributedConfig, numUser: int, numItem: int, numFactor: int):
+        self.model = BPREngine(numUser, numItem, numFactor, self.device, self.max_batch, lr=1e-3, optimizer=self.optimizer)
+        return self.model, None        # the reference returns (model, strategy) (BPRModel.py:74)
+
+    def extractPositivesNegatives(self, trainDf, customerId, productIds):
+        """BPRModel.py:111-119: every (positive, non-interacted) pair of one customer."""
+        existing = trainDf[trainDf.CUSTOMER_ID == customerId].PRODUCT_ID.tolist()
+        ex = set(existing)
+        return [{"CUSTOMER_ID": customerId, "pPRODUCT_ID": p, "nPRODUCT_ID": n} for p in existing for n in productIds if n not in ex]
+
+    def fit(self, X: dict, y=None, batch_size=64, epochs=1, seed=0):
+        """model.fit({'customerId_input','pProduct_input','nProduct_input'}, ones, batch_size, epochs) (BPRModel.py:100-109)."""
+        e = self.model
+        u = _to_dev(X["customerId_input"], e.device, e.id_dtype).view(-1)
+        p = _to_dev(X["pProduct_input"], e.device, e.id_dtype).view(-1)
+        n = _to_dev(X["nProduct_input"], e.device, e.id_dtype).view(-1)
+        hist = History()
+        g = torch.Generator(device=e.device).manual_seed(seed)
+        for _ in range(epochs):
+            perm = torch.randperm(u.shape[0], device=e.device, generator=g)
+            uu, pp, nn = u[perm], p[perm], n[perm]
+            for s in range(0, u.shape[0], batch_size):
+                e.train_step(uu[s:s + batch_size], pp[s:s + batch_size], nn[s:s + batch_size])
+            e.check_ids()
+            hist.add({"loss": e.pop_loss()})
+        return hist
+
+
+class TwoTowerModel:
+    """trainers/twoTower.py:19-111 with the same constructor arguments."""
+
+    def __init__(self, embedDim, nbrItem, nbrUser, userKey, itemKey, usersId, itemsId, eval_batch_size=8000, loss=None,
+                 rdZero=False, resKey=None, semb=100, device="cuda:0", max_batch=65536, learningRate=0.1, optimiser="Adagrad"):
+        self.userKey, self.itemKey, self.resKey, self.rdZero, self.eval_batch_size = userKey, itemKey, resKey, rdZero, eval_batch_size
+        self.userTowerIn, self.itemTowerIn = StringLookup(usersId), StringLookup(itemsId)
+        self.engine = TwoTowerEngine(embedDim, nbrItem, nbrUser, semb, device, max_batch, lr=learningRate, optimizer=optimiser, rd_zero=rdZero)
+        self.device = self.engine.device
+        self._cand, self._cand_ids, self._k = None, None, None
+
+    def _ids(self, info):
+        return (self.userTowerIn(info[self.userKey], self.device), self.itemTowerIn(info[self.itemKey], self.device))
+
+    def computeEmb(self, info):
+        u, i = self._ids(info)
+        return self.engine.compute_emb(u, i, u.shape[0])
+
+    def train_step(self, info):
+        u, i = self._ids(info)
+        y = None if not self.rdZero else _to_dev(info[self.resKey], self.device, torch.float32)
+        self.engine.train_step(u, i, y)
+        return {"loss": None}     # read back with engine.pop_loss() (no per-step host sync)
+
+    def test_step(self, info):
+        u, i = self._ids(info)
+        self.engine.test_step(u, i)
+        return {"loss": None}
+
+    def fit(self, batches, epochs=1):
+        """model.fit(trainSetCached, epochs) (twoTower.py:214): `batches` = iterable of info dicts."""
+        hist = History()
+        for _ in range(epochs):
+            for info in batches:
+                self.train_step(info)
+            self.engine.check_ids()
+            hist.add({"loss": self.engine.pop_loss()})
+        return hist
+
+    def setCandidates(self, items, k):
+        """BruteForce(k).index(itemTower(items), identifiers=items) (twoTower.py:64-69)."""
+        self._cand_ids = list(items)
+        self._cand = self.engine.item_tower(self.itemTowerIn(self._cand_ids, self.device))
+        self._k = k
+
+    def call(self, users):
+        """userTower -> BruteForce top-k (twoTower.py:60-62) -> (scores (U,k), identifiers (U,k))."""
+        q = self.engine.user_tower(self.userTowerIn(users, self.device))
+        ts, ti = ops.topk_rows(ops.score_matrix(q, self._cand), self._k)
+        ids = np.asarray(self._cand_ids, dtype=object)[ti.cpu().numpy()]
+        return ts.cpu().numpy(), ids
+
+    predict = call
+
+    def topk(self, usersId, itemsId, k):
+        self.setCandidates(itemsId, k)
+        q = self.engine.user_tower(self.userTowerIn(usersId, self.device))
+        return ops.topk_rows(ops.score_matrix(q, self._cand), k)
