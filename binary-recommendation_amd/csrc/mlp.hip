@@ -19,6 +19,8 @@
 //             one slab per (workgroup, row group) -> fixed-order reduce (reproducible, no atomics).
 // Column statistics (BatchNorm sums) leave as double atomics into BR_STAT_REPLICAS replicas
 // (replica = workgroup % 8) so no address takes more than grid/8 serialised adds.
+#include <stdlib.h>
+
 #include "common.h"
 #include "philox.h"
 
@@ -522,73 +524,105 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------- head
 // concat [dot | a3] (mf_first) or [a3 | dot] -> Dense(1) -> sigmoid -> loss (+ grads)
+// One thread per pair; a wave's 64 rows of a3 / da3 are contiguous in memory (lda3 == N3), so they
+// move as coalesced flat chunks through a per-wave LDS patch instead of 40-B-strided accesses.
 __global__ __launch_bounds__(256) void neumf_head_kernel(const float* __restrict__ a3, int64_t lda3, const float* __restrict__ dot,
                                                           const float* __restrict__ labels, const float* __restrict__ w4,
                                                           const float* __restrict__ b4, int64_t batch, int N3, int mf_first, int loss,
                                                           float inv_batch, float* __restrict__ logit, float* __restrict__ prob,
                                                           double* __restrict__ sums, float* __restrict__ da3, int64_t ldda3,
                                                           float* __restrict__ ddot, float* __restrict__ slabs) {
-  // one thread per pair; N3 <= 32
+  __shared__ float patch[4][64 * 33];
   const int moff = mf_first ? 1 : 0;        // a3 weights start
   const float wdot = w4[mf_first ? 0 : N3];
   const float bias = b4[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* P = patch[wave];
+  const int ldp = N3 | 1;                   // odd row stride: conflict-free row reads
   float gw[33];
 #pragma unroll
   for (int i = 0; i < 33; ++i) gw[i] = 0.f;
   float gb = 0.f;
   double s_loss = 0.0, s_se = 0.0, s_ae = 0.0, s_ok = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += stride) {
+  const bool flat_in = lda3 == N3, flat_out = da3 && ldda3 == N3;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4 * 64;
+  for (int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * 64; b0 < batch; b0 += wave_stride) {
+    const int64_t b = b0 + lane;
+    const int nrow = (int)((batch - b0) < 64 ? (batch - b0) : 64);
+    // stage the wave's rows of a3
+    if (flat_in) {
+      for (int e = lane; e < nrow * N3; e += 64) { const int r = e / N3; P[r * ldp + (e - r * N3)] = a3[b0 * N3 + e]; }
+    } else if (b < batch) {
+      for (int i = 0; i < N3; ++i) P[lane * ldp + i] = a3[b * lda3 + i];
+    }
+    __builtin_amdgcn_wave_barrier();
     float av[32];
-    const float d = dot[b];
-    float z = bias + d * wdot;
+    float z = bias, d = 0.f;
+    if (b < batch) {
+      d = dot[b];
+      z += d * wdot;
 #pragma unroll
-    for (int i = 0; i < 32; ++i)
-      if (i < N3) { av[i] = a3[b * lda3 + i]; z += av[i] * w4[moff + i]; }
+      for (int i = 0; i < 32; ++i)
+        if (i < N3) { av[i] = P[lane * ldp + i]; z += av[i] * w4[moff + i]; }
+    }
     const float p = sigmoidf_acc(z);
-    if (logit) logit[b] = z;
-    if (prob) prob[b] = p;
-    if (labels) {
-      const float yv = labels[b];
-      float l, dz;
-      if (loss == BR_LOSS_BCE) {
-        l = fmaxf(z, 0.f) - z * yv + log1pf(expf(-fabsf(z)));
-        dz = (p - yv) * inv_batch;
-      } else {
-        l = (p - yv) * (p - yv);
-        dz = 2.f * (p - yv) * p * (1.f - p) * inv_batch;
+    float dz = 0.f;
+    if (b < batch) {
+      if (logit) logit[b] = z;
+      if (prob) prob[b] = p;
+      if (labels) {
+        const float yv = labels[b];
+        float l;
+        if (loss == BR_LOSS_BCE) {
+          l = fmaxf(z, 0.f) - z * yv + log1pf(expf(-fabsf(z)));
+          dz = (p - yv) * inv_batch;
+        } else {
+          l = (p - yv) * (p - yv);
+          dz = 2.f * (p - yv) * p * (1.f - p) * inv_batch;
+        }
+        s_loss += (double)l;
+        s_se += (double)((p - yv) * (p - yv));
+        s_ae += (double)fabsf(p - yv);
+        s_ok += ((p > 0.5f) == (yv > 0.5f)) ? 1.0 : 0.0;
       }
-      s_loss += (double)l;
-      s_se += (double)((p - yv) * (p - yv));
-      s_ae += (double)fabsf(p - yv);
-      s_ok += ((p > 0.5f) == (yv > 0.5f)) ? 1.0 : 0.0;
-      if (da3) {
+    }
+    if (da3 && labels) {
+      __builtin_amdgcn_wave_barrier();
+      if (b < batch) {
 #pragma unroll
         for (int i = 0; i < 32; ++i)
-          if (i < N3) { da3[b * ldda3 + i] = dz * w4[moff + i]; gw[i] += dz * av[i]; }
+          if (i < N3) { const float gv = dz * w4[moff + i]; gw[i] += dz * av[i]; if (flat_out) P[lane * ldp + i] = gv; else da3[b * ldda3 + i] = gv; }
         ddot[b] = dz * wdot;
         gw[32] += dz * d;
         gb += dz;
       }
+      __builtin_amdgcn_wave_barrier();
+      if (flat_out)
+        for (int e = lane; e < nrow * N3; e += 64) { const int r = e / N3; da3[b0 * N3 + e] = P[r * ldp + (e - r * N3)]; }
     }
+    __builtin_amdgcn_wave_barrier();
   }
   if (!labels) return;
   __shared__ double redd[4][4];
   __shared__ float redf[4][34];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   s_loss = wave_sum_d(s_loss); s_se = wave_sum_d(s_se); s_ae = wave_sum_d(s_ae); s_ok = wave_sum_d(s_ok);
   if (lane == 0) { redd[wave][0] = s_loss; redd[wave][1] = s_se; redd[wave][2] = s_ae; redd[wave][3] = s_ok; }
   if (da3) {
 #pragma unroll
     for (int i = 0; i < 33; ++i) {
-      const float v = group_sum<64>(gw[i]);
-      if (lane == 0) redf[wave][i] = v;
+      if (i < N3 || i == 32) {
+        const float v = group_sum<64>(gw[i]);
+        if (lane == 0) redf[wave][i] = v;
+      }
     }
     const float v = group_sum<64>(gb);
     if (lane == 0) redf[wave][33] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 4 && sums) atomicAdd(sums + threadIdx.x, redd[0][threadIdx.x] + redd[1][threadIdx.x] + redd[2][threadIdx.x] + redd[3][threadIdx.x]);
+  // 4 metric sums per slot, slot = workgroup & 63: same-line double atomics serialise (~12 ns each)
+  if (threadIdx.x < 4 && sums)
+    atomicAdd(sums + (size_t)(blockIdx.x & (BR_SUM_SLOTS - 1)) * 4 + threadIdx.x,
+              redd[0][threadIdx.x] + redd[1][threadIdx.x] + redd[2][threadIdx.x] + redd[3][threadIdx.x]);
   if (da3 && slabs) {
     // slab layout [dW4 (N3+1, concat order) | db4]
     float* slab = slabs + (int64_t)blockIdx.x * (N3 + 2);

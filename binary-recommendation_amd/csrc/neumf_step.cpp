@@ -57,6 +57,16 @@ extern "C" int brProbeRead(int i, int* tag, float* ms) {
     if (rc_ != BR_OK) return rc_;  \
   } while (0)
 
+// fork/join events of the optional aux stream (created once, on first use)
+namespace {
+hipEvent_t g_fork = nullptr, g_join = nullptr;
+bool ensure_events() {
+  if (g_fork) return true;
+  return hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&g_join, hipEventDisableTiming) == hipSuccess;
+}
+}  // namespace
+
 extern "C" int64_t brNeumfStepSizeof(void) { return (int64_t)sizeof(brNeumfStep); }
 
 extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream) {
@@ -94,6 +104,18 @@ extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream
   double *stats1 = s->dstat, *stats2 = stats1 + R * 2 * n1, *bsum1 = stats2 + R * 2 * n2, *bsum2 = bsum1 + R * 2 * n1;
   float *mm1 = s->moving, *mv1 = mm1 + n1, *mm2 = mv1 + n1, *mv2 = mm2 + n2;
   const int uoff = s->item_first ? D : 0, ioff = s->item_first ? 0 : D;
+  // dedup sorts on the aux stream: forked at the top of the step, joined before the Adam-rows kernels
+  const bool aux_index = train && s->aux_stream && (ph & BR_PH_FWD1) && (ph & BR_PH_OPT_TABLES) && (ph & BR_PH_EMBED);
+  if (aux_index) {
+    if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
+    hipStream_t as = (hipStream_t)s->aux_stream;
+    (void)hipEventRecord(g_fork, hs);                 // previous step's readers of the index buffers are done
+    (void)hipStreamWaitEvent(as, g_fork, 0);
+    int rc = brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, s->aux_stream);
+    if (rc == BR_OK) rc = brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, s->aux_stream);
+    if (rc != BR_OK) return rc;
+    (void)hipEventRecord(g_join, as);
+  }
   if (ph & BR_PH_FWD1) {
     if (train) {
       hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(BR_STAT_REPLICAS * (4 * n1 + 4 * n2)), hs);
@@ -155,8 +177,12 @@ extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream
     if (ph & BR_PH_EMBED)
       RUN(BR_TAG_EMBED_BWD, brNeumfEmbedBackward(s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows, s->users, s->items, s->id_type, D,
                                B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, stream));
-    RUN(BR_TAG_INDEX_USER, brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, stream));
-    RUN(BR_TAG_INDEX_ITEM, brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, stream));
+    if (aux_index) {
+      (void)hipStreamWaitEvent(hs, g_join, 0);
+    } else {
+      RUN(BR_TAG_INDEX_USER, brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, stream));
+      RUN(BR_TAG_INDEX_ITEM, brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, stream));
+    }
     uint8_t* um = s->adam_dense ? s->user_mark : nullptr;
     uint8_t* im = s->adam_dense ? s->item_mark : nullptr;
     RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSorted(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type, s->u_sorted_pos, B,

@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes
 import dataclasses
 import math
+import os
 
 import torch
 
@@ -169,7 +170,7 @@ class NeuMFEngine:
         self.stats2 = self.dstat[o:o + R * 2 * n2]; o += R * 2 * n2
         self.bsum1 = self.dstat[o:o + R * 2 * n1]; o += R * 2 * n1
         self.bsum2 = self.dstat[o:o + R * 2 * n2]
-        self.msums = torch.zeros(4, dtype=torch.float64, device=dev)   # loss, se, ae, correct (epoch)
+        self.msums = torch.zeros(ops.SUM_SLOTS, 4, dtype=torch.float64, device=dev)   # [slot][loss, se, ae, correct] (epoch)
         self.bn_buf = f(4 * n1 + 4 * n2)      # [scale1|shift1|mean1|rstd1|scale2|shift2|mean2|rstd2]
         self.bn, o = {}, 0
         for k, n in (("scale1", n1), ("shift1", n1), ("mean1", n1), ("rstd1", n1), ("scale2", n2), ("shift2", n2), ("mean2", n2), ("rstd2", n2)):
@@ -214,6 +215,9 @@ class NeuMFEngine:
         st.bn, st.dstat, st.msums = P(self.bn_buf), P(self.dstat), P(self.msums)
         st.slabs, st.hslabs, st.err_flag = P(self.slabs), P(self.hslabs), P(self.err)
         self._bind_indexes(st)
+        if not self.sharded and os.environ.get("BR_AUX_STREAM", "1") != "0":
+            self.aux_stream = torch.cuda.Stream(device=self.device)     # the dedup sorts run beside fwd/bwd
+            st.aux_stream = self.aux_stream.cuda_stream
         self.step_struct = st
         self.PH = {k[6:]: v for k, v in _lib.parse_enums().items() if k.startswith("BR_PH_")}
 
@@ -360,7 +364,7 @@ class NeuMFEngine:
 
     def pop_metrics(self, n_samples: int) -> dict:
         """Host sync: mean loss / mse / mae / binary_accuracy since the last call (RModel.py:20)."""
-        s = self.msums.cpu().tolist()
+        s = self.msums.sum(dim=0).cpu().tolist()
         self.msums.zero_()
         n = max(1, n_samples)
         return {"loss": s[0] / n, "mse": s[1] / n, "mae": s[2] / n, "binary_accuracy": s[3] / n}

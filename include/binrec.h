@@ -196,7 +196,8 @@ int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* ou
 /* ---- head: concat [GMF dot | MLP out] -> Dense(1) -> sigmoid -> loss, and its backward --------
  * NFC_plain.py:149-155 (mf_first=1, BCE) / NeuMFModel.py:80-91 (mf_first=0, MSE).
  * a3: (B x N3); dot: (B); w4: (N3+1) in concat order; b4: (1).  Outputs: logit, prob (B);
- * sums (double[4]) += [loss, sum (p-y)^2, sum |p-y|, #correct@0.5]; when labels && training:
+ * sums (double[BR_SUM_SLOTS][4], slot = workgroup & 63) += [loss, sum (p-y)^2, sum |p-y|,
+ * #correct@0.5] (the caller adds the slots); when labels && training:
  * da3 (B x N3), ddot (B), head_slabs (n_slabs x (N3+2)) partials of [dW4 | db4].
  * inv_batch = 1/global batch. */
 int brHeadSlabs(int64_t batch);
@@ -275,11 +276,14 @@ typedef struct brNeumfStep {
   float* da3; float* ddot; float* gh2; float* gh1; float* dx0; float* g_user; float* g_item;
   float* bn;                               /* [scale1|shift1|mean1|rstd1] n1 each, then the same for layer 2 */
   double* dstat;                           /* [stats1 | stats2 | bsum1 | bsum2], each [BR_STAT_REPLICAS][2n]; zeroed in FWD1 */
-  double* msums;                           /* [loss, sum sq err, sum abs err, #correct] accumulated */
+  double* msums;                           /* [BR_SUM_SLOTS][loss, sum sq err, sum abs err, #correct] accumulated */
   float* slabs; float* hslabs;
   int* err_flag;
   void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;
   void* i_sorted_ids; int32_t* i_sorted_pos; void* i_ws; int64_t i_ws_bytes;
+  void* aux_stream;   /* optional second hipStream_t: the two dedup sorts depend only on the ids, so with
+                         BR_PH_FWD1|BR_PH_OPT_TABLES in one call they run here beside the forward/backward
+                         and are joined (event) before the Adam-rows kernels; NULL = same stream */
 } brNeumfStep;
 int64_t brNeumfStepSizeof(void);
 int brNeumfStepRun(const brNeumfStep* s, uint32_t phases, brStream stream);
