@@ -1,24 +1,26 @@
 // T1-T4 + B1: the MLP tower on fp32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 fma chains, the
 // only MFMA form that meets the 1e-5 logit/loss tolerance; 157 TFLOP/s peak on MI355X).
 //
-// Structure (both kernels): 512-thread workgroups (8 waves), TWO resident per CU (4 waves per SIMD,
-// <= 128 VGPRs) so one workgroup's load / epilogue phases overlap the other's MFMA phase — a single
-// barrier-synchronised workgroup per CU left the matrix pipe idle 2/3 of the time (rocprofv3 PMC:
-// SQ_VALU_MFMA_BUSY_CYCLES = 32 % of the kernel, round-1 profile).
-//   * W never goes through LDS: every wave keeps the <= 32 fragment registers of the 16 weight
-//     columns (forward: n-tile, backward: k-tile) it owns for the whole launch.
-//   * One LDS image of the current batch tile; the raw global loads of tile t+1 are issued before
-//     the MFMA phase of tile t and wait in registers (global -> reg -> LDS staging); BatchNorm-affine
-//     + Philox dropout are applied on the way in.
-//   * K is contracted in a lane-permuted order (lane group g = lane>>4 owns k = 16j+4g..+3) so one
-//     ds_read_b128 feeds four MFMA k-steps; A and B use the same permutation.
-//   forward : wave (n-tile nt, row group) : y[rows][16 cols] = act(T(x)·W + b) ; BN column sums.
-//   backward: dz = act'(y)·BN-backward(gy) elementwise into LDS; wave (k-tile kt, row group):
-//             dx[rows][16 cols of kt] = dz·W^T  and  dW[16 rows of kt][N] += T(x)^T·dz from the
-//             same LDS tiles; dW/db live in registers across the workgroup's tiles and leave as
-//             one slab per (workgroup, row group) -> fixed-order reduce (reproducible, no atomics).
-// Column statistics (BatchNorm sums) leave as double atomics into BR_STAT_REPLICAS replicas
-// (replica = workgroup % 8) so no address takes more than grid/8 serialised adds.
+// forward (dense_fwd_kernel) and backward-dx (dense_dx_kernel): one 512-thread workgroup per CU.
+//   * The layer's W is staged ONCE into LDS (forward: pre-swizzled [j][g][n][s] so a lane's four
+//     k-steps are one conflict-free ds_read_b128; dx: row-major, read along n as ds_read_b128).
+//   * After that single barrier every wave is independent: it walks its own 16-row tiles, loads the A
+//     fragments STRAIGHT from global memory in the MFMA lane layout (lane (c16,g) <- 16 B of row c16 at
+//     k = 16j+4g; K is contracted in that lane-permuted order), with branch-free guarded loads and the
+//     next tile's loads in flight during the current tile's MFMAs.
+//   * BatchNorm-affine + Philox dropout are applied in registers (keep-bytes of the 16 x K tile in a
+//     per-wave LDS patch: <= 4 Philox calls per lane per tile, reused by the dx epilogue).
+//   * MFMA in passes of <= 4 (dx: 2) output tiles: independent accumulator chains, B fragments of the
+//     next k-step read from LDS while the current one is in the matrix pipe.
+//   * A wave owns whole output rows, so they leave as back-to-back pieces of the same 128-B lines.
+//   * dx also forms dz = act'(y)·BN-backward(gy) in registers and hands it to the dW kernel via HBM.
+// backward-dW (dense_dw_kernel): a skinny split-K GEMM over the batch; wave (k-tile, row group) keeps its
+//   dW strip in registers across the workgroup's row range -> one slab per (workgroup, row group) ->
+//   fixed-order reduce (reproducible, no float atomics).
+// Column statistics (BatchNorm sums) leave as double atomics into BR_STAT_REPLICAS replicas.
+// Round-1 measurement (tools/mlp_bench.py, 128 x 100 layer, batch 65 536, MI355X): the MFMA passes run
+// at the fp32-MFMA rate (14.4 us vs 13.6 us ideal) but the A loads (7 us), W staging (3 us) and stores
+// (4 us) of this one-generation launch (2 tiles per wave) are not hidden behind them: 32 us = 25 % of peak.
 #include <stdlib.h>
 
 #include "common.h"
@@ -30,12 +32,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kThreads = 512;
 constexpr int kMaxT = 8;         // max 16-wide tiles along K or N (=> K,N <= 128)
-constexpr int kMaxGrid = 512;    // two workgroups per CU
+constexpr int kMaxGrid = 256;    // one 8-wave workgroup per CU, each wave walks several 16-row tiles
 constexpr int kRep = BR_STAT_REPLICAS;
-
-// rows per tile: every one of the 8 waves must own at least one 16-row tile
-__host__ __device__ constexpr int fwd_tm(int ntp) { return 16 * ((8 / ntp) > 4 ? (8 / ntp) : 4); }   // 64 (128 when N <= 16)
-__host__ __device__ constexpr int bwd_tm(int ktp) { return 16 * ((8 / ktp) > 2 ? (8 / ktp) : 2); }   // 32 (64 / 128 for K <= 32 / 16)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -47,21 +45,37 @@ struct InXform {       // T(x): BatchNorm affine of the producer + dropout, appl
   DropoutCfg drop;
 };
 
-// 8 consecutive floats of row gr starting at column c (zeros outside [0,K) x [0,batch))
-__device__ __forceinline__ void load8(float (&v)[8], const float* __restrict__ base, int64_t ld, int64_t gr, int64_t batch,
-                                      int c, int K, bool vec_ok) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = 0.f;
-  if (gr >= batch || c >= K) return;
-  const float* src = base + gr * ld + c;
-  if (vec_ok && c + 7 < K) {
-    const float4 a = *reinterpret_cast<const float4*>(src);
-    const float4 b = *reinterpret_cast<const float4*>(src + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+// Branch-free guarded loads.  Every load below is issued UNCONDITIONALLY from an address clamped
+// into the buffer and the out-of-range lanes are zeroed with selects: an `if (in range) load` makes
+// hipcc put each load in its own exec-masked block followed by s_waitcnt vmcnt(0), which serialises
+// the loads of a tile at one HBM latency each (measured: 9.5 us of a 31 us forward kernel).
+// vec = wave-uniform: row stride % 4 == 0, K % 4 == 0, base 16-B aligned.
+// VEC is a template parameter and callers branch on the wave-uniform flag ONCE around their whole load
+// loop, so all loads of a tile sit in one basic block (one wait at first use, not one per load).
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_guard(const float* __restrict__ base, int64_t ld, int64_t row, int64_t nrows, int k, int K) {
+  const bool rin = row < nrows;
+  const int64_t r = rin ? row : nrows - 1;
+  float4 v;
+  if (VEC) {
+    const bool ok = rin && k < K;
+    const float4 t = *reinterpret_cast<const float4*>(base + r * ld + (k < K ? k : 0));
+    v = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
   } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (c + i < K) v[i] = src[i];
+    const float* p = base + r * ld;
+    const float t0 = p[k + 0 < K ? k + 0 : K - 1], t1 = p[k + 1 < K ? k + 1 : K - 1];
+    const float t2 = p[k + 2 < K ? k + 2 : K - 1], t3 = p[k + 3 < K ? k + 3 : K - 1];
+    v = make_float4((rin && k + 0 < K) ? t0 : 0.f, (rin && k + 1 < K) ? t1 : 0.f, (rin && k + 2 < K) ? t2 : 0.f, (rin && k + 3 < K) ? t3 : 0.f);
   }
+  return v;
+}
+
+// 8 consecutive floats of row gr starting at column c (zeros outside [0,K) x [0,batch))
+template <bool VEC>
+__device__ __forceinline__ void load8(float (&v)[8], const float* __restrict__ base, int64_t ld, int64_t gr, int64_t batch, int c, int K) {
+  const float4 a = ld4_guard<VEC>(base, ld, gr, batch, c, K);
+  const float4 b = ld4_guard<VEC>(base, ld, gr, batch, c + 4, K);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
 // T(): BN affine + dropout on one 8-column chunk; returns the keep bits
@@ -89,126 +103,172 @@ __device__ __forceinline__ void store8_lds(float* dst, const float (&v)[8]) {
 }
 
 // ------------------------------------------------------------------------------------ forward
-// NTP = n-tiles covered by the 8 waves (1,2,4,8): wave -> (n-tile = wave % NTP, row group = wave / NTP)
-// KJ  = K tiles of 16 (compile-time so the k-loop has no branches and LDS reads hoist freely)
-template <int NTP, int KJ>
-__global__ __launch_bounds__(kThreads, 4) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
+// Every wave is independent (no barrier after the W image is staged): it walks its own 16-row tiles,
+// loads the A fragments STRAIGHT from global memory in the MFMA lane layout (lane (c16,g) <- 16 B of
+// row c16 at k = 16j+4g), applies BN-affine + dropout in registers, and contracts against the W image
+// in LDS, stored pre-swizzled [j][g][n][s] so one conflict-free ds_read_b128 yields the four k-steps
+// of a lane.  One wave owns all n-tiles of its rows, so a row's outputs leave as back-to-back 64-B
+// pieces of the same 128-B lines (no partial-line write amplification between waves).
+// Per-wave scratch in LDS: dropout keep-bytes [16 rows][2*KJ] (4 Philox calls per lane per tile).
+template <int NT, int KJ>
+__global__ __launch_bounds__(kThreads, 2) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
                                                                  const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
                                                                  int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
                                                                  double* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int RGN = 8 / NTP;            // row groups
-  constexpr int TM = fwd_tm(NTP);         // rows per tile
-  constexpr int RT = TM / 16 / RGN;       // row tiles per wave (4, 2, 1, 1)
-  constexpr int Kp = KJ * 16, ldx = Kp + 4;
-  constexpr int CPR = Kp / 8;             // 8-float chunks per row
-  constexpr int MAXC = (TM * CPR + kThreads - 1) / kThreads;
-  float* Xs = smem;
-  float* ssb = smem + TM * ldx;           // [scale Kp | shift Kp]
-  const float* ss = tin.scale ? ssb : nullptr;
+  constexpr int Np = NT * 16, Kp = KJ * 16, NCH = 2 * KJ;
+  float* Ws = smem;                                   // [KJ][4][Np][4]
+  float* ssb = Ws + Kp * Np;                          // [scale Kp | shift Kp]
+  uint8_t* mk_all = reinterpret_cast<uint8_t*>(ssb + 2 * Kp);   // [8 waves][16][NCH]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  uint8_t* mk = mk_all + wave * 16 * NCH;
+  const bool vec_ok = (ldx_g % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const int64_t n_tiles = (batch + 15) >> 4;
+  const int64_t tstride = (int64_t)gridDim.x * 8;
+
+  // A fragments of one 16-row tile straight from global: lane (c16,g) <- 16 B of row c16 at k = 16j+4g
+  // (tiles past the end read row batch-1 and are zeroed: no branch around the loads)
+  auto load_a = [&](float4 (&a)[KJ], int64_t tile) {
+    const int64_t arow = tile < n_tiles ? (tile << 4) + c16 : batch;
+    if (vec_ok) {
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) a[j] = ld4_guard<true>(x, ldx_g, arow, batch, 16 * j + 4 * g, K);
+    } else {
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) a[j] = ld4_guard<false>(x, ldx_g, arow, batch, 16 * j + 4 * g, K);
+    }
+  };
+
+  int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  float4 a[KJ], an[KJ];
+  load_a(a, tile);                                    // first tile's loads fly while W is staged
+
+  // W image: thread -> (j, g, n): 4 coalesced loads (k = 16j+4g+s) -> one conflict-free ds_write_b128
+  for (int idx = threadIdx.x; idx < KJ * 4 * Np; idx += kThreads) {
+    const int jg = idx / Np, n = idx - jg * Np;
+    const int k0 = 4 * jg;
+    const int nc = n < N ? n : N - 1;
+    const float t0 = W[(k0 + 0 < K ? k0 + 0 : K - 1) * N + nc], t1 = W[(k0 + 1 < K ? k0 + 1 : K - 1) * N + nc];
+    const float t2 = W[(k0 + 2 < K ? k0 + 2 : K - 1) * N + nc], t3 = W[(k0 + 3 < K ? k0 + 3 : K - 1) * N + nc];
+    const bool nin = n < N;
+    *reinterpret_cast<float4*>(Ws + (jg * Np + n) * 4) =
+        make_float4((nin && k0 + 0 < K) ? t0 : 0.f, (nin && k0 + 1 < K) ? t1 : 0.f, (nin && k0 + 2 < K) ? t2 : 0.f, (nin && k0 + 3 < K) ? t3 : 0.f);
+  }
   if (tin.scale)
-    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+    for (int k = threadIdx.x; k < Kp; k += kThreads) {
       ssb[k] = k < K ? tin.scale[k] : 0.f;
       ssb[Kp + k] = k < K ? tin.shift[k] : 0.f;
     }
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c16 = lane & 15, g = lane >> 4;
-  const int nt = wave % NTP, rgp = wave / NTP;
-  const int ncol = nt * 16 + c16;
-  const bool vec_ok = (ldx_g % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-
-  // this wave's W fragments: bw[4j+s] = W[16j+4g+s][ncol]
-  float bw[4 * KJ];
-#pragma unroll
-  for (int j = 0; j < KJ; ++j)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k = 16 * j + 4 * g + s;
-      bw[4 * j + s] = (k < K && ncol < N) ? W[k * N + ncol] : 0.f;
-    }
-  const float bcol = (bias && ncol < N) ? bias[ncol] : 0.f;
-  float ssum = 0.f, ssq = 0.f;
-
-  float pre[MAXC][8];
-  const int64_t n_tiles = (batch + TM - 1) / TM;
-
-  auto load_tile = [&](int64_t tile) {
-    const int64_t row_base = tile * TM;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int idx = threadIdx.x + kThreads * i;
-      if (idx < TM * CPR) {
-        const int r = idx / CPR, c = (idx - r * CPR) << 3;
-        load8(pre[i], x, ldx_g, row_base + r, batch, c, K, vec_ok);
-      }
-    }
-  };
-  auto write_tile = [&](int64_t tile) {
-    const int64_t row_base = tile * TM;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int idx = threadIdx.x + kThreads * i;
-      if (idx < TM * CPR) {
-        const int r = idx / CPR, c = (idx - r * CPR) << 3;
-        xform8(pre[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
-        store8_lds(Xs + r * ldx + c, pre[i]);
-      }
-    }
-  };
-
-  int64_t tile = blockIdx.x;
-  if (tile < n_tiles) load_tile(tile);
-  __syncthreads();                 // scale|shift staged
-  if (tile < n_tiles) write_tile(tile);
   __syncthreads();
-  while (tile < n_tiles) {
-    const int64_t next = tile + gridDim.x;
-    if (next < n_tiles) load_tile(next);
-    // ---- MFMA: RT row tiles (independent accumulator chains) x this wave's n-tile ----
-    const int64_t row_base = tile * TM;
-    f32x4 acc[RT];
+
+  float bcol[NT], ssum[NT], ssq[NT];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + c16;
+    bcol[nt] = (bias && n < N) ? bias[n] : 0.f;
+    ssum[nt] = 0.f; ssq[nt] = 0.f;
+  }
+  for (; tile < n_tiles; tile += tstride) {
+    const int64_t rbase = tile << 4;
+    const int64_t arow = rbase + c16;                  // the row this lane feeds as the A operand
+    load_a(an, tile + tstride);                        // next tile's A in flight during this tile's MFMAs
+    // ---- dropout keep-bytes of the tile: 16 rows x NCH chunks, <= 4 Philox calls per lane ----
+    if (tin.drop.thr) {
+#pragma unroll
+      for (int i = 0; i < (16 * NCH + 63) / 64; ++i) {
+        const int q = lane + 64 * i;
+        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- T(): BN affine + dropout, in registers ----
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const float4 a4 = *reinterpret_cast<const float4*>(Xs + ((rgp + RGN * i) * 16 + c16) * ldx + 16 * j + 4 * g);
-        acc[i] = mfma16(a4.x, bw[4 * j + 0], acc[i]);
-        acc[i] = mfma16(a4.y, bw[4 * j + 1], acc[i]);
-        acc[i] = mfma16(a4.z, bw[4 * j + 2], acc[i]);
-        acc[i] = mfma16(a4.w, bw[4 * j + 3], acc[i]);
+      const int k = 16 * j + 4 * g;
+      if (tin.scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(ssb + k), sh = *reinterpret_cast<const float4*>(ssb + Kp + k);
+        a[j].x = a[j].x * sc.x + sh.x; a[j].y = a[j].y * sc.y + sh.y; a[j].z = a[j].z * sc.z + sh.z; a[j].w = a[j].w * sc.w + sh.w;
       }
+      if (tin.drop.thr) {
+        const uint32_t bits = (uint32_t)mk[c16 * NCH + (k >> 3)] >> (k & 4);
+        const float ik = tin.drop.inv_keep;
+        a[j].x = (bits & 1u) ? a[j].x * ik : 0.f; a[j].y = (bits & 2u) ? a[j].y * ik : 0.f;
+        a[j].z = (bits & 4u) ? a[j].z * ik : 0.f; a[j].w = (bits & 8u) ? a[j].w * ik : 0.f;
+      }
+      if (arow >= batch) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // ---- epilogue: lane holds rows 4g..4g+3 of each of its row tiles, column ncol ----
+    // ---- MFMA in passes of <= 4 n-tiles: the pass's accumulators are independent chains (s outer,
+    //      n-tile inner => a chain is revisited every >= 3 MFMAs), and the B fragments of k-step j+1
+    //      are read from LDS while step j is in the matrix pipe (explicit double buffer: with the
+    //      128-VGPR budget hipcc otherwise issues read -> wait -> 4 dependent MFMAs) ----
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const int rt = rgp + RGN * i;
+    for (int nt0 = 0; nt0 < NT; nt0 += 4) {
+      constexpr int WMAX = 4;
+      const int Wn = (NT - nt0) < WMAX ? (NT - nt0) : WMAX;     // compile-time after unrolling
+      f32x4 acc[WMAX];
+      float4 bc[WMAX], bn[WMAX];
+#pragma unroll
+      for (int w = 0; w < WMAX; ++w) {
+        acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (w < Wn) bc[w] = *reinterpret_cast<const float4*>(Ws + ((0 * 4 + g) * Np + c16) * 4 + (nt0 + w) * 64);
+      }
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        if (j + 1 < KJ) {
+#pragma unroll
+          for (int w = 0; w < WMAX; ++w)
+            if (w < Wn) bn[w] = *reinterpret_cast<const float4*>(Ws + (((j + 1) * 4 + g) * Np + c16) * 4 + (nt0 + w) * 64);
+        }
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].x, bc[w].x, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].y, bc[w].y, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].z, bc[w].z, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].w, bc[w].w, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) bc[w] = bn[w];
+      }
+      // epilogue of the pass: lane holds rows 4g..4g+3, column (nt0+w)*16+c16
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t gr = row_base + rt * 16 + 4 * g + r;
-        const float v = act_apply(acc[i][r] + bcol, act);
-        if (gr < batch && ncol < N) {
-          y[gr * ldy + ncol] = v;
-          ssum += v;
-          ssq += v * v;
+        const int64_t gr = rbase + 4 * g + r;
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) {
+          if (w < Wn) {
+            const int n = (nt0 + w) * 16 + c16;
+            const float v = act_apply(acc[w][r] + bcol[nt0 + w], act);
+            if (gr < batch && n < N) {
+              y[gr * ldy + n] = v;
+              ssum[nt0 + w] += v;
+              ssq[nt0 + w] += v * v;
+            }
+          }
         }
       }
     }
-    __syncthreads();               // everyone done reading the LDS image
-    if (next < n_tiles) write_tile(next);
-    __syncthreads();
-    tile = next;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) a[j] = an[j];
   }
   if (stats) {
-    double s = (double)ssum, q = (double)ssq;
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-    if (g == 0 && ncol < N) {
-      double* rep = stats + (size_t)(blockIdx.x % kRep) * 2 * N;
-      atomicAdd(rep + ncol, s);
-      atomicAdd(rep + N + ncol, q);
+    // wave -> workgroup (LDS double atomics) -> one global atomic per column and workgroup
+    __shared__ double red[2][kMaxT * 16];
+    for (int n = threadIdx.x; n < 2 * kMaxT * 16; n += kThreads) (&red[0][0])[n] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      double sv = (double)ssum[nt], q = (double)ssq[nt];
+      sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (g == 0) { atomicAdd(&red[0][nt * 16 + c16], sv); atomicAdd(&red[1][nt * 16 + c16], q); }
+    }
+    __syncthreads();
+    double* rep = stats + (size_t)(blockIdx.x % kRep) * 2 * N;
+    for (int n = threadIdx.x; n < N; n += kThreads) {
+      atomicAdd(rep + n, red[0][n]);
+      atomicAdd(rep + N + n, red[1][n]);
     }
   }
 }
@@ -269,42 +329,33 @@ struct InBn {                // BN carried by the input (for the producer's back
   const float* rstd;
 };
 
-// NT = n-tiles (1..8); KTP = pow2 >= number of k-tiles: wave -> (k-tile = wave % KTP, row group = wave / KTP)
-template <int NT, int KTP>
-__global__ __launch_bounds__(kThreads, 4) void dense_bwd_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
-                                                                 const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
-                                                                 int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
-                                                                 int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ slabs,
-                                                                 double* __restrict__ in_sums) {
+// ---- backward, part 1: dz and dx -------------------------------------------------------------
+// Same skeleton as the forward: independent waves over 16-row tiles.  The A fragments are dz, formed
+// in registers straight from gy / y (BN-backward constants from LDS); dz is also written out
+// ([batch][Np], zero padded) for the dW kernel.  dx = dz·W^T against the row-major W image in LDS
+// (lane (c16,g) reads W[kt*16+c16][16j+4g..+3] as one ds_read_b128).  Epilogue: dropout transposed
+// (keep-bytes in the per-wave LDS patch), gx stored, BN-backward sums of the producer accumulated.
+template <int NT, int KT>
+__global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
+                                                                int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
+                                                                int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ dzbuf,
+                                                                double* __restrict__ in_sums) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int Np = NT * 16, ldz = Np + 4;
-  constexpr int RGN = 8 / KTP;                      // row groups
-  constexpr int TM = bwd_tm(KTP);                   // rows per tile
-  constexpr int RT = TM / 16 / RGN;                 // row tiles per wave (2, 1, 1, 1)
-  const int KT = (K + 15) >> 4, Kp = KT << 4, ldx = Kp + 4;
-  const int mkld = Kp >> 3;                         // mask bytes per row
-  float* Xs = smem;                                 // [TM][ldx]   T(x)
-  float* Zs = Xs + TM * ldx;                        // [TM][ldz]   dz
-  uint8_t* Mk = reinterpret_cast<uint8_t*>(Zs + TM * ldz);   // [TM][mkld] dropout keep bits
-  float* Cs = Zs + TM * ldz + ((TM * mkld + 3) >> 2);        // [4][Np] per-column constants of the out BN
-  float* ssb = Cs + 4 * Np;                         // [scale Kp | shift Kp] of the in transform
-  const float* ss = tin.scale ? ssb : nullptr;
-  if (tin.scale)
-    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
-      ssb[k] = k < K ? tin.scale[k] : 0.f;
-      ssb[Kp + k] = k < K ? tin.shift[k] : 0.f;
-    }
-
+  constexpr int Np = NT * 16, Kp = KT * 16, ldw = Np + 4, NCH = 2 * KT;
+  float* Ws = smem;                                   // [Kp][ldw] row-major W
+  float* Cs = Ws + Kp * ldw;                          // [4][Np] out-BN constants
+  float* Is = Cs + 4 * Np;                            // [mean Kp | rstd Kp] of the in BN
+  uint8_t* mk_all = reinterpret_cast<uint8_t*>(Is + 2 * Kp);   // [8 waves][16][NCH]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
-  const int kt = wave % KTP, rg = wave / KTP;
-  const bool kt_live = kt < KT;
-  const int kcol = kt * 16 + c16;
-  const bool xvec = (ldx_g % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  const bool gvec = (ldgy % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
-  const bool yvec = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  uint8_t* mk = mk_all + wave * 16 * NCH;
 
-  for (int n = threadIdx.x; n < Np; n += blockDim.x) {
+  for (int k = threadIdx.x; k < Kp; k += kThreads) {
+    Is[k] = (ibn.mean && k < K) ? ibn.mean[k] : 0.f;
+    Is[Kp + k] = (ibn.mean && k < K) ? ibn.rstd[k] : 0.f;
+  }
+  for (int n = threadIdx.x; n < Np; n += kThreads) {
     float c1 = 1.f, c2 = 0.f, c3 = 0.f, mu = 0.f, rs = 0.f;
     if (to.mean && n < N) {
       double s1 = 0.0, s2 = 0.0;
@@ -316,28 +367,218 @@ __global__ __launch_bounds__(kThreads, 4) void dense_bwd_kernel(const float* __r
     }
     Cs[0 * Np + n] = c1; Cs[1 * Np + n] = c2; Cs[2 * Np + n] = c3 * rs; Cs[3 * Np + n] = mu;
   }
-  // W^T fragments of this wave's k-tile: bwt[4j+s] = W[kcol][16j+4g+s]
-  float bwt[4 * NT];
+  __syncthreads();                                    // BN constants visible: dz can be formed at load time
+
+  const bool gvec = (ldgy % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+  const bool yvec = (ldy % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  const int64_t n_tiles = (batch + 15) >> 4;
+  const int64_t tstride = (int64_t)gridDim.x * 8;
+
+  // dz fragments (A layout) of one tile: lane (c16,g) <- columns 16j+4g..+3 of row c16; also written out for dW
+  auto load_dz = [&](float4 (&dz)[NT], int64_t tile) {
+    const int64_t arow = tile < n_tiles ? (tile << 4) + c16 : batch;
+    const bool live = arow < batch;
+    float4 vg[NT], vy[NT];
+    if (gvec && yvec) {                   // all loads first, in one basic block; arithmetic after
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j) {
+        vg[j] = ld4_guard<true>(gy, ldgy, arow, batch, 16 * j + 4 * g, N);
+        vy[j] = ld4_guard<true>(y, ldy, arow, batch, 16 * j + 4 * g, N);
+      }
+    } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int n = 16 * j + 4 * g + s;
-      bwt[4 * j + s] = (kt_live && kcol < K && n < N) ? W[(int64_t)kcol * N + n] : 0.f;
+      for (int j = 0; j < NT; ++j) {
+        vg[j] = ld4_guard<false>(gy, ldgy, arow, batch, 16 * j + 4 * g, N);
+        vy[j] = ld4_guard<false>(y, ldy, arow, batch, 16 * j + 4 * g, N);
+      }
     }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = 16 * j + 4 * g;
+      const float ge[4] = {vg[j].x, vg[j].y, vg[j].z, vg[j].w}, ye[4] = {vy[j].x, vy[j].y, vy[j].z, vy[j].w};
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float da = ge[e];
+        // da = gamma*rstd * (gy - mean(gy) - xhat*mean(gy*xhat)), xhat = (y-mu)*rstd
+        if (to.mean) da = Cs[n + e] * (ge[e] - Cs[Np + n + e] - (ye[e] - Cs[3 * Np + n + e]) * Cs[2 * Np + n + e]);
+        v[e] = (live && n + e < N) ? da * act_grad_from_out(ye[e], act) : 0.f;
+      }
+      dz[j] = make_float4(v[0], v[1], v[2], v[3]);
+      if (live) *reinterpret_cast<float4*>(dzbuf + arow * Np + n) = dz[j];
+    }
+  };
+
+  int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  float4 dz[NT], dzn[NT];
+  load_dz(dz, tile);                                  // first tile's loads fly while W is staged
+  if (gx)
+    for (int idx = threadIdx.x; idx < Kp * (Np / 4); idx += kThreads) {
+      const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
+      const float* wr = W + (int64_t)(k < K ? k : K - 1) * N;
+      const float t0 = wr[n + 0 < N ? n + 0 : N - 1], t1 = wr[n + 1 < N ? n + 1 : N - 1];
+      const float t2 = wr[n + 2 < N ? n + 2 : N - 1], t3 = wr[n + 3 < N ? n + 3 : N - 1];
+      const bool kin = k < K;
+      *reinterpret_cast<float4*>(Ws + k * ldw + n) =
+          make_float4((kin && n + 0 < N) ? t0 : 0.f, (kin && n + 1 < N) ? t1 : 0.f, (kin && n + 2 < N) ? t2 : 0.f, (kin && n + 3 < N) ? t3 : 0.f);
+    }
+  __syncthreads();
+
+  float isum[KT], isq[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) { isum[kt] = 0.f; isq[kt] = 0.f; }
+  for (; tile < n_tiles; tile += tstride) {
+    const int64_t rbase = tile << 4;
+    load_dz(dzn, tile + tstride);                     // next tile's gy / y in flight during this tile's MFMAs
+    if (!gx) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) dz[j] = dzn[j];
+      continue;
+    }
+    if (tin.drop.thr) {
+#pragma unroll
+      for (int i = 0; i < (16 * NCH + 63) / 64; ++i) {
+        const int q = lane + 64 * i;
+        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- dx = dz · W^T in passes of 2 k-tiles: two independent chains alternate (revisit distance
+    //      64 cycles >= the 40-cycle dependent latency), B fragments double-buffered; 2 instead of 4 keeps the
+    //      kernel inside the 128-VGPR budget of 4 waves/SIMD without scratch traffic in the loop ----
+#pragma unroll
+    for (int kt0 = 0; kt0 < KT; kt0 += 2) {
+      constexpr int WMAX = 2;
+      const int Wn = (KT - kt0) < WMAX ? (KT - kt0) : WMAX;
+      f32x4 acc[WMAX];
+      float4 bc[WMAX], bn[WMAX];
+      float xv[4][WMAX];      // raw x of this pass's outputs (for xhat): loaded now, used after the MFMAs
+      if (ibn.mean) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gr = rbase + 4 * g + r;
+          const float* xr = x + (gr < batch ? gr : batch - 1) * ldx_g;
+#pragma unroll
+          for (int w = 0; w < WMAX; ++w) {
+            const int k = (kt0 + w) * 16 + c16;
+            xv[r][w] = xr[k < K ? k : K - 1];
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < WMAX; ++w) {
+        acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (w < Wn) bc[w] = *reinterpret_cast<const float4*>(Ws + ((kt0 + w) * 16 + c16) * ldw + 4 * g);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j + 1 < NT) {
+#pragma unroll
+          for (int w = 0; w < WMAX; ++w)
+            if (w < Wn) bn[w] = *reinterpret_cast<const float4*>(Ws + ((kt0 + w) * 16 + c16) * ldw + 16 * (j + 1) + 4 * g);
+        }
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(dz[j].x, bc[w].x, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(dz[j].y, bc[w].y, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(dz[j].z, bc[w].z, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(dz[j].w, bc[w].w, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) bc[w] = bn[w];
+      }
+      // epilogue of the pass: rows 4g..4g+3, column (kt0+w)*16+c16
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = 4 * g + r;
+        const int64_t gr = rbase + lr;
+        if (gr < batch) {
+#pragma unroll
+          for (int w = 0; w < WMAX; ++w) {
+            if (w < Wn) {
+              const int k = (kt0 + w) * 16 + c16;
+              if (k < K) {
+                // gx = gradient w.r.t. the producer's BN output h (dropout transposed here)
+                const bool keep = tin.drop.thr ? ((mk[lr * NCH + (k >> 3)] >> (k & 7)) & 1) : true;
+                const float dh = keep ? acc[w][r] * tin.drop.inv_keep : 0.f;
+                gx[gr * ldgx + k] = dh;
+                if (ibn.mean && keep) {
+                  const float xhat = (xv[r][w] - Is[k]) * Is[Kp + k];
+                  isum[kt0 + w] += dh;
+                  isq[kt0 + w] += dh * xhat;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) dz[j] = dzn[j];
+  }
+  if (in_sums && ibn.mean) {
+    __shared__ double red[2][kMaxT * 16];
+    for (int n = threadIdx.x; n < 2 * kMaxT * 16; n += kThreads) (&red[0][0])[n] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      double sv = (double)isum[kt], q = (double)isq[kt];
+      sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (g == 0) { atomicAdd(&red[0][kt * 16 + c16], sv); atomicAdd(&red[1][kt * 16 + c16], q); }
+    }
+    __syncthreads();
+    double* rep = in_sums + (size_t)(blockIdx.x % kRep) * 2 * K;
+    for (int k = threadIdx.x; k < K; k += kThreads) {
+      atomicAdd(rep + k, red[0][k]);
+      atomicAdd(rep + K + k, red[1][k]);
+    }
+  }
+}
+
+// ---- backward, part 2: dW = T(x)^T · dz and db -------------------------------------------------
+// A skinny split-K GEMM (K x N output, reduction over the batch): one workgroup per CU sweeps its
+// row range in tiles of TM rows; T(x) (BN-affine + dropout re-applied) and dz are staged through a
+// single LDS image with the next tile's global loads in flight in registers; wave (k-tile, row group)
+// keeps its dW strip in registers for the whole launch -> one slab per (workgroup, row group).
+// KTP = pow2 >= number of k-tiles: wave -> (k-tile = wave % KTP, row group = wave / KTP)
+template <int NT, int KTP>
+__global__ __launch_bounds__(kThreads, 2) void dense_dw_kernel(const float* __restrict__ dzbuf, const float* __restrict__ x, int64_t ldx_g,
+                                                                int64_t batch, int K, int N, InXform tin, int64_t row0,
+                                                                float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int Np = NT * 16, ldz = Np + 4;
+  constexpr int RGN = 8 / KTP;                      // row groups
+  constexpr int TM = 16 * (RGN > 4 ? RGN : 4);      // 64 rows per tile (128 when K <= 16)
+  constexpr int RT = TM / 16 / RGN;                 // row tiles per wave per tile
+  const int KT = (K + 15) >> 4, Kp = KT << 4, ldx = Kp + 4;
+  float* Xs = smem;                                 // [TM][ldx]   T(x)
+  float* Zs = Xs + TM * ldx;                        // [TM][ldz]   dz
+  float* ssb = Zs + TM * ldz;                       // [scale Kp | shift Kp]
+  const float* ss = tin.scale ? ssb : nullptr;
+  if (tin.scale)
+    for (int k = threadIdx.x; k < Kp; k += kThreads) {
+      ssb[k] = k < K ? tin.scale[k] : 0.f;
+      ssb[Kp + k] = k < K ? tin.shift[k] : 0.f;
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int kt = wave % KTP, rg = wave / KTP;
+  const bool kt_live = kt < KT;
+  const int kcol = kt * 16 + c16;
+  const bool xvec = (ldx_g % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+
   f32x4 dW[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) dW[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float db_acc = 0.f;                 // thread t < Np owns column t of db
-  float isum = 0.f, isq = 0.f;        // in-BN sums of column kcol
-  const float imean = (ibn.mean && kt_live && kcol < K) ? ibn.mean[kcol] : 0.f;
-  const float irstd = (ibn.mean && kt_live && kcol < K) ? ibn.rstd[kcol] : 0.f;
+  float db_acc = 0.f;                               // thread t < Np owns column t of db
 
-  constexpr int ZCR = Np / 8;                       // dz chunks per row
+  constexpr int ZCR = Np / 8;
   constexpr int MAXZ = (TM * ZCR + kThreads - 1) / kThreads;
-  constexpr int MAXX = (TM * (kMaxT * 16 / 8) + kThreads - 1) / kThreads;   // bound for Kp <= 128
+  constexpr int MAXX = (TM * (kMaxT * 16 / 8) + kThreads - 1) / kThreads;
   const int xc_row = Kp >> 3, n_xc = TM * xc_row;
-  float pz[MAXZ][8], px[MAXX][8];     // dz is formed at load time: one register set instead of gy + y
+  float pz[MAXZ][8], px[MAXX][8];
   const int64_t n_tiles = (batch + TM - 1) / TM;
 
   auto load_tile = [&](int64_t tile) {
@@ -345,28 +586,26 @@ __global__ __launch_bounds__(kThreads, 4) void dense_bwd_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < MAXZ; ++i) {
       const int idx = threadIdx.x + kThreads * i;
-      if (idx < TM * ZCR) {
-        const int r = idx / ZCR, c = (idx - r * ZCR) << 3;
-        const bool live = (row_base + r) < batch;
-        float vg[8], vy[8];
-        load8(vg, gy, ldgy, row_base + r, batch, c, N, gvec);
-        load8(vy, y, ldy, row_base + r, batch, c, N, yvec);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int n = c + e;
-          float da = vg[e];
-          // da = gamma*rstd * (gy - mean(gy) - xhat*mean(gy*xhat)), xhat = (y-mu)*rstd
-          if (to.mean) da = Cs[n] * (vg[e] - Cs[Np + n] - (vy[e] - Cs[3 * Np + n]) * Cs[2 * Np + n]);
-          pz[i][e] = (live && n < N) ? da * act_grad_from_out(vy[e], act) : 0.f;
-        }
-      }
+      // out-of-tile chunks (idx >= TM*ZCR) clamp to the tile's first chunk; they are never written back
+      const int idc = idx < TM * ZCR ? idx : 0;
+      const int r = idc / ZCR, c = (idc - r * ZCR) << 3;
+      load8<true>(pz[i], dzbuf, Np, row_base + r, batch, c, Np);
     }
+    if (xvec) {
 #pragma unroll
-    for (int i = 0; i < MAXX; ++i) {
-      const int idx = threadIdx.x + kThreads * i;
-      if (idx < n_xc) {
-        const int r = idx / xc_row, c = (idx - r * xc_row) << 3;
-        load8(px[i], x, ldx_g, row_base + r, batch, c, K, xvec);
+      for (int i = 0; i < MAXX; ++i) {
+        const int idx = threadIdx.x + kThreads * i;
+        const int idc = idx < n_xc ? idx : 0;
+        const int r = idc / xc_row, c = (idc - r * xc_row) << 3;
+        load8<true>(px[i], x, ldx_g, row_base + r, batch, c, K);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXX; ++i) {
+        const int idx = threadIdx.x + kThreads * i;
+        const int idc = idx < n_xc ? idx : 0;
+        const int r = idc / xc_row, c = (idc - r * xc_row) << 3;
+        load8<false>(px[i], x, ldx_g, row_base + r, batch, c, K);
       }
     }
   };
@@ -385,86 +624,43 @@ __global__ __launch_bounds__(kThreads, 4) void dense_bwd_kernel(const float* __r
       const int idx = threadIdx.x + kThreads * i;
       if (idx < n_xc) {
         const int r = idx / xc_row, c = (idx - r * xc_row) << 3;
-        const uint32_t bits = xform8(px[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
+        xform8(px[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
         store8_lds(Xs + r * ldx + c, px[i]);
-        Mk[r * mkld + (c >> 3)] = (uint8_t)bits;
       }
     }
   };
 
   int64_t tile = blockIdx.x;
-  __syncthreads();   // Cs, scale|shift visible
   if (tile < n_tiles) load_tile(tile);
+  __syncthreads();   // scale|shift visible
   if (tile < n_tiles) write_tile(tile);
   __syncthreads();
   while (tile < n_tiles) {
     const int64_t next = tile + gridDim.x;
     if (next < n_tiles) load_tile(next);
-    const int64_t row_base = tile * TM;
     if (kt_live) {
-      // ---- dx[rows of my row tiles][k-tile] = dz · W^T ; contraction over n ----
-      if (gx) {
-        f32x4 acc[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-#pragma unroll
-          for (int i = 0; i < RT; ++i) {
-            const float4 a4 = *reinterpret_cast<const float4*>(Zs + ((rg + RGN * i) * 16 + c16) * ldz + 16 * j + 4 * g);
-            acc[i] = mfma16(a4.x, bwt[4 * j + 0], acc[i]);
-            acc[i] = mfma16(a4.y, bwt[4 * j + 1], acc[i]);
-            acc[i] = mfma16(a4.z, bwt[4 * j + 2], acc[i]);
-            acc[i] = mfma16(a4.w, bwt[4 * j + 3], acc[i]);
-          }
-        }
-        if (kcol < K) {
-#pragma unroll
-          for (int i = 0; i < RT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int lr = (rg + RGN * i) * 16 + 4 * g + r;
-              const int64_t gr = row_base + lr;
-              if (gr < batch) {
-                // gx = gradient w.r.t. the producer's BN output h (dropout transposed here)
-                const bool keep = (Mk[lr * mkld + (kcol >> 3)] >> (kcol & 7)) & 1;
-                const float dh = keep ? acc[i][r] * tin.drop.inv_keep : 0.f;
-                gx[gr * ldgx + kcol] = dh;
-                if (ibn.mean && keep) {
-                  const float xhat = (x[gr * ldx_g + kcol] - imean) * irstd;
-                  isum += dh;
-                  isq += dh * xhat;
-                }
-              }
-            }
-          }
-        }
-      }
-      // ---- dW[k-tile rows][N] += T(x)^T · dz ; contraction over my row tiles' rows ----
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int r = (rg + RGN * i) * 16 + 4 * g + s;
-          const float a = Xs[r * ldx + kcol];
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int r = (rg + RGN * i) * 16 + 4 * g + s4;
+          const float av = Xs[r * ldx + kcol];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) dW[nt] = mfma16(a, Zs[r * ldz + nt * 16 + c16], dW[nt]);
+          for (int nt = 0; nt < NT; ++nt) dW[nt] = mfma16(av, Zs[r * ldz + nt * 16 + c16], dW[nt]);
         }
       }
     }
-    // ---- db: thread t < Np sums column t of dz ----
     if (threadIdx.x < Np) {
       float sacc = 0.f;
 #pragma unroll 8
       for (int r = 0; r < TM; ++r) sacc += Zs[r * ldz + threadIdx.x];
       db_acc += sacc;
     }
-    __syncthreads();               // everyone done reading the LDS images
+    __syncthreads();
     if (next < n_tiles) write_tile(next);
     __syncthreads();
     tile = next;
   }
-
   // ---- slab (workgroup, row group): [dW (K x N) | db (N)] ----
   const int64_t slab_elems = (int64_t)K * N + N;
   if (kt_live) {
@@ -482,16 +678,6 @@ __global__ __launch_bounds__(kThreads, 4) void dense_bwd_kernel(const float* __r
   if ((int)threadIdx.x < N) {
     for (int r = 0; r < RGN; ++r)
       slabs[((int64_t)blockIdx.x * RGN + r) * slab_elems + (int64_t)K * N + threadIdx.x] = (r == 0) ? db_acc : 0.f;
-  }
-  if (in_sums && ibn.mean && kt_live) {
-    double s = (double)isum, q = (double)isq;
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-    if (g == 0 && kcol < K) {
-      double* rep = in_sums + (size_t)(blockIdx.x % kRep) * 2 * K;
-      atomicAdd(rep + kcol, s);
-      atomicAdd(rep + K + kcol, q);
-    }
   }
 }
 
@@ -662,17 +848,16 @@ static inline unsigned grid_for(int64_t batch, int tm) {
   int64_t t = ceil_div(batch, tm);
   return (unsigned)(t < kMaxGrid ? (t < 1 ? 1 : t) : kMaxGrid);
 }
-constexpr int kMaxDynLds = 80 * 1024 - 1024;   // two workgroups per CU
-
-template <int NTP, int KJ>
+constexpr int kMaxDynLds = 150 * 1024;
+template <int NT, int KJ>
 static void launch_fwd(unsigned grid, size_t shmem, hipStream_t s, const float* x, int64_t ldx, const float* W, const float* bias, float* y,
                        int64_t ldy, int64_t batch, int K, int N, int act, InXform t, int64_t row0, double* stats) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NTP, KJ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     attr_set = true;
   }
-  dense_fwd_kernel<NTP, KJ><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats);
+  dense_fwd_kernel<NT, KJ><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats);
 }
 
 extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
@@ -685,20 +870,19 @@ extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const
   BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
   BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
   if (batch == 0) return BR_OK;
-  const int NTP = pow2_ge(tiles16(N)), KJ = tiles16(K), Kp = KJ * 16;
-  const int tm = fwd_tm(NTP);
-  const size_t shmem = ((size_t)tm * (Kp + 4) + 2 * (size_t)Kp) * sizeof(float);
+  const int NT = tiles16(N), KJ = tiles16(K), Kp = KJ * 16, Np = NT * 16;
+  const size_t shmem = ((size_t)Kp * Np + 2 * (size_t)Kp) * sizeof(float) + (size_t)8 * 16 * 2 * KJ + 16;
   InXform t{in_scale, in_shift, make_dropout(drop_p, seed, step, site)};
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = grid_for(batch, tm);
-#define BR_FWD_KJ(NTPv, KJv) case KJv: launch_fwd<NTPv, KJv>(grid, shmem, s, x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats); break;
-#define BR_FWD(NTPv)                                                                                            \
-  case NTPv:                                                                                                    \
-    switch (KJ) { BR_FWD_KJ(NTPv, 1) BR_FWD_KJ(NTPv, 2) BR_FWD_KJ(NTPv, 3) BR_FWD_KJ(NTPv, 4) BR_FWD_KJ(NTPv, 5) \
-                  BR_FWD_KJ(NTPv, 6) BR_FWD_KJ(NTPv, 7) BR_FWD_KJ(NTPv, 8) default: break; }                   \
+  const unsigned grid = grid_for(batch, 16 * 8);
+#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(grid, shmem, s, x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats); break;
+#define BR_FWD(NTv)                                                                                        \
+  case NTv:                                                                                                \
+    switch (KJ) { BR_FWD_KJ(NTv, 1) BR_FWD_KJ(NTv, 2) BR_FWD_KJ(NTv, 3) BR_FWD_KJ(NTv, 4) BR_FWD_KJ(NTv, 5) \
+                  BR_FWD_KJ(NTv, 6) BR_FWD_KJ(NTv, 7) BR_FWD_KJ(NTv, 8) default: break; }                  \
     break;
-  switch (NTP) {
-    BR_FWD(1) BR_FWD(2) BR_FWD(4) BR_FWD(8)
+  switch (NT) {
+    BR_FWD(1) BR_FWD(2) BR_FWD(3) BR_FWD(4) BR_FWD(5) BR_FWD(6) BR_FWD(7) BR_FWD(8)
     default: br::set_error("brDenseForward: unsupported N"); return BR_ERR_UNSUPPORTED;
   }
   BR_CHECK_LAUNCH("brDenseForward");
@@ -731,22 +915,44 @@ extern "C" int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta
   return BR_OK;
 }
 
+static inline int dw_tm(int ktp) { return 16 * ((8 / ktp) > 4 ? (8 / ktp) : 4); }
+static inline unsigned dw_grid(int64_t batch, int ktp) {
+  int64_t t = ceil_div(batch, dw_tm(ktp));
+  return (unsigned)(t < 256 ? (t < 1 ? 1 : t) : 256);     // one workgroup per CU
+}
+
 extern "C" int brDenseBackwardSlabs(int64_t batch, int K, int N) {
   (void)N;
   const int KTP = pow2_ge(tiles16(K < 1 ? 1 : K));
-  return (int)grid_for(batch, bwd_tm(KTP)) * (8 / KTP);
+  return (int)dw_grid(batch, KTP) * (8 / KTP);
+}
+
+extern "C" int64_t brDenseBackwardWorkspaceFloats(int64_t batch, int K, int N) {
+  (void)K;
+  return batch * (int64_t)(tiles16(N) * 16);
+}
+
+template <int NT, int KT>
+static void launch_dx(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
+                      int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn, int64_t row0,
+                      float* gx, int64_t ldgx, float* dzbuf, double* in_sums) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dense_dx_kernel<NT, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  dense_dx_kernel<NT, KT><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
 }
 
 template <int NT, int KTP>
-static void launch_bwd(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
-                       int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn, int64_t row0,
-                       float* gx, int64_t ldgx, float* slabs, double* in_sums) {
+static void launch_dw(unsigned grid, size_t shmem, hipStream_t s, const float* dzbuf, const float* x, int64_t ldx, int64_t batch, int K, int N,
+                      InXform tin, int64_t row0, float* slabs) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_bwd_kernel<NT, KTP>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    (void)hipFuncSetAttribute((const void*)dense_dw_kernel<NT, KTP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     attr_set = true;
   }
-  dense_bwd_kernel<NT, KTP><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, slabs, in_sums);
+  dense_dw_kernel<NT, KTP><<<grid, kThreads, shmem, s>>>(dzbuf, x, ldx, batch, K, N, tin, row0, slabs);
 }
 
 extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
@@ -754,8 +960,8 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
                                const float* out_rstd, const float* out_gamma, const double* bn_sums, double batch_total,
                                const float* in_scale, const float* in_shift, const float* in_mean, const float* in_rstd,
                                float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0, float* gx,
-                               int64_t ldgx, float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream) {
-  BR_CHECK_ARG(gy && y && x && W && dW_slabs && batch >= 0 && K >= 1 && N >= 1, "brDenseBackward: bad args");
+                               int64_t ldgx, float* dz_ws, float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream) {
+  BR_CHECK_ARG(gy && y && x && W && dW_slabs && dz_ws && batch >= 0 && K >= 1 && N >= 1, "brDenseBackward: bad args");
   BR_CHECK_ARG(K <= kMaxT * 16 && N <= kMaxT * 16, "brDenseBackward: K=%d N=%d exceed %d", K, N, kMaxT * 16);
   BR_CHECK_ARG(ldgy >= N && ldy >= N && ldx >= K && (!gx || ldgx >= K), "brDenseBackward: bad leading dims");
   BR_CHECK_ARG((out_mean == nullptr) == (out_rstd == nullptr) && (out_mean == nullptr) == (out_gamma == nullptr) &&
@@ -764,28 +970,46 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
   BR_CHECK_ARG((in_mean == nullptr) == (in_rstd == nullptr) && (in_mean == nullptr) == (in_bn_sums == nullptr),
                "brDenseBackward: in BN pointers all or none");
   BR_CHECK_ARG(!in_mean || gx, "brDenseBackward: in BN sums need gx");
+  BR_CHECK_ARG((reinterpret_cast<uintptr_t>(dz_ws) & 15) == 0, "brDenseBackward: dz_ws must be 16-byte aligned");
   if (batch == 0) return BR_OK;
   const int KT = tiles16(K), NT = tiles16(N);
   const int Kp = KT * 16, Np = NT * 16;
-  const int KTP = pow2_ge(KT), tm = bwd_tm(KTP);
-  const unsigned grid = grid_for(batch, tm);
+  const int KTP = pow2_ge(KT);
   const int want = brDenseBackwardSlabs(batch, K, N);
   BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
-  const size_t shmem = ((size_t)tm * (Kp + 4) + (size_t)tm * (Np + 4) + (size_t)((tm * (Kp / 8) + 3) / 4) + 4 * (size_t)Np + 2 * (size_t)Kp) * sizeof(float);
   OutXform to{out_mean, out_rstd, out_gamma, bn_sums, (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch))};
   InXform tin{in_scale, in_shift, make_dropout(in_drop_p, seed, step, in_site)};
   InBn ibn{in_mean, in_rstd};
   hipStream_t s = (hipStream_t)stream;
-#define BR_BWD_K(NTv, KTPv) case KTPv: launch_bwd<NTv, KTPv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dW_slabs, in_bn_sums); break;
-#define BR_BWD(NTv) \
-  case NTv:         \
-    switch (KTP) { BR_BWD_K(NTv, 1) BR_BWD_K(NTv, 2) BR_BWD_K(NTv, 4) BR_BWD_K(NTv, 8) default: break; } \
+  {
+    const unsigned grid = grid_for(batch, 16 * 8);
+    const size_t shmem = ((size_t)Kp * (Np + 4) + 4 * (size_t)Np + 2 * (size_t)Kp) * sizeof(float) + (size_t)8 * 16 * 2 * KT + 16;
+#define BR_DX_K(NTv, KTv) case KTv: launch_dx<NTv, KTv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, in_bn_sums); break;
+#define BR_DX(NTv) \
+  case NTv:        \
+    switch (KT) { BR_DX_K(NTv, 1) BR_DX_K(NTv, 2) BR_DX_K(NTv, 3) BR_DX_K(NTv, 4) BR_DX_K(NTv, 5) BR_DX_K(NTv, 6) BR_DX_K(NTv, 7) BR_DX_K(NTv, 8) default: break; } \
     break;
-  switch (NT) {
-    BR_BWD(1) BR_BWD(2) BR_BWD(3) BR_BWD(4) BR_BWD(5) BR_BWD(6) BR_BWD(7) BR_BWD(8)
-    default: br::set_error("brDenseBackward: unsupported N"); return BR_ERR_UNSUPPORTED;
+    switch (NT) {
+      BR_DX(1) BR_DX(2) BR_DX(3) BR_DX(4) BR_DX(5) BR_DX(6) BR_DX(7) BR_DX(8)
+      default: br::set_error("brDenseBackward: unsupported N"); return BR_ERR_UNSUPPORTED;
+    }
+    BR_CHECK_LAUNCH("brDenseBackward(dx)");
   }
-  BR_CHECK_LAUNCH("brDenseBackward");
+  {
+    const unsigned grid = dw_grid(batch, KTP);
+    const int tm = dw_tm(KTP);
+    const size_t shmem = ((size_t)tm * (Kp + 4) + (size_t)tm * (Np + 4) + 2 * (size_t)Kp) * sizeof(float);
+#define BR_DW_K(NTv, KTPv) case KTPv: launch_dw<NTv, KTPv>(grid, shmem, s, dz_ws, x, ldx, batch, K, N, tin, row0, dW_slabs); break;
+#define BR_DW(NTv) \
+  case NTv:        \
+    switch (KTP) { BR_DW_K(NTv, 1) BR_DW_K(NTv, 2) BR_DW_K(NTv, 4) BR_DW_K(NTv, 8) default: break; } \
+    break;
+    switch (NT) {
+      BR_DW(1) BR_DW(2) BR_DW(3) BR_DW(4) BR_DW(5) BR_DW(6) BR_DW(7) BR_DW(8)
+      default: br::set_error("brDenseBackward: unsupported N"); return BR_ERR_UNSUPPORTED;
+    }
+    BR_CHECK_LAUNCH("brDenseBackward(dW)");
+  }
   return BR_OK;
 }
 

@@ -149,7 +149,7 @@ extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream
       RUN(BR_TAG_REDUCE, brReduceSlabs(s->hslabs, nsh, n3 + 2, gr + oW4, stream));
       const int ns3 = brDenseBackwardSlabs(B, n2, n3);
       RUN(BR_TAG_BWD_L3, brDenseBackward(s->da3, n3, s->a3, n3, s->a2, n2, th + oW3, B, n2, n3, s->act, nullptr, nullptr, nullptr, nullptr, bt, scale2,
-                          shift2, mean2, rstd2, p, 2, s->seed, (uint32_t)s->step, s->row0, s->gh2, n2, s->slabs, ns3, bsum2, stream));
+                          shift2, mean2, rstd2, p, 2, s->seed, (uint32_t)s->step, s->row0, s->gh2, n2, s->dz_ws, s->slabs, ns3, bsum2, stream));
       RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns3, (int64_t)n2 * n3 + n3, gr + oW3, stream));
     } else {
       RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob,
@@ -160,13 +160,13 @@ extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream
   if (ph & BR_PH_BWD2) {
     const int ns2 = brDenseBackwardSlabs(B, n1, n2);
     RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, n2, s->a2, n2, s->a1, n1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt, scale1, shift1,
-                        mean1, rstd1, p, 1, s->seed, (uint32_t)s->step, s->row0, s->gh1, n1, s->slabs, ns2, bsum1, stream));
+                        mean1, rstd1, p, 1, s->seed, (uint32_t)s->step, s->row0, s->gh1, n1, s->dz_ws, s->slabs, ns2, bsum1, stream));
     RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns2, (int64_t)n1 * n2 + n2, gr + oW2, stream));
   }
   if (ph & BR_PH_BWD1) {
     const int ns1 = brDenseBackwardSlabs(B, 2 * D, n1);
     RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, n1, s->a1, n1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt, nullptr,
-                        nullptr, nullptr, nullptr, p, 0, s->seed, (uint32_t)s->step, s->row0, s->dx0, 2 * D, s->slabs, ns1, nullptr, stream));
+                        nullptr, nullptr, nullptr, p, 0, s->seed, (uint32_t)s->step, s->row0, s->dx0, 2 * D, s->dz_ws, s->slabs, ns1, nullptr, stream));
     RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns1, (int64_t)2 * D * n1 + n1, gr + oW1, stream));
   }
   if (ph & BR_PH_BNG) {

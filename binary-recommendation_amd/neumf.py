@@ -177,6 +177,7 @@ class NeuMFEngine:
             self.bn[k] = self.bn_buf[o:o + n]; o += n
         layers = ((2 * D, n1), (n1, n2), (n2, n3))
         self.slabs = f(max(ops.dense_backward_slabs(B, k, n) * (k * n + n) for k, n in layers))
+        self.dz_ws = f(max(ops.dense_backward_ws_floats(B, k, n) for k, n in layers))
         self.nsh = ops.head_slabs(B)
         self.hslabs = f(self.nsh * (n3 + 2))
         self.err = ops.new_err_flag(dev)
@@ -213,7 +214,7 @@ class NeuMFEngine:
         for k in ("x0", "dot", "a1", "a2", "a3", "logit", "prob", "da3", "ddot", "gh2", "gh1", "dx0", "g_user", "g_item"):
             setattr(st, k, P(getattr(self, k)))
         st.bn, st.dstat, st.msums = P(self.bn_buf), P(self.dstat), P(self.msums)
-        st.slabs, st.hslabs, st.err_flag = P(self.slabs), P(self.hslabs), P(self.err)
+        st.slabs, st.hslabs, st.err_flag, st.dz_ws = P(self.slabs), P(self.hslabs), P(self.err), P(self.dz_ws)
         self._bind_indexes(st)
         if not self.sharded and os.environ.get("BR_AUX_STREAM", "1") != "0":
             self.aux_stream = torch.cuda.Stream(device=self.device)     # the dedup sorts run beside fwd/bwd

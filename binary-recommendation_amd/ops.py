@@ -250,19 +250,25 @@ def dense_backward_slabs(batch, K, N) -> int:
     return int(_lib.load().brDenseBackwardSlabs(batch, K, N))
 
 
+def dense_backward_ws_floats(batch, K, N) -> int:
+    return int(_lib.load().brDenseBackwardWorkspaceFloats(batch, K, N))
+
+
 def dense_backward(gy, y, x, W, act, slabs, n_slabs, gx=None, out_bn=None, bn_sums=None, batch_total=None,
                    in_scale=None, in_shift=None, in_bn=None, in_drop_p=0.0, in_site=0, seed=0, step=0, row0=0,
-                   in_bn_sums=None, batch=None):
+                   in_bn_sums=None, batch=None, dz_ws=None):
     """out_bn = (mean, rstd, gamma) of the BN after this layer; in_bn = (mean, rstd) of the BN before it."""
     B = gy.shape[0] if batch is None else batch
     K, N = W.shape
     om, ors, og = out_bn if out_bn is not None else (None, None, None)
     im, irs = in_bn if in_bn is not None else (None, None)
+    if dz_ws is None:
+        dz_ws = torch.empty(dense_backward_ws_floats(B, K, N), dtype=torch.float32, device=gy.device)
     check(_lib.load().brDenseBackward(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0),
                                       W.data_ptr(), B, K, N, ACT[act], _p(om), _p(ors), _p(og), _p(bn_sums),
                                       float(batch_total if batch_total is not None else B), _p(in_scale), _p(in_shift),
                                       _p(im), _p(irs), float(in_drop_p), int(in_site), int(seed), int(step), int(row0),
-                                      _p(gx), gx.stride(0) if gx is not None else 0, slabs.data_ptr(), int(n_slabs),
+                                      _p(gx), gx.stride(0) if gx is not None else 0, dz_ws.data_ptr(), slabs.data_ptr(), int(n_slabs),
                                       _p(in_bn_sums), _stream()), "brDenseBackward")
 
 

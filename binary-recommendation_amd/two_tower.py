@@ -60,6 +60,7 @@ class TwoTowerEngine:
         self.loss_slots = torch.zeros(ops.SUM_SLOTS, dtype=torch.float64, device=dev)
         self.ns = ops.dense_backward_slabs(B, E, S)
         self.slabs = f(self.ns * (E * S + S))
+        self.dz_ws = f(ops.dense_backward_ws_floats(B, E, S))
         self.user_index, self.item_index = ops.RowIndex(B, id_dtype, dev), ops.RowIndex(B, id_dtype, dev)
         self.err = ops.new_err_flag(dev)
         self.t, self.n_seen = 0, 0
@@ -120,7 +121,7 @@ class TwoTowerEngine:
         for tower, g_out, e_in, d_e in (("user", dq, self.eu[:B], self.deu[:B]), ("item", dc, self.ei[:B], self.dei[:B])):
             Wt, _ = self.W(tower)
             y = self.q[:B] if tower == "user" else self.c[:B]
-            ops.dense_backward(g_out, y, e_in, Wt, "linear", self.slabs, ns, gx=d_e)
+            ops.dense_backward(g_out, y, e_in, Wt, "linear", self.slabs, ns, gx=d_e, dz_ws=self.dz_ws)
             ops.reduce_slabs(self.slabs, ns, E * S + S, self._gW(tower))
         self.user_index.build(users, self.user_emb.shape[0])
         self.item_index.build(items, self.item_emb.shape[0])

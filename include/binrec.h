@@ -181,14 +181,17 @@ int brBnInference(const float* gamma, const float* beta, const float* moving_mea
  *      of [dW | db], reduced by brReduceSlabs in a fixed order (bitwise reproducible; no float
  *      atomics).  n_slabs = brDenseBackwardSlabs(). */
 int brDenseBackwardSlabs(int64_t batch, int K, int N);
+/* dz_ws: caller scratch of brDenseBackwardWorkspaceFloats() floats (16-B aligned): dz = dL/dz of the
+ * layer, written by the dx kernel and re-read by the dW kernel (two launches inside the call). */
+int64_t brDenseBackwardWorkspaceFloats(int64_t batch, int K, int N);
 int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
                     int64_t ldx, const float* W, int64_t batch, int K, int N, int act,
                     const float* out_mean, const float* out_rstd, const float* out_gamma,
                     const double* bn_sums, double batch_total, const float* in_scale,
                     const float* in_shift, const float* in_mean, const float* in_rstd,
                     float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0,
-                    float* gx, int64_t ldgx, float* dW_slabs, int n_slabs, double* in_bn_sums,
-                    brStream stream);
+                    float* gx, int64_t ldgx, float* dz_ws, float* dW_slabs, int n_slabs,
+                    double* in_bn_sums, brStream stream);
 /* dgamma = sum gy*xhat, dbeta = sum gy: the BN-backward column sums as fp32 parameter grads. */
 int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta, int N, brStream stream);
 int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* out, brStream stream);
@@ -278,6 +281,7 @@ typedef struct brNeumfStep {
   double* dstat;                           /* [stats1 | stats2 | bsum1 | bsum2], each [BR_STAT_REPLICAS][2n]; zeroed in FWD1 */
   double* msums;                           /* [BR_SUM_SLOTS][loss, sum sq err, sum abs err, #correct] accumulated */
   float* slabs; float* hslabs;
+  float* dz_ws;                            /* brDenseBackwardWorkspaceFloats(max layer) floats */
   int* err_flag;
   void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;
   void* i_sorted_ids; int32_t* i_sorted_pos; void* i_ws; int64_t i_ws_bytes;

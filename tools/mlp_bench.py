@@ -34,7 +34,8 @@ for (K, N) in ((128, 100), (100, 50), (50, 10), (128, 64), (128, 128)):
     for tag, kw in (("plain", dict(act="linear")), ("sigmoid,drop", dict(act="sigmoid", in_drop_p=0.2)),
                     ("full", dict(act="sigmoid", in_drop_p=0.2, out_bn=(mean, rstd, gam), bn_sums=bns, in_scale=sc, in_shift=sh, in_bn=(mi, ri), in_bn_sums=ins))):
         act = kw.pop("act")
-        t = timeit(lambda: ops.dense_backward(gy, y, x, W, act, slabs, ns, gx=gx, seed=1, step=1, **kw))
+        dzw = torch.empty(ops.dense_backward_ws_floats(B, K, N), device=dev)
+        t = timeit(lambda: ops.dense_backward(gy, y, x, W, act, slabs, ns, gx=gx, seed=1, step=1, dz_ws=dzw, **kw))
         res[f"bwd[{K}x{N}] {tag}"] = round(t, 1)
     out = torch.empty(K * N + N, device=dev)
     res[f"reduce[{K}x{N}] ns={ns}"] = round(timeit(lambda: ops.reduce_slabs(slabs, ns, K * N + N, out)), 1)

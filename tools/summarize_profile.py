@@ -33,8 +33,14 @@ if f and w:
         # the sweep kernel runs on two table sizes: keep the largest-grid launches separately
         fv, wv = fa[k].get("FETCH_SIZE", []), wa.get(k, {}).get("WRITE_SIZE", [])
         if not fv: continue
-        gmax = max(g for _, g in fv)
-        fsel = [v for v, g in fv if g == gmax]; wsel = [v for v, g in wv if g == gmax]
+        # kernels launched on two table sizes with the same (capped) grid: keep the larger table's
+        # launches = the upper half by counter value
+        def upper(vals):
+            xs = sorted(v for v, _ in vals)
+            if len(xs) >= 2 and xs[-1] > 1.5 * xs[0]:
+                xs = xs[len(xs) // 2:]
+            return xs
+        fsel, wsel = upper(fv), upper(wv)
         fetch_kib = sum(fsel) / len(fsel); write_kib = (sum(wsel) / len(wsel)) if wsel else 0.0
         summary["traffic_bytes_per_launch"][k] = {"FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                                                   "hbm_bytes_corrected": 2 * fetch_kib * 1024 + write_kib * 1024, "launches": len(fsel)}
