@@ -217,3 +217,71 @@ def make_sharded_engine(base_cls):
             self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
 
     return ShardedNeuMFEngine
+
+
+def make_sharded_two_tower(base_cls):
+    """ShardedTwoTowerEngine = trainers/twoTower.py on W GPUs (BASELINE config 4): embedding tables
+    row-sharded (owner = id mod W, all-to-all ids / rows / row grads as for NeuMF), towers replicated
+    (dense gradients all-reduced), and GLOBAL in-batch negatives: every rank scores its B queries against
+    the all-gathered W*B candidates (streaming LSE, never materialised), and its B candidates against
+    the all-gathered queries for dC — no reduce-scatter needed."""
+    from . import ops
+
+    class ShardedTwoTowerEngine(base_cls):
+        def __init__(self, embed_dim, nbr_item, nbr_user, semb, device, max_batch, ctx: DistCtx, full_tables=None, **kw):
+            self.ctx = ctx
+            super().__init__(embed_dim, nbr_item, nbr_user, semb, device, max_batch, **kw)
+            self.dist = ctx
+            r, W = ctx.rank, ctx.world
+            full = full_tables or {"user_emb": self.user_emb, "item_emb": self.item_emb}   # same seed on every rank
+            for name in ("user_emb", "item_emb"):
+                shard = full[name].to(self.device)[r::W].contiguous()
+                if shard.shape[0] == 0:
+                    shard = torch.zeros(1, embed_dim, device=self.device)
+                setattr(self, name, shard)
+                acc0 = 0.1 if self.optimizer == "Adagrad" else 0.0
+                setattr(self, name.replace("_emb", "_acc"), torch.full_like(shard, acc0))
+                if self.optimizer == "Adam":
+                    setattr(self, name.replace("_emb", "_v"), torch.zeros_like(shard))
+            self.xu, self.xi = ShardExchange(ctx), ShardExchange(ctx)
+            cap = int(2.5 * self.max_batch) + 64
+            self.user_index, self.item_index = ops.RowIndex(cap, self.id_dtype, self.device), ops.RowIndex(cap, self.id_dtype, self.device)
+            self._idx_cap = cap
+
+        def _lookup(self, users, items, B):
+            xu, xi = self.xu.plan(users), self.xi.plan(items)
+            xu.exchange_counts(xi)
+            ru, ri = xu.send_ids(), xi.send_ids()
+            E = self.E
+            empty = torch.empty(0, E, device=self.device)
+            gu = ops.gather_rows([self.user_emb], [ru], err_flag=self.err)[0] if ru.numel() else empty
+            gi = ops.gather_rows([self.item_emb], [ri], err_flag=self.err)[0] if ri.numel() else empty
+            bu, bi = xu.return_rows(gu), xi.return_rows(gi)                      # bucket order
+            ops.gather_rows([bu, bi], [xu.inv.to(self.id_dtype), xi.inv.to(self.id_dtype)], [self.eu[:B], self.ei[:B]])
+
+        def _softmax(self, q, c, items, B, dq, dc):
+            ctx = self.ctx
+            off = ctx.rank * B
+            c_all, ids_all = ctx.all_gather_rows(c.contiguous()), ctx.all_gather_rows(items.contiguous())
+            ops.inbatch_softmax_lse(q, c_all, items, ids_all, off, self.lse[:B], self.loss_slots)
+            if dq is None:
+                return
+            ops.inbatch_softmax_grad(q, c_all, items, ids_all, off, self.lse[:B], dq, None)
+            q_all, lse_all = ctx.all_gather_rows(q.contiguous()), ctx.all_gather_rows(self.lse[:B].contiguous())
+            # dC of MY candidates against ALL queries: query g's positive is my candidate g - rank*B
+            ops.inbatch_softmax_grad(q_all, c.contiguous(), ids_all, items, -off, lse_all, None, dc)
+
+        def _apply_tables(self, users, items, B):
+            xu, xi = self.xu, self.xi
+            bu = ops.gather_rows([self.deu[:B]], [xu.order.to(self.id_dtype)])[0]
+            bi = ops.gather_rows([self.dei[:B]], [xi.order.to(self.id_dtype)])[0]
+            ou, oi = xu.send_row_grads(bu), xi.send_row_grads(bi)
+            if max(xu.n_recv, xi.n_recv) > self._idx_cap:
+                self._idx_cap = int(1.25 * max(xu.n_recv, xi.n_recv)) + 64
+                self.user_index, self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device), ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
+            self.user_index.build(xu.recv_local, self.user_emb.shape[0])
+            self.item_index.build(xi.recv_local, self.item_emb.shape[0])
+            self._opt_rows(self.user_emb, self.user_acc, getattr(self, "user_v", None), self.user_index, ou)
+            self._opt_rows(self.item_emb, self.item_acc, getattr(self, "item_v", None), self.item_index, oi)
+
+    return ShardedTwoTowerEngine

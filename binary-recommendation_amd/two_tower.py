@@ -74,9 +74,36 @@ class TwoTowerEngine:
         o = 0 if tower == "user" else self.E * self.S + self.S
         return self.grad[o:o + self.E * self.S + self.S]
 
+    # ---- hooks the row-sharded / data-parallel subclass overrides (parallel.py) ----
+    dist = None
+
+    def _lookup(self, users, items, B):
+        """G1: both embedding lookups in one launch -> eu, ei (B x E)."""
+        ops.gather_rows([self.user_emb, self.item_emb], [users, items], [self.eu[:B], self.ei[:B]], err_flag=self.err)
+
+    def _softmax(self, q, c, items, B, dq, dc):
+        """L4: in-batch softmax loss (+ gradients when dq is given) over the local batch."""
+        ops.inbatch_softmax_lse(q, c, items, items, 0, self.lse[:B], self.loss_slots)
+        if dq is not None:
+            ops.inbatch_softmax_grad(q, c, items, items, 0, self.lse[:B], dq, dc)
+
+    def _apply_tables(self, users, items, B):
+        """S1 + O2/O1 on the two embedding tables from the per-pair row gradients deu / dei."""
+        E = self.E
+        self.user_index.build(users, self.user_emb.shape[0])
+        self.item_index.build(items, self.item_emb.shape[0])
+        self._opt_rows(self.user_emb, self.user_acc, getattr(self, "user_v", None), self.user_index, self.deu[:B])
+        self._opt_rows(self.item_emb, self.item_acc, getattr(self, "item_v", None), self.item_index, self.dei[:B])
+
+    def _opt_rows(self, table, acc, v, index, row_grads):
+        if self.optimizer == "Adagrad":
+            ops.adagrad_rows_sorted(table, acc, index, row_grads, row_grads.stride(0), self.lr)
+        else:
+            ops.adam_rows_sorted(table, acc, v, index, row_grads, row_grads.stride(0), ops.adam_alpha(self.lr, self.t))
+
     def compute_emb(self, users, items, B):
         """computeEmb (twoTower.py:77-80): (q, c) = towers(user ids), towers(item ids)."""
-        ops.gather_rows([self.user_emb, self.item_emb], [users, items], [self.eu[:B], self.ei[:B]], err_flag=self.err)
+        self._lookup(users, items, B)
         Wu, bu = self.W("user"); Wi, bi = self.W("item")
         ops.dense_forward(self.eu[:B], Wu, bu, self.q[:B], "linear")
         ops.dense_forward(self.ei[:B], Wi, bi, self.c[:B], "linear")
@@ -99,7 +126,7 @@ class TwoTowerEngine:
         ops.dense_forward(e, Wu, bu, out, "linear")
         return out
 
-    def train_step(self, users, items, labels=None):
+    def train_step(self, users, items, labels=None, batch_total=None):
         """train_step (twoTower.py:89-102). labels only for rd_zero (RATING_TYPE)."""
         B = users.shape[0]
         if B == 0:
@@ -110,12 +137,12 @@ class TwoTowerEngine:
         q, c = self.compute_emb(users, items, B)
         dq, dc = self.dq[:B], self.dc[:B]
         if self.rd_zero:
+            bt = B if batch_total is None else batch_total
             ops.row_dot(q, c, self.z[:B])
-            ops.bce_logits(self.z[:B], labels, 1.0 / B, prob=self.prob[:B], dz=self.dz[:B], sums=self.loss_slots)
+            ops.bce_logits(self.z[:B], labels, 1.0 / bt, prob=self.prob[:B], dz=self.dz[:B], sums=self.loss_slots)
             ops.row_dot_backward(q, c, self.dz[:B], dq, dc)
         else:
-            ops.inbatch_softmax_lse(q, c, items, items, 0, self.lse[:B], self.loss_slots)
-            ops.inbatch_softmax_grad(q, c, items, items, 0, self.lse[:B], dq, dc)
+            self._softmax(q, c, items, B, dq, dc)
         E, S = self.E, self.S
         ns = ops.dense_backward_slabs(B, E, S)
         for tower, g_out, e_in, d_e in (("user", dq, self.eu[:B], self.deu[:B]), ("item", dc, self.ei[:B], self.dei[:B])):
@@ -123,24 +150,20 @@ class TwoTowerEngine:
             y = self.q[:B] if tower == "user" else self.c[:B]
             ops.dense_backward(g_out, y, e_in, Wt, "linear", self.slabs, ns, gx=d_e, dz_ws=self.dz_ws)
             ops.reduce_slabs(self.slabs, ns, E * S + S, self._gW(tower))
-        self.user_index.build(users, self.user_emb.shape[0])
-        self.item_index.build(items, self.item_emb.shape[0])
+        if self.dist is not None:
+            self.dist.all_reduce_sum(self.grad)
+        self._apply_tables(users, items, B)
         if self.optimizer == "Adagrad":
-            ops.adagrad_rows_sorted(self.user_emb, self.user_acc, self.user_index, self.deu[:B], E, self.lr)
-            ops.adagrad_rows_sorted(self.item_emb, self.item_acc, self.item_index, self.dei[:B], E, self.lr)
             ops.adagrad_flat(self.theta, self.theta_acc, self.grad, self.lr)
         else:
-            a = ops.adam_alpha(self.lr, self.t)
-            ops.adam_rows_sorted(self.user_emb, self.user_acc, self.user_v, self.user_index, self.deu[:B], E, a)
-            ops.adam_rows_sorted(self.item_emb, self.item_acc, self.item_v, self.item_index, self.dei[:B], E, a)
-            ops.adam_flat(self.theta, self.theta_acc, self.theta_v, self.grad, a)
+            ops.adam_flat(self.theta, self.theta_acc, self.theta_v, self.grad, ops.adam_alpha(self.lr, self.t))
         self.n_seen += B if self.rd_zero else 1
 
     def test_step(self, users, items):
         """test_step (twoTower.py:104-111): the retrieval loss without an update."""
         B = users.shape[0]
         q, c = self.compute_emb(users, items, B)
-        ops.inbatch_softmax_lse(q, c, items, items, 0, self.lse[:B], self.loss_slots)
+        self._softmax(q, c, items, B, None, None)
         self.n_seen += 1
 
     def pop_loss(self) -> float:

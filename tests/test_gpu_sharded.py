@@ -103,3 +103,67 @@ def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer):
         p.join(timeout=60)
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
+
+
+def _tt_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from importlib import import_module
+    from oracle import binrec_oracle as O
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        par = import_module("binary-recommendation_amd.parallel")
+        tt = import_module("binary-recommendation_amd.two_tower")
+        dev = torch.device("cuda:0")
+        ctx = par.DistCtx()
+        U, I, E, S, Bl = 60, 31, 75, 50, 48
+        B = Bl * world
+        rng = np.random.default_rng(77)
+        prm = {"user_emb": rng.uniform(-.05, .05, (U + 2, E)).astype(np.float32), "item_emb": rng.uniform(-.05, .05, (I + 2, E)).astype(np.float32),
+               "Wu": rng.normal(0, .15, (E, S)).astype(np.float32), "bu": rng.normal(0, .1, S).astype(np.float32),
+               "Wi": rng.normal(0, .15, (E, S)).astype(np.float32), "bi": rng.normal(0, .1, S).astype(np.float32)}
+        Eng = par.make_sharded_two_tower(tt.TwoTowerEngine)
+        eng = Eng(E, I, U, S, dev, Bl, ctx, full_tables={k: torch.from_numpy(prm[k]) for k in ("user_emb", "item_emb")}, lr=0.1)
+        td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        Wu, bu = eng.W("user"); Wi, bi = eng.W("item")
+        Wu.copy_(td(prm["Wu"])); bu.copy_(td(prm["bu"])); Wi.copy_(td(prm["Wi"])); bi.copy_(td(prm["bi"]))
+        u = rng.integers(2, U + 2, B); i = rng.integers(2, I + 2, B)          # I < B: accidental hits across ranks
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        eng.train_step(td(u[sl]).int(), td(i[sl]).int())
+        torch.cuda.synchronize(); eng.check_ids()
+        loss, (qr, cr), g, rg = O.twotower_step_grads(prm, u, i, None, rd_zero=False)      # ONE global batch
+        np.testing.assert_allclose(eng.q[:Bl].cpu().numpy(), qr[sl], rtol=1e-5, atol=5e-6 * np.abs(qr).max())
+        tot = torch.tensor([eng.loss_slots.sum().item()], dtype=torch.float64)
+        dist.all_reduce(tot)
+        assert abs(tot.item() - loss) <= 1e-5 * abs(loss), (tot.item(), loss)
+        np.testing.assert_allclose(eng.deu[:Bl].cpu().numpy(), rg["user_emb"][sl], rtol=1e-4, atol=1e-5 * np.abs(rg["user_emb"]).max())
+        np.testing.assert_allclose(eng.dei[:Bl].cpu().numpy(), rg["item_emb"][sl], rtol=1e-4, atol=1e-5 * np.abs(rg["item_emb"]).max())
+        gref = np.concatenate([g["Wu"].reshape(-1), g["bu"], g["Wi"].reshape(-1), g["bi"]])
+        np.testing.assert_allclose(eng.grad.cpu().numpy(), gref, rtol=1e-4, atol=2e-4 * np.abs(gref).max())
+        ref_t, _ = O.adagrad_sparse(prm["item_emb"], np.full(prm["item_emb"].shape, 0.1), i, rg["item_emb"], 0.1)
+        got = eng.item_emb.cpu().numpy()
+        np.testing.assert_allclose(got[: ref_t[rank::world].shape[0]], ref_t[rank::world], rtol=1e-5, atol=2e-3 * 0.1)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()[-1800:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def test_sharded_two_tower_global_negatives(dev):
+    world, port = 2, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_tt_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
