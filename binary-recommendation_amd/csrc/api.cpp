@@ -10,6 +10,9 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+static thread_local const StepStateDev* g_step_state = nullptr;
+const StepStateDev* current_step_state() { return g_step_state; }
+void set_current_step_state(const StepStateDev* p) { g_step_state = p; }
 }  // namespace br
 
 extern "C" const char* brGetLastError(void) { return br::g_err; }

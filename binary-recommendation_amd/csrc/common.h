@@ -11,6 +11,16 @@ namespace br {
 
 void set_error(const char* fmt, ...);
 
+// Optional device-resident step state (hipGraph replays bake kernel arguments in, so the two per-step
+// scalars — the dropout step counter and Adam's alpha_t — are then read from device memory).
+// Set by brNeumfStepRun for the duration of a call when brNeumfStep.step_state != NULL.
+struct StepStateDev {
+  uint32_t step;
+  float alpha_t;
+};
+const StepStateDev* current_step_state();
+void set_current_step_state(const StepStateDev* p);
+
 #define BR_CHECK_ARG(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_fwd_kernel(const float* __r
                                                                  int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
                                                                  double* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  dropout_resolve(tin.drop);
   constexpr int Np = NT * 16, Kp = KJ * 16, NCH = 2 * KJ;
   float* Ws = smem;                                   // [KJ][4][Np][4]
   float* ssb = Ws + Kp * Np;                          // [scale Kp | shift Kp]
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
                                                                 int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ dzbuf,
                                                                 double* __restrict__ in_sums) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  dropout_resolve(tin.drop);
   constexpr int Np = NT * 16, Kp = KT * 16, ldw = Np + 4, NCH = 2 * KT;
   float* Ws = smem;                                   // [Kp][ldw] row-major W
   float* Cs = Ws + Kp * ldw;                          // [4][Np] out-BN constants
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dw_kernel(const float* __re
                                                                 int64_t batch, int K, int N, InXform tin, int64_t row0,
                                                                 float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  dropout_resolve(tin.drop);
   constexpr int Np = NT * 16, ldz = Np + 4;
   constexpr int RGN = 8 / KTP;                      // row groups
   constexpr int TM = 16 * (RGN > 4 ? RGN : 4);      // 64 rows per tile (128 when K <= 16)
@@ -873,6 +876,7 @@ extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const
   const int NT = tiles16(N), KJ = tiles16(K), Kp = KJ * 16, Np = NT * 16;
   const size_t shmem = ((size_t)Kp * Np + 2 * (size_t)Kp) * sizeof(float) + (size_t)8 * 16 * 2 * KJ + 16;
   InXform t{in_scale, in_shift, make_dropout(drop_p, seed, step, site)};
+  if (const StepStateDev* ss = current_step_state()) t.drop.step_ptr = &ss->step;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = grid_for(batch, 16 * 8);
 #define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(grid, shmem, s, x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats); break;
@@ -979,6 +983,7 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
   BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
   OutXform to{out_mean, out_rstd, out_gamma, bn_sums, (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch))};
   InXform tin{in_scale, in_shift, make_dropout(in_drop_p, seed, step, in_site)};
+  if (const StepStateDev* ss = current_step_state()) tin.drop.step_ptr = &ss->step;
   InBn ibn{in_mean, in_rstd};
   hipStream_t s = (hipStream_t)stream;
   {

@@ -11,16 +11,24 @@ struct Probe {
   std::vector<hipEvent_t> ev;   // 2 per record
   std::vector<int> tag;
   int n = 0, cap = 0;
+  bool open = false;
 };
 Probe g_probe;
 inline void probe_begin(int tag, hipStream_t s) {
+  g_probe.open = false;
   if (g_probe.n < g_probe.cap) {
+    // timed events cannot be recorded into a stream capture (hipErrorInvalidHandle on ROCm 7.2):
+    // launches that are being captured into a hipGraph are not probed
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
     g_probe.tag[g_probe.n] = tag;
     (void)hipEventRecord(g_probe.ev[2 * g_probe.n], s);
+    g_probe.open = true;
   }
 }
 inline void probe_end(hipStream_t s) {
-  if (g_probe.n < g_probe.cap) {
+  if (g_probe.open) {
+    g_probe.open = false;
     (void)hipEventRecord(g_probe.ev[2 * g_probe.n + 1], s);
     ++g_probe.n;
   }
@@ -69,8 +77,19 @@ bool ensure_events() {
 
 extern "C" int64_t brNeumfStepSizeof(void) { return (int64_t)sizeof(brNeumfStep); }
 
+extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream);
+
+static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream);
+
 extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream) {
   BR_CHECK_ARG(s != nullptr, "brNeumfStepRun: null struct");
+  br::set_current_step_state(reinterpret_cast<const br::StepStateDev*>(s->step_state));
+  const int rc = step_run_impl(s, ph, stream);
+  br::set_current_step_state(nullptr);
+  return rc;
+}
+
+static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const int64_t B = s->batch;
   if (B == 0) return BR_OK;
   hipStream_t hs = (hipStream_t)stream;
@@ -116,6 +135,8 @@ extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream
     if (rc != BR_OK) return rc;
     (void)hipEventRecord(g_join, as);
   }
+  if ((ph & BR_PH_FWD1) && train && s->step_state)
+    RUN(BR_TAG_SMALL, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, stream));
   if (ph & BR_PH_FWD1) {
     if (train) {
       hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(BR_STAT_REPLICAS * (4 * n1 + 4 * n2)), hs);
@@ -183,15 +204,19 @@ extern "C" int brNeumfStepRun(const brNeumfStep* s, uint32_t ph, brStream stream
       RUN(BR_TAG_INDEX_USER, brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, stream));
       RUN(BR_TAG_INDEX_ITEM, brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, stream));
     }
+  }
+  {
     uint8_t* um = s->adam_dense ? s->user_mark : nullptr;
     uint8_t* im = s->adam_dense ? s->item_mark : nullptr;
-    RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSorted(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type, s->u_sorted_pos, B,
-                         s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
-    if (s->adam_dense)
+    if (ph & BR_PH_ROWS_USER)
+      RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSorted(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type, s->u_sorted_pos, B,
+                           s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
+    if ((ph & BR_PH_SWEEP_USER) && s->adam_dense)
       RUN(BR_TAG_SWEEP_USER, brAdamDenseSweep(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
-    RUN(BR_TAG_ADAM_ROWS_ITEM, brAdamRowsSorted(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->i_sorted_ids, s->id_type, s->i_sorted_pos, B,
-                         s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
-    if (s->adam_dense)
+    if (ph & BR_PH_ROWS_ITEM)
+      RUN(BR_TAG_ADAM_ROWS_ITEM, brAdamRowsSorted(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->i_sorted_ids, s->id_type, s->i_sorted_pos, B,
+                           s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
+    if ((ph & BR_PH_SWEEP_ITEM) && s->adam_dense)
       RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
   }
   if (ph & BR_PH_OPT_DENSE)

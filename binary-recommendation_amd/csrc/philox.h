@@ -48,6 +48,7 @@ struct DropoutCfg {
   uint32_t site;
   uint32_t thr;      // 0 => dropout off
   float inv_keep;    // 1/(1-p)
+  const uint32_t* step_ptr;   // non-null: the step counter lives in device memory (hipGraph replays)
 };
 
 __host__ inline DropoutCfg make_dropout(float p, uint64_t seed, uint32_t step, uint32_t site) {
@@ -58,7 +59,13 @@ __host__ inline DropoutCfg make_dropout(float p, uint64_t seed, uint32_t step, u
   c.site = site;
   c.thr = p > 0.f ? dropout_threshold(p) : 0u;
   c.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  c.step_ptr = nullptr;
   return c;
+}
+
+// kernels call this once on their by-value copy
+__device__ __forceinline__ void dropout_resolve(DropoutCfg& c) {
+  if (c.step_ptr) c.step = *c.step_ptr;
 }
 
 // keep-bits (bit i = column 8*c8 + i kept) of the 8 columns of chunk c8 of global row r

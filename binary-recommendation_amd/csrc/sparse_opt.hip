@@ -49,7 +49,11 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const IdT* __restrict_
 
 struct AdamHp {
   float alpha, b1, omb1, b2, omb2, eps;
+  const float* alpha_ptr;   // non-null: alpha_t lives in device memory (hipGraph replays)
 };
+__device__ __forceinline__ void adam_resolve(AdamHp& h) {
+  if (h.alpha_ptr) h.alpha = *h.alpha_ptr;
+}
 
 __device__ __forceinline__ void adam_update1(float& th, float& m, float& v, float g, const AdamHp& h) {
   m = h.b1 * m + h.omb1 * g;
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict
                                                                 const float* __restrict__ g1, int64_t ldg1, int split,
                                                                 AdamHp h, uint8_t* __restrict__ mark) {
   using V = typename VecT<VEC>::type;
+  adam_resolve(h);
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = tid >> lpr_log2;
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(256) void adam_dense_sweep_kernel(float* __restrict
                                                                 float* __restrict__ Vv, int64_t n_vec, int chunks,
                                                                 AdamHp h, const uint8_t* __restrict__ mark) {
   using V = typename VecT<VEC>::type;
+  adam_resolve(h);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_vec; e += stride) {
     const int64_t row = e / chunks;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(256) void adam_dense_sweep_kernel(float* __restrict
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ th, float* __restrict__ m, float* __restrict__ v,
                                                          const float* __restrict__ g, int64_t n, AdamHp h) {
+  adam_resolve(h);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) adam_update1(th[i], m[i], v[i], g[i], h);
 }
@@ -187,6 +194,12 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ gt
   atomicAdd(gt + id * dim + d, rows[e]);
 }
 
+__global__ void step_state_advance_kernel(StepStateDev* st, double lr, double b1, double b2) {
+  const uint32_t t = st->step + 1;
+  st->step = t;
+  st->alpha_t = (float)(lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
+}
+
 static inline AdamHp make_hp(double alpha, double b1, double b2, double eps) {
   AdamHp h;
   h.alpha = (float)alpha;
@@ -195,6 +208,8 @@ static inline AdamHp make_hp(double alpha, double b1, double b2, double eps) {
   h.b2 = (float)b2;
   h.omb2 = (float)(1.0 - b2);
   h.eps = (float)eps;
+  const StepStateDev* ss = current_step_state();
+  h.alpha_ptr = ss ? &ss->alpha_t : nullptr;
   return h;
 }
 
@@ -380,5 +395,12 @@ extern "C" int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n
   BR_CHECK_ARG(theta && acc && g && n > 0, "brAdagradFlat: bad args");
   adagrad_flat_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(theta, acc, g, n, (float)lr, (float)eps);
   BR_CHECK_LAUNCH("brAdagradFlat");
+  return BR_OK;
+}
+
+extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream) {
+  BR_CHECK_ARG(step_state != nullptr, "brStepStateAdvance: null state");
+  step_state_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>((StepStateDev*)step_state, lr, beta1, beta2);
+  BR_CHECK_LAUNCH("brStepStateAdvance");
   return BR_OK;
 }

@@ -220,7 +220,9 @@ class NeuMFEngine:
             self.aux_stream = torch.cuda.Stream(device=self.device)     # the dedup sorts run beside fwd/bwd
             st.aux_stream = self.aux_stream.cuda_stream
         self.step_struct = st
-        self.PH = {k[6:]: v for k, v in _lib.parse_enums().items() if k.startswith("BR_PH_")}
+        PH = self.PH = {k[6:]: v for k, v in _lib.parse_enums().items() if k.startswith("BR_PH_")}
+        PH["OPT_ROWS"] = PH["ROWS_USER"] | PH["SWEEP_USER"] | PH["ROWS_ITEM"] | PH["SWEEP_ITEM"]
+        self._graph = None
 
     def _bind_indexes(self, st):
         ui, ii = self.user_index, self.item_index
@@ -269,6 +271,9 @@ class NeuMFEngine:
             return
         batch_total = B if batch_total is None else batch_total
         self.t += 1
+        if self._graph is not None and B == self._graph["batch"] and row0 == 0 and batch_total == B:
+            self._replay(users, items, labels)
+            return
         self._set_batch(users, items, labels, B, True, row0, batch_total)
         if self.dist is None:
             self._run(PH["ALL"])
@@ -300,8 +305,85 @@ class NeuMFEngine:
         if self.sharded:
             self._embed_backward_apply(users, items, B)
         else:
-            self._run(PH["OPT_TABLES"] | PH["EMBED"])
+            self._run(PH["OPT_TABLES"] | PH["EMBED"] | PH["OPT_ROWS"])
         self._run(PH["OPT_DENSE"])
+
+    # ------------------------------------------------------------------ hipGraph replay of the step
+    def enable_graph(self, batch: int | None = None, eager_sweep: bool = False):
+        """Capture the single-GPU training step for batches of exactly `batch` pairs into a hipGraph and
+        replay it from `train_step` (other batch sizes keep the eager launch sequence).  The two per-step
+        scalars (dropout step counter, Adam alpha_t) then live in device memory (brNeumfStep.step_state)
+        and are advanced by a 1-thread kernel at the top of the step; ids/labels are read from the static
+        buffers `in_users / in_items / in_labels` (train_step copies into them unless it is handed
+        exactly those tensors).
+        eager_sweep: keep the user-table Adam sweep OUTSIDE the graphs (graph A -> eager launch -> graph B)
+        so that HIP events can bracket it; timed events cannot be recorded inside a capture on ROCm 7.2."""
+        if self.dist is not None:
+            raise ValueError("graph replay covers the single-GPU step (collectives run between the phases otherwise)")
+        B = self.max_batch if batch is None else int(batch)
+        if not 0 < B <= self.max_batch:
+            raise ValueError("graph batch must be in (0, max_batch]")
+        dev, st, PH = self.device, self.step_struct, self.PH
+        self.in_users = torch.zeros(B, dtype=self.id_dtype, device=dev)
+        self.in_items = torch.zeros(B, dtype=self.id_dtype, device=dev)
+        self.in_labels = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)      # {uint32 step; float alpha_t}
+        st.lr, st.step_state = self.cfg.lr, self.step_state.data_ptr()
+        # every kernel of the step runs once outside a capture first (code objects load on first launch);
+        # the model state is put back afterwards
+        keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state_dict().items()}
+        keep_sums = self.msums.clone()
+        self._sync_step_state()
+        self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, 0, B)
+        self._run(PH["ALL"])
+        torch.cuda.synchronize(dev)
+        self.load_state_dict(keep)
+        self.msums.copy_(keep_sums)
+        del keep
+        self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, 0, B)
+        if eager_sweep and self.cfg.optimizer == "adam_dense":
+            tail = PH["ROWS_ITEM"] | PH["SWEEP_ITEM"] | PH["OPT_DENSE"]
+            parts = [PH["ALL"] & ~(tail | PH["SWEEP_USER"]), PH["SWEEP_USER"], tail]
+        else:
+            parts = [PH["ALL"]]
+        graphs = []
+        for i, ph in enumerate(parts):
+            if len(parts) == 3 and i == 1:
+                graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run(ph)
+            graphs.append(g)
+        # the capture itself executes nothing, but the dry run above advanced the device step counter
+        self._sync_step_state()
+        self._graph = {"batch": B, "parts": parts, "graphs": graphs}
+
+    def disable_graph(self):
+        self._graph = None
+
+    def _sync_step_state(self):
+        """device step counter := self.t (after enable_graph / load_state_dict)."""
+        if getattr(self, "step_state", None) is not None:
+            a = ops.adam_alpha(self.cfg.lr, max(self.t, 1), self.cfg.beta1, self.cfg.beta2)
+            host = torch.tensor([self.t], dtype=torch.int32)
+            self.step_state[0:1].copy_(host)
+            self.step_state[1:2].view(torch.float32).fill_(a)
+
+    def _replay(self, users, items, labels):
+        if users.data_ptr() != self.in_users.data_ptr():
+            self.in_users.copy_(users)
+        if items.data_ptr() != self.in_items.data_ptr():
+            self.in_items.copy_(items)
+        if labels.data_ptr() != self.in_labels.data_ptr():
+            self.in_labels.copy_(labels)
+        gr = self._graph
+        for ph, g in zip(gr["parts"], gr["graphs"]):
+            if g is None:
+                self._set_batch(self.in_users, self.in_items, self.in_labels, gr["batch"], True, 0, gr["batch"])
+                self._run(ph)
+            else:
+                g.replay()
 
     def row_grad_views(self, B):
         """name -> (tensor, row stride): the MLP halves are views of dx0, the MF halves of g_user / g_item."""
@@ -389,6 +471,7 @@ class NeuMFEngine:
             self.fused[k].copy_(sd["table." + k]); self.fused_m[k].copy_(sd["table." + k + ".m"]); self.fused_v[k].copy_(sd["table." + k + ".v"])
         for k in self.moving:
             self.moving[k].copy_(sd[k])
+        self._sync_step_state()
 
     def load_numpy_params(self, p: dict):
         """Load a parameter dict in the oracle's naming (tests / golden fixtures)."""

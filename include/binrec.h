@@ -251,15 +251,19 @@ int brTopKRows(const float* scores, int64_t n_users, int64_t n_items, int k, flo
  *   FWD3 BN2 finalize, dense L3, head (+ loss/metric sums, head grads), backward L3 (+ BN2-bwd sums)
  *   BWD2 backward L2 (+ BN1-bwd sums)        BWD1 backward L1
  *   BNG  gamma/beta grads from the BN-backward sums
- *   OPT_TABLES [EMBED] embed backward, dedup index, Adam rows (+ dense sweep)   OPT_DENSE Adam on theta
+ *   OPT_TABLES [EMBED] embed backward, dedup index   ROWS_USER / SWEEP_USER / ROWS_ITEM / SWEEP_ITEM the table
+ *   optimizer launches (separate bits so a host can keep one of them outside a captured hipGraph)
+ *   OPT_DENSE Adam on theta
  * EMBED: include the table-side embed forward/backward (single GPU); cleared by the row-sharded
  * host, which runs its own exchange and calls brNeumfEmbedForward/Backward on the received rows.
  * Dense parameter layout (theta/grad/adam_m/adam_v, floats):
  *   [W1 2*dim x n1 | b1 n1 | g1 n1 | be1 n1 | W2 n1 x n2 | b2 n2 | g2 n2 | be2 n2 | W3 n2 x n3 | b3 n3 | W4 n3+1 | b4 1] */
 enum {
   BR_PH_FWD1 = 1, BR_PH_FWD2 = 2, BR_PH_FWD3 = 4, BR_PH_BWD2 = 8, BR_PH_BWD1 = 16, BR_PH_BNG = 32,
-  BR_PH_OPT_TABLES = 64, BR_PH_OPT_DENSE = 128, BR_PH_EMBED = 256,
-  BR_PH_ALL = 511
+  BR_PH_OPT_TABLES = 64,      /* embed backward + dedup index (or the join of the aux-stream sorts) */
+  BR_PH_OPT_DENSE = 128, BR_PH_EMBED = 256,
+  BR_PH_ROWS_USER = 512, BR_PH_SWEEP_USER = 1024, BR_PH_ROWS_ITEM = 2048, BR_PH_SWEEP_ITEM = 4096,
+  BR_PH_ALL = 8191
 };
 typedef struct brNeumfStep {
   int64_t batch, batch_total, row0, user_rows, item_rows;
@@ -285,10 +289,17 @@ typedef struct brNeumfStep {
   int* err_flag;
   void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;
   void* i_sorted_ids; int32_t* i_sorted_pos; void* i_ws; int64_t i_ws_bytes;
+  double lr;          /* learning rate (only used with step_state) */
+  void* step_state;   /* optional device {uint32 step; float alpha_t}: when non-NULL the step advances it in
+                         FWD1 (step += 1, alpha_t = lr*sqrt(1-b2^step)/(1-b1^step)) and every kernel reads the
+                         dropout step / Adam alpha from there instead of `step` / `alpha_t` above, so the whole
+                         call can be captured once in a hipGraph and replayed */
   void* aux_stream;   /* optional second hipStream_t: the two dedup sorts depend only on the ids, so with
                          BR_PH_FWD1|BR_PH_OPT_TABLES in one call they run here beside the forward/backward
                          and are joined (event) before the Adam-rows kernels; NULL = same stream */
 } brNeumfStep;
+/* step_state (device {uint32 step; float alpha_t}): step += 1, alpha_t = lr*sqrt(1-b2^step)/(1-b1^step). */
+int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream);
 int64_t brNeumfStepSizeof(void);
 int brNeumfStepRun(const brNeumfStep* s, uint32_t phases, brStream stream);
 

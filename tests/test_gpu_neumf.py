@@ -184,3 +184,68 @@ def test_empty_batch_is_noop(dev):
     before = eng.theta.buf.clone()
     eng.train_step(e, e, torch.empty(0, device=dev))
     assert torch.equal(before, eng.theta.buf) and eng.t == 0
+
+
+@pytest.mark.parametrize("optimizer,eager_sweep", [("adam_dense", False), ("adam_dense", True), ("adam_lazy", False)])
+def test_graph_replay_matches_eager_steps(dev, optimizer, eager_sweep):
+    """hipGraph replay of the step (NeuMFEngine.enable_graph) against the eager launch sequence over 4
+    steps with fresh batches, a ragged (eager) batch in between, and a state reload.  The only arithmetic
+    difference is alpha_t: computed on the device in double and rounded to fp32 (eager: on the host),
+    so parameters agree to an fp32 ulp of alpha (1e-6 relative), everything else is the same launches."""
+    B = 192
+    ops, eg, spec, cfg, p, u, i, y = _setup("A", 64, B, dev, optimizer=optimizer)
+    _, gr, *_ = _setup("A", 64, B, dev, optimizer=optimizer)
+    gr.enable_graph(B, eager_sweep=eager_sweep)
+    assert gr.t == 0
+    rng = np.random.default_rng(11)
+    td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
+    for step in range(5):
+        n = 77 if step == 2 else B      # step 2: ragged batch -> eager path on both engines
+        uu, ii = rng.integers(0, 97, n), rng.integers(0, 53, n)
+        yy = (rng.random(n) < 0.3).astype(np.float32)
+        for e in (eg, gr):
+            e.train_step(td(uu, torch.int32), td(ii, torch.int32), td(yy, torch.float32))
+        if step == 3:   # reload: the device step counter must follow t
+            gr.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in gr.state_dict().items()})
+    torch.cuda.synchronize()
+    gr.check_ids()
+    assert gr.t == eg.t == 5
+    assert int(gr.step_state[0].item()) == 5
+    for k in ("user", "item"):
+        _close(gr.fused[k].cpu().numpy(), eg.fused[k].cpu().numpy(), "table " + k, rtol=2e-6, atol_frac=1e-6)
+        _close(gr.fused_v[k].cpu().numpy(), eg.fused_v[k].cpu().numpy(), "v " + k, rtol=2e-6, atol_frac=1e-6)
+    _close(gr.theta.buf.cpu().numpy(), eg.theta.buf.cpu().numpy(), "theta", rtol=2e-6, atol_frac=1e-6)
+    _close(gr.moving_buf.cpu().numpy(), eg.moving_buf.cpu().numpy(), "moving", rtol=2e-6, atol_frac=1e-6)
+    _close(gr.msums.sum(0).cpu().numpy(), eg.msums.sum(0).cpu().numpy(), "metric sums", rtol=1e-6)
+
+
+def test_graph_replay_against_oracle(dev):
+    """Three replayed steps against the oracle (dropout masks keyed by the DEVICE step counter, alpha_t
+    computed on the device); same bounds as test_three_optimizer_steps."""
+    B = 200
+    ops, eng, spec, cfg, p, u, i, y = _setup("A", 64, B, dev, optimizer="adam_dense")
+    eng.enable_graph(B)
+    td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
+    rng = np.random.default_rng(11)
+    P = {k: v.astype(np.float64) for k, v in p.items()}
+    names = ("user_mlp", "item_mlp", "user_mf", "item_mf")
+    M = {k: np.zeros_like(P[k]) for k in list(O.DENSE_ORDER) + list(names)}
+    V = {k: np.zeros_like(P[k]) for k in M}
+    for t in range(1, 4):
+        u = rng.integers(0, 97, B); i = rng.integers(0, 53, B); u[:20] = u[0]
+        y = (rng.random(B) < 0.25).astype(np.float32)
+        eng.train_step(td(u, torch.int32), td(i, torch.int32), td(y, torch.float32))
+        loss, c, g, rg, ns = O.neumf_step_grads(spec, P, u, i, y, _masks(cfg, spec, t, B), dt=np.float64)
+        for k in O.DENSE_ORDER:
+            P[k], M[k], V[k] = O.adam_dense(P[k], M[k], V[k], g[k], cfg.lr, t)
+        for k in names:
+            P[k], M[k], V[k] = O.adam_sparse_tf(P[k], M[k], V[k], u if k.startswith("user") else i, rg[k], cfg.lr, t, lazy=False)
+        P.update(ns)
+    torch.cuda.synchronize()
+    eng.check_ids()
+    travel = 3 * cfg.lr
+    for k in O.DENSE_ORDER:
+        np.testing.assert_allclose(eng.theta.view(k).cpu().numpy().reshape(P[k].shape), P[k], rtol=1e-5, atol=2e-2 * travel, err_msg=k)
+    for k in names:
+        np.testing.assert_allclose(eng.tables[k].cpu().numpy(), P[k], rtol=1e-5, atol=5e-3 * travel, err_msg=k)
+        assert np.median(np.abs(eng.tables[k].cpu().numpy() - P[k])) <= 1e-7
