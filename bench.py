@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--items", type=int, default=100_000)
     ap.add_argument("--variant", default="A")
     ap.add_argument("--optimizer", default="adam_dense", choices=["adam_dense", "adam_lazy"])
+    ap.add_argument("--dense-impl", default=None, choices=["deferred", "sweep"],
+                    help="adam_dense: per-row deferred replay (default on one GPU) or one table sweep per step (row-sharded runs)")
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) ids instead of uniform")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -198,8 +200,10 @@ def main():
     batch_total = B * world
     row0 = rank * B
 
-    def build(optimizer):
-        cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004)
+    impl = args.dense_impl or ("deferred" if world == 1 else "sweep")
+
+    def build(optimizer, dense_impl=impl):
+        cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl)
         if world == 1:
             return neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=1)
         return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1)
@@ -231,7 +235,8 @@ def main():
         eager_profile = {"steps": np_, "ms_per_step": dte / np_ * 1e3, "value": B * np_ / dte, "unit": "pairs/s",
                          "note": "eager launch sequence with a HIP event pair around every launch (source of the per-kernel table)"}
         log(f"eager profiling pass: {dte / np_ * 1e3:.3f} ms/step")
-        eng.enable_graph(B, eager_sweep=(args.optimizer == "adam_dense"))
+        sweeping = args.optimizer == "adam_dense" and not eng.deferred
+        eng.enable_graph(B, eager_phases=("SWEEP_USER",) if sweeping else ("BWD1",))
         run_steps(eng, batches, max(2, args.warmup), row0, batch_total)
         if lib.brProbeEnable(4 * args.steps) != 0:
             raise RuntimeError(lib.brGetLastError().decode())
@@ -300,10 +305,10 @@ def main():
         gpu_us_per_step += v["us"] * v["launches"] / nsteps
 
     # dominant kernel of the step
-    if args.optimizer == "adam_dense":
+    if args.optimizer == "adam_dense" and not eng.deferred:
         dom_key, dom_name = f"adam_dense_sweep[user {loc_users}x{2 * D}]", "adam_dense_sweep_kernel"
     else:
-        dom_key, dom_name = f"dense_bwd[{2 * D}x{n1}]", "dense_bwd_kernel"
+        dom_key, dom_name = f"dense_bwd[{2 * D}x{n1}]", "dense_dx_kernel+dense_dw_kernel"
     dom = kernels.get(dom_key)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -323,9 +328,46 @@ def main():
                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
                         "avg_launch_us": dom["us"], "algorithmic_flop_per_launch": dom["flop"], "measured_in": dom["measured_in"]}
 
-    lazy = None
+    deferred_mode = bool(getattr(eng, "deferred", False))
+    lazy = sweep_leg = flush_info = full_graph = None
+    if use_graph:
+        # the same engine with the WHOLE step in one graph (what a training loop runs; no launch is left
+        # outside, so nothing can be bracketed by events)
+        eng.enable_graph(B)
+        dtg = timed(eng, batches, args.steps, args.warmup, ctx, row0, batch_total)
+        full_graph = {"value": B * args.steps / dtg, "unit": "pairs/s", "ms_per_step": dtg / args.steps * 1e3}
+        log(f"whole-step graph: {dtg / args.steps * 1e3:.3f} ms/step")
+    if deferred_mode and world == 1:
+        # the deferred tables must be flushed at least every BR_ALPHA_RING-8 steps: run up to that point and
+        # time the flush a long job pays there (worst case: every row replays a full ring of steps)
+        period = eng.ALPHA_RING - 8
+        run_steps(eng, batches, max(0, period - 1 - (eng.t - eng._flush_t)), row0, batch_total)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.flush()
+        torch.cuda.synchronize()
+        fl = time.perf_counter() - t0
+        ms = dt / args.steps * 1e3
+        flush_info = {"flush_ms": fl * 1e3, "every_steps": period, "amortized_ms_per_step": fl * 1e3 / period,
+                      "value_including_flush": B * period / (period * ms * 1e-3 + fl), "unit": "pairs/s"}
+        log(f"flush after {period} steps: {fl * 1e3:.2f} ms")
+
+    def extra_leg(optimizer, dense_impl):
+        torch.cuda.empty_cache()
+        e2 = build(optimizer, dense_impl)
+        if use_graph:
+            run_steps(e2, batches, 2, row0, batch_total)
+            e2.enable_graph(B)
+        d2 = timed(e2, batches, args.steps, args.warmup, ctx, row0, batch_total)
+        del e2
+        return {"value": B * world * args.steps / d2, "unit": "pairs/s", "ms_per_step": d2 / args.steps * 1e3}
+
     if not args.no_lazy and args.optimizer == "adam_dense":
         del eng
+        if deferred_mode:
+            sweep_leg = extra_leg("adam_dense", "sweep")
+            sweep_leg["note"] = "same Keras semantics by sweeping every table row every step (bit-equal tables, tests/test_gpu_neumf.py)"
+            log(f"adam_dense sweep done: {sweep_leg['ms_per_step']:.3f} ms/step")
         torch.cuda.empty_cache()
         eng2 = build("adam_lazy")
         if use_graph:
@@ -353,10 +395,10 @@ def main():
                                    f"embed_dim={D}, {args.users} users x {args.items} items per GPU, batch {B} per GPU, "
                                    f"{'Zipf(1.05)' if args.zipf else 'uniform'} ids",
                        "global_batch": batch_total, "parallelism": "single GPU" if world == 1 else f"row-sharded tables x{world} + dp{world}",
-                       "optimizer": args.optimizer},
-            "roofline": roofline, "cpu_baseline": cpu, "adam_lazy": lazy, "gpu_kernel_us_per_step": gpu_us_per_step,
-            "launch_mode": ("hipGraph replay (graph A -> eager adam_dense_sweep[user] with HIP events -> graph B)" if use_graph and args.optimizer == "adam_dense"
-                            else "hipGraph replay" if use_graph else "eager launches (brNeumfStepRun)"),
+                       "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
+            "roofline": roofline, "cpu_baseline": cpu, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
+            "launch_mode": (f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)" if use_graph
+                            else "eager launches (brNeumfStepRun)"),
             "eager": eager_profile,
             "kernels": kernels,
         }

@@ -4,6 +4,7 @@
 // independent 16-B loads in flight; 4096+ workgroups at batch 65 536 to fill 256 CUs.
 #include "common.h"
 #include "rows.h"
+#include "adam_math.h"
 
 namespace br {
 
@@ -111,6 +112,82 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_kernel(
   }
   s = rowgroup_sum(s, lpr);
   if (live && lir == 0) dot[b] = s;
+}
+
+// Deferred-Adam variant of the embed forward on the FUSED tables (row = [mlp | mf], stride 2*dim): rows lag
+// behind by the g = 0 steps (last[row], t-1]; they are replayed in registers (adam_math.h) and NOT written
+// back (duplicate ids in a batch would race) — brAdamRowsSortedDeferred does the authoritative update of
+// the unique rows later in the step.  The caught-up MF halves are stashed per pair for the backward.
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void neumf_embed_fwd_deferred_kernel(
+    const float* __restrict__ user_tab, const float* __restrict__ user_m, const float* __restrict__ user_v,
+    const int32_t* __restrict__ user_last, const float* __restrict__ item_tab, const float* __restrict__ item_m,
+    const float* __restrict__ item_v, const int32_t* __restrict__ item_last, int64_t user_rows, int64_t item_rows,
+    const IdT* __restrict__ users, const IdT* __restrict__ items, int dim, int chunks, int lpr_log2, int64_t batch,
+    int item_first, const StepStateDev* __restrict__ ss, AdamHp h, float* __restrict__ x0, float* __restrict__ dot,
+    float* __restrict__ stash_user, float* __restrict__ stash_item, int64_t ld_stash, int* err) {
+  using V = typename VecT<VEC>::type;
+  __shared__ float ring[BR_ALPHA_RING];
+  stage_alpha_ring(ring, ss);
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  const bool live = b < batch;
+  if (!live) b = batch - 1;
+  int64_t u = load_id(users, b), i = load_id(items, b);
+  const bool uok = (uint64_t)u < (uint64_t)user_rows, iok = (uint64_t)i < (uint64_t)item_rows;
+  if ((!uok || !iok) && err && lir == 0) *err = 1;
+  if (!uok) u = 0;
+  if (!iok) i = 0;
+  const uint32_t t = ss->step;                       // the step being computed: rows must include steps <= t-1
+  const uint32_t lu = (uint32_t)user_last[u], li = (uint32_t)item_last[i];
+  const int64_t ld = 2 * (int64_t)dim;
+  float* xrow = x0 + b * ld;
+  const int uoff = item_first ? dim : 0, ioff = item_first ? 0 : dim;
+  float s = 0.f;
+  for (int c = lir; c < chunks; c += lpr) {
+    const int64_t uo = u * ld + c * VEC, io = i * ld + c * VEC;
+    V um = vload<VEC>(user_tab + uo), uf = vload<VEC>(user_tab + uo + dim);
+    V im = vload<VEC>(item_tab + io), vf = vload<VEC>(item_tab + io + dim);
+    if (lu + 1 < t) {
+      V m0 = vload<VEC>(user_m + uo), v0 = vload<VEC>(user_v + uo), m1 = vload<VEC>(user_m + uo + dim), v1 = vload<VEC>(user_v + uo + dim);
+      adam_replay(um, m0, v0, lu, t - 1, ring, h);
+      adam_replay(uf, m1, v1, lu, t - 1, ring, h);
+    }
+    if (li + 1 < t) {
+      V m0 = vload<VEC>(item_m + io), v0 = vload<VEC>(item_v + io), m1 = vload<VEC>(item_m + io + dim), v1 = vload<VEC>(item_v + io + dim);
+      adam_replay(im, m0, v0, li, t - 1, ring, h);
+      adam_replay(vf, m1, v1, li, t - 1, ring, h);
+    }
+    if (!uok) { um = vzero<VEC>(); uf = vzero<VEC>(); }
+    if (!iok) { im = vzero<VEC>(); vf = vzero<VEC>(); }
+    if (live) {
+      vstore<VEC>(xrow + uoff + c * VEC, um);
+      vstore<VEC>(xrow + ioff + c * VEC, im);
+      vstore<VEC>(stash_user + b * ld_stash + c * VEC, uf);
+      vstore<VEC>(stash_item + b * ld_stash + c * VEC, vf);
+    }
+    s += vdot(uf, vf);
+  }
+  s = rowgroup_sum(s, lpr);
+  if (live && lir == 0) dot[b] = s;
+}
+
+// B1 of the GMF dot on the stashed MF rows, in place: (u, i) -> (ddot * i, ddot * u).  No __restrict__: the
+// two outputs ARE the two inputs.
+template <int VEC>
+__global__ __launch_bounds__(256) void mf_grad_inplace_kernel(float* su, float* si, int64_t ld, const float* __restrict__ ddot,
+                                                               int64_t batch, int chunks) {
+  using V = typename VecT<VEC>::type;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= batch * chunks) return;
+  const int64_t b = e / chunks;
+  const int c = (int)(e - b * chunks);
+  const float g = ddot[b];
+  const V u = vload<VEC>(su + b * ld + c * VEC), i = vload<VEC>(si + b * ld + c * VEC);
+  vstore<VEC>(su + b * ld + c * VEC, vmul(i, g));
+  vstore<VEC>(si + b * ld + c * VEC, vmul(u, g));
 }
 
 template <typename IdT, int VEC>
@@ -312,6 +389,47 @@ extern "C" int brNeumfEmbedForward(const float* user_mlp, const float* item_mlp,
                                (const int64_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag)));
   }
   BR_CHECK_LAUNCH("brNeumfEmbedForward");
+  return BR_OK;
+}
+
+extern "C" int brNeumfEmbedForwardDeferred(const float* user_tab, const float* user_m, const float* user_v, const int32_t* user_last,
+                                           const float* item_tab, const float* item_m, const float* item_v, const int32_t* item_last,
+                                           int64_t user_rows, int64_t item_rows, const void* users, const void* items, int id_type,
+                                           int dim, int64_t batch, int item_first, const void* step_state, double beta1, double beta2,
+                                           double eps, float* x0, float* dot, float* stash_user, float* stash_item, int64_t ld_stash,
+                                           int* err_flag, brStream stream) {
+  BR_CHECK_ARG(user_tab && user_m && user_v && user_last && item_tab && item_m && item_v && item_last && step_state && x0 && dot &&
+                   stash_user && stash_item, "brNeumfEmbedForwardDeferred: null pointer");
+  BR_CHECK_ARG(dim >= 1 && batch >= 0 && user_rows > 0 && item_rows > 0 && ld_stash >= dim, "brNeumfEmbedForwardDeferred: bad sizes");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brNeumfEmbedForwardDeferred: bad id_type");
+  if (batch == 0) return BR_OK;
+  const RowGeom g = row_geom_ld(dim, ld_stash % 4 == 0 ? 4 : ld_stash % 2 == 0 ? 2 : 1);
+  const unsigned grid = grid_for_rows(batch, g.lpr_log2);
+  const AdamHp h = make_hp(0.0, beta1, beta2, eps);
+  const StepStateDev* ss = (const StepStateDev*)step_state;
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32) {
+    BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_deferred_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
+                               user_tab, user_m, user_v, user_last, item_tab, item_m, item_v, item_last, user_rows, item_rows,
+                               (const int32_t*)users, (const int32_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, ss, h, x0, dot,
+                               stash_user, stash_item, ld_stash, err_flag)));
+  } else {
+    BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_deferred_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
+                               user_tab, user_m, user_v, user_last, item_tab, item_m, item_v, item_last, user_rows, item_rows,
+                               (const int64_t*)users, (const int64_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, ss, h, x0, dot,
+                               stash_user, stash_item, ld_stash, err_flag)));
+  }
+  BR_CHECK_LAUNCH("brNeumfEmbedForwardDeferred");
+  return BR_OK;
+}
+
+extern "C" int brMfGradInplace(float* stash_user, float* stash_item, int64_t ld, const float* ddot, int64_t batch, int dim, brStream stream) {
+  BR_CHECK_ARG(stash_user && stash_item && ddot && dim >= 1 && ld >= dim && batch >= 0, "brMfGradInplace: bad args");
+  if (batch == 0) return BR_OK;
+  const RowGeom g = row_geom_ld(dim, ld % 4 == 0 ? 4 : ld % 2 == 0 ? 2 : 1);
+  const unsigned grid = (unsigned)ceil_div(batch * g.chunks, 256);
+  BR_DISPATCH_VEC(g.vec, (mf_grad_inplace_kernel<VEC><<<grid, 256, 0, (hipStream_t)stream>>>(stash_user, stash_item, ld, ddot, batch, g.chunks)));
+  BR_CHECK_LAUNCH("brMfGradInplace");
   return BR_OK;
 }
 

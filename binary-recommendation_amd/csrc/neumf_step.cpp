@@ -96,6 +96,8 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const int D = s->dim, n1 = s->n1, n2 = s->n2, n3 = s->n3;
   BR_CHECK_ARG(B > 0 && D >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1 && n3 <= 32, "brNeumfStepRun: bad geometry");
   const bool train = s->training != 0;
+  const bool deferred = s->adam_dense == 2;
+  BR_CHECK_ARG(!deferred || (s->step_state && s->user_last && s->item_last), "brNeumfStepRun: deferred Adam needs step_state and the last[] arrays");
   const float p = train ? s->dropout : 0.f;
   const double bt = (double)(s->batch_total > 0 ? s->batch_total : B);
   const float inv_b = (float)(1.0 / bt);
@@ -124,7 +126,9 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   float *mm1 = s->moving, *mv1 = mm1 + n1, *mm2 = mv1 + n1, *mv2 = mm2 + n2;
   const int uoff = s->item_first ? D : 0, ioff = s->item_first ? 0 : D;
   // dedup sorts on the aux stream: forked at the top of the step, joined before the Adam-rows kernels
-  const bool aux_index = train && s->aux_stream && (ph & BR_PH_FWD1) && (ph & BR_PH_OPT_TABLES) && (ph & BR_PH_EMBED);
+  const bool build_index = train && (ph & BR_PH_INDEX);
+  const bool aux_index = build_index && s->aux_stream && (ph & BR_PH_FWD1);
+  bool joined = !aux_index;
   if (aux_index) {
     if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
     hipStream_t as = (hipStream_t)s->aux_stream;
@@ -142,7 +146,11 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(BR_STAT_REPLICAS * (4 * n1 + 4 * n2)), hs);
       if (e != hipSuccess) { br::set_error("brNeumfStepRun: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
     }
-    if (ph & BR_PH_EMBED)
+    if ((ph & BR_PH_EMBED) && deferred && train)
+      RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForwardDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->item_tab, s->item_m, s->item_v, s->item_last,
+                              s->user_rows, s->item_rows, s->users, s->items, s->id_type, D, B, s->item_first, s->step_state, s->beta1, s->beta2,
+                              s->adam_eps, s->x0, s->dot, s->g_user + D, s->g_item + D, 2 * D, s->err_flag, stream));
+    else if (ph & BR_PH_EMBED)   /* deferred + inference: the host flushed the tables (brAdamFlush) first */
       RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForward(s->user_tab, s->item_tab, s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows,
                               s->users, s->items, s->id_type, D, B, s->item_first, s->x0, s->dot, s->err_flag, stream));
     RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, n1, B, 2 * D, n1, s->act, nullptr, nullptr, p, s->seed,
@@ -195,31 +203,42 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     RUN(BR_TAG_SMALL, brBnParamGrads(bsum1, gr + og1, gr + obe1, n1, stream));
   }
   if (ph & BR_PH_OPT_TABLES) {
-    if (ph & BR_PH_EMBED)
+    if ((ph & BR_PH_EMBED) && deferred)
+      RUN(BR_TAG_EMBED_BWD, brMfGradInplace(s->g_user + D, s->g_item + D, 2 * D, s->ddot, B, D, stream));
+    else if (ph & BR_PH_EMBED)
       RUN(BR_TAG_EMBED_BWD, brNeumfEmbedBackward(s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows, s->users, s->items, s->id_type, D,
                                B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, stream));
-    if (aux_index) {
-      (void)hipStreamWaitEvent(hs, g_join, 0);
-    } else {
-      RUN(BR_TAG_INDEX_USER, brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, stream));
-      RUN(BR_TAG_INDEX_ITEM, brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, stream));
-    }
+  }
+  if (build_index && !aux_index) {
+    RUN(BR_TAG_INDEX_USER, brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, stream));
+    RUN(BR_TAG_INDEX_ITEM, brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, stream));
+  }
+  if (!joined && (ph & (BR_PH_ROWS_USER | BR_PH_ROWS_ITEM))) {
+    (void)hipStreamWaitEvent(hs, g_join, 0);
+    joined = true;
   }
   {
-    uint8_t* um = s->adam_dense ? s->user_mark : nullptr;
-    uint8_t* im = s->adam_dense ? s->item_mark : nullptr;
-    if (ph & BR_PH_ROWS_USER)
+    uint8_t* um = s->adam_dense == 1 ? s->user_mark : nullptr;
+    uint8_t* im = s->adam_dense == 1 ? s->item_mark : nullptr;
+    if ((ph & BR_PH_ROWS_USER) && deferred)
+      RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type,
+                           s->u_sorted_pos, B, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, stream));
+    else if (ph & BR_PH_ROWS_USER)
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSorted(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type, s->u_sorted_pos, B,
                            s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
-    if ((ph & BR_PH_SWEEP_USER) && s->adam_dense)
+    if ((ph & BR_PH_SWEEP_USER) && s->adam_dense == 1)
       RUN(BR_TAG_SWEEP_USER, brAdamDenseSweep(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
-    if (ph & BR_PH_ROWS_ITEM)
+    if ((ph & BR_PH_ROWS_ITEM) && deferred)
+      RUN(BR_TAG_ADAM_ROWS_ITEM, brAdamRowsSortedDeferred(s->item_tab, s->item_m, s->item_v, s->item_last, s->item_rows, 2 * D, s->i_sorted_ids, s->id_type,
+                           s->i_sorted_pos, B, s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, stream));
+    else if (ph & BR_PH_ROWS_ITEM)
       RUN(BR_TAG_ADAM_ROWS_ITEM, brAdamRowsSorted(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->i_sorted_ids, s->id_type, s->i_sorted_pos, B,
                            s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
-    if ((ph & BR_PH_SWEEP_ITEM) && s->adam_dense)
+    if ((ph & BR_PH_SWEEP_ITEM) && s->adam_dense == 1)
       RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
   }
   if (ph & BR_PH_OPT_DENSE)
     RUN(BR_TAG_ADAM_FLAT, brAdamFlat(th, s->adam_m, s->adam_v, gr, n_dense, s->alpha_t, s->beta1, s->beta2, s->adam_eps, stream));
+  if (!joined) (void)hipStreamWaitEvent(hs, g_join, 0);   // the consumers run in a later call: join the sorts here
   return BR_OK;
 }

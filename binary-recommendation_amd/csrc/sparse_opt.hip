@@ -9,7 +9,9 @@
 // read back here through the inverted index (cdna_hip_programming.md App. B "Scatter / gather").
 #include "common.h"
 #include "rows.h"
+#include "adam_math.h"
 
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 
 namespace br {
@@ -47,30 +49,6 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const IdT* __restrict_
   }
 }
 
-struct AdamHp {
-  float alpha, b1, omb1, b2, omb2, eps;
-  const float* alpha_ptr;   // non-null: alpha_t lives in device memory (hipGraph replays)
-};
-__device__ __forceinline__ void adam_resolve(AdamHp& h) {
-  if (h.alpha_ptr) h.alpha = *h.alpha_ptr;
-}
-
-__device__ __forceinline__ void adam_update1(float& th, float& m, float& v, float g, const AdamHp& h) {
-  m = h.b1 * m + h.omb1 * g;
-  v = h.b2 * v + h.omb2 * (g * g);
-  th = th - h.alpha * m / (sqrtf(v) + h.eps);
-}
-__device__ __forceinline__ void adam_update(float4& th, float4& m, float4& v, float4 g, const AdamHp& h) {
-  adam_update1(th.x, m.x, v.x, g.x, h); adam_update1(th.y, m.y, v.y, g.y, h);
-  adam_update1(th.z, m.z, v.z, g.z, h); adam_update1(th.w, m.w, v.w, g.w, h);
-}
-__device__ __forceinline__ void adam_update(float2& th, float2& m, float2& v, float2 g, const AdamHp& h) {
-  adam_update1(th.x, m.x, v.x, g.x, h); adam_update1(th.y, m.y, v.y, g.y, h);
-}
-__device__ __forceinline__ void adam_update(float& th, float& m, float& v, float g, const AdamHp& h) {
-  adam_update1(th, m, v, g, h);
-}
-
 // Row gradients may come from two buffers: columns [0,split) from g0, [split,dim) from g1 (the fused
 // NeuMF tables [mlp | mf] take their MLP half from dx0 and their MF half from the embed backward).
 template <typename IdT, int VEC>
@@ -80,8 +58,11 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict
                                                                 const int32_t* __restrict__ spos, int64_t n,
                                                                 const float* __restrict__ g0, int64_t ldg0,
                                                                 const float* __restrict__ g1, int64_t ldg1, int split,
-                                                                AdamHp h, uint8_t* __restrict__ mark) {
+                                                                AdamHp h, uint8_t* __restrict__ mark,
+                                                                int32_t* __restrict__ last, const StepStateDev* __restrict__ ss) {
   using V = typename VecT<VEC>::type;
+  __shared__ float ring[BR_ALPHA_RING];
+  if (last) stage_alpha_ring(ring, ss);      // uniform branch: whole workgroup
   adam_resolve(h);
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,6 +73,9 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict
   const int64_t row = (int64_t)sid[i];
   if ((uint64_t)row >= (uint64_t)table_rows) return;  // out-of-range ids were flagged by the forward
   if (mark && lir == 0) mark[row] = 1;
+  // deferred mode: this row includes the steps <= last[row]; replay the g = 0 steps up to t-1 first
+  const uint32_t t = last ? ss->step : 0u;
+  const uint32_t seen = last ? (uint32_t)last[row] : 0u;
   for (int c = lir; c < chunks; c += lpr) {
     const int col = c * VEC;
     const float* g = col < split ? g0 + col : g1 + (col - split);
@@ -100,11 +84,42 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict
     for (int64_t j = i + 1; j < n && (int64_t)sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg));
     const int64_t off = row * dim + col;
     V th = vload<VEC>(table + off), m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
+    if (last && seen + 1 < t) adam_replay(th, m, v, seen, t - 1, ring, h);
     adam_update(th, m, v, acc, h);
     vstore<VEC>(table + off, th);
     vstore<VEC>(M + off, m);
     vstore<VEC>(Vv + off, v);
   }
+  if (last && lir == 0) last[row] = (int32_t)t;
+}
+
+// Deferred mode, whole table: bring every row up to the current step (inclusive) — before the table is
+// read by anything but the catch-up gather (inference, checkpoint), and at least once per BR_ALPHA_RING steps.
+template <int VEC>
+__global__ __launch_bounds__(256) void adam_flush_kernel(float* __restrict__ table, float* __restrict__ M, float* __restrict__ Vv,
+                                                          int64_t n_vec, int chunks, AdamHp h, int32_t* __restrict__ last,
+                                                          const StepStateDev* __restrict__ ss) {
+  using V = typename VecT<VEC>::type;
+  __shared__ float ring[BR_ALPHA_RING];
+  stage_alpha_ring(ring, ss);
+  const uint32_t t = ss->step;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_vec; e += stride) {
+    const int64_t row = e / chunks;
+    const uint32_t seen = (uint32_t)last[row];
+    if (seen >= t) continue;
+    V m = vload<VEC>(M + e * VEC), v = vload<VEC>(Vv + e * VEC);
+    if (all_zero(m) && all_zero(v)) continue;
+    V th = vload<VEC>(table + e * VEC);
+    adam_replay(th, m, v, seen, t, ring, h);
+    vstore<VEC>(table + e * VEC, th);
+    vstore<VEC>(M + e * VEC, m);
+    vstore<VEC>(Vv + e * VEC, v);
+  }
+}
+__global__ __launch_bounds__(256) void fill_last_kernel(int32_t* __restrict__ last, int64_t rows, const StepStateDev* __restrict__ ss) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) last[i] = (int32_t)ss->step;
 }
 
 // Dense sweep: all rows NOT marked get the zero-gradient update.  float4 streaming,
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(256) void adam_dense_sweep_kernel(float* __restrict
     const int64_t row = e / chunks;
     if (mark && mark[row]) continue;
     V th = vload<VEC>(table + e * VEC), m = vload<VEC>(M + e * VEC), v = vload<VEC>(Vv + e * VEC);
-    adam_update(th, m, v, vzero<VEC>(), h);
+    adam_decay(th, m, v, h.alpha, h);
     vstore<VEC>(table + e * VEC, th);
     vstore<VEC>(M + e * VEC, m);
     vstore<VEC>(Vv + e * VEC, v);
@@ -197,20 +212,9 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ gt
 __global__ void step_state_advance_kernel(StepStateDev* st, double lr, double b1, double b2) {
   const uint32_t t = st->step + 1;
   st->step = t;
-  st->alpha_t = (float)(lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
-}
-
-static inline AdamHp make_hp(double alpha, double b1, double b2, double eps) {
-  AdamHp h;
-  h.alpha = (float)alpha;
-  h.b1 = (float)b1;
-  h.omb1 = (float)(1.0 - b1);
-  h.b2 = (float)b2;
-  h.omb2 = (float)(1.0 - b2);
-  h.eps = (float)eps;
-  const StepStateDev* ss = current_step_state();
-  h.alpha_ptr = ss ? &ss->alpha_t : nullptr;
-  return h;
+  const float a = (float)(lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
+  st->alpha_t = a;
+  st->alpha_hist[t & (BR_ALPHA_RING - 1)] = a;
 }
 
 static inline int bits_for(int64_t upper) {
@@ -308,10 +312,10 @@ extern "C" int brScatterAddRows(float* g_table, int64_t table_rows, const void* 
   return BR_OK;
 }
 
-extern "C" int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int dim, const void* sorted_ids,
-                                int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
-                                const float* row_grads_hi, int64_t ldg_hi, int split, double alpha_t, double beta1,
-                                double beta2, double eps, uint8_t* mark, brStream stream) {
+static int adam_rows_launch(float* table, float* m, float* v, int64_t table_rows, int dim, const void* sorted_ids,
+                            int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
+                            const float* row_grads_hi, int64_t ldg_hi, int split, double alpha_t, double beta1,
+                            double beta2, double eps, uint8_t* mark, int32_t* last, const StepStateDev* ss, brStream stream) {
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdamRowsSorted: bad id_type");
   if (n == 0) return BR_OK;
   BR_CHECK_ARG(table && m && v && sorted_ids && sorted_pos && row_grads && dim >= 1 && table_rows > 0, "brAdamRowsSorted: bad args");
@@ -323,17 +327,51 @@ extern "C" int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_
                   : (ldg % 2 == 0 && ldg_hi % 2 == 0 && split % 2 == 0 && (al & 7) == 0) ? 2 : 1;
   const RowGeom g = row_geom_ld(dim, ldmin);
   const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
-  const AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
+  AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
+  if (ss) h.alpha_ptr = &ss->alpha_t;
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
                                table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int32_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark)));
+                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark, last, ss)));
   else
     BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
                                table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int64_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark)));
+                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark, last, ss)));
   BR_CHECK_LAUNCH("brAdamRowsSorted");
+  return BR_OK;
+}
+
+extern "C" int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int dim, const void* sorted_ids,
+                                int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
+                                const float* row_grads_hi, int64_t ldg_hi, int split, double alpha_t, double beta1,
+                                double beta2, double eps, uint8_t* mark, brStream stream) {
+  return adam_rows_launch(table, m, v, table_rows, dim, sorted_ids, id_type, sorted_pos, n, row_grads, ldg, row_grads_hi, ldg_hi,
+                          split, alpha_t, beta1, beta2, eps, mark, nullptr, nullptr, stream);
+}
+
+extern "C" int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,
+                                        const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                                        const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
+                                        const void* step_state, double beta1, double beta2, double eps, brStream stream) {
+  BR_CHECK_ARG(last && step_state, "brAdamRowsSortedDeferred: last / step_state missing");
+  return adam_rows_launch(table, m, v, table_rows, dim, sorted_ids, id_type, sorted_pos, n, row_grads, ldg, row_grads_hi, ldg_hi,
+                          split, 0.0, beta1, beta2, eps, nullptr, last, (const StepStateDev*)step_state, stream);
+}
+
+extern "C" int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,
+                           double beta1, double beta2, double eps, brStream stream) {
+  BR_CHECK_ARG(table && m && v && last && step_state && dim >= 1 && table_rows > 0, "brAdamFlush: bad args");
+  const RowGeom g = row_geom(dim);
+  const int64_t n_vec = table_rows * g.chunks;
+  const int64_t blocks = std::min<int64_t>(ceil_div(n_vec, 256), 256 * 16);
+  const AdamHp h = make_hp(0.0, beta1, beta2, eps);
+  const StepStateDev* ss = (const StepStateDev*)step_state;
+  hipStream_t s = (hipStream_t)stream;
+  BR_DISPATCH_VEC(g.vec, (adam_flush_kernel<VEC><<<(unsigned)blocks, 256, 0, s>>>(table, m, v, n_vec, g.chunks, h, last, ss)));
+  BR_CHECK_LAUNCH("brAdamFlush");
+  fill_last_kernel<<<(unsigned)ceil_div(table_rows, 256), 256, 0, s>>>(last, table_rows, ss);
+  BR_CHECK_LAUNCH("brAdamFlush(last)");
   return BR_OK;
 }
 
@@ -397,6 +435,8 @@ extern "C" int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n
   BR_CHECK_LAUNCH("brAdagradFlat");
   return BR_OK;
 }
+
+extern "C" int64_t brStepStateBytes(void) { return (int64_t)sizeof(StepStateDev); }
 
 extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream) {
   BR_CHECK_ARG(step_state != nullptr, "brStepStateAdvance: null state");

@@ -39,12 +39,16 @@ class NeuMFConfig:
     adam_eps: float = 1e-7
     optimizer: str = "adam_dense"       # "adam_dense" = Keras semantics (non-lazy sparse apply);
                                         # "adam_lazy"  = touched rows only (throughput deviation)
+    dense_impl: str = "deferred"        # how adam_dense reaches the untouched rows: "deferred" = per-row catch-up
+                                        # replay (same values, no per-step table sweep; include/binrec.h
+                                        # "Deferred dense Adam"), "sweep" = one pass over the table per step
     seed: int = 0x5EED
     sync_bn: bool = True                # data-parallel: batch statistics over the GLOBAL batch
 
     def __post_init__(self):
         assert self.variant in ("A", "B")
         assert self.optimizer in ("adam_dense", "adam_lazy")
+        assert self.dense_impl in ("deferred", "sweep")
         if self.variant == "A":
             self.hidden = tuple(self.hidden) if self.hidden else (100, 50, 10)
             self.act, self.item_first, self.mf_first, self.loss = "sigmoid", 1, 1, "bce"
@@ -98,7 +102,9 @@ class NeuMFEngine:
         dev = self.device
         g = torch.Generator(device="cpu").manual_seed(init_seed)
         # [TF-sem] Embedding init U(-0.05, 0.05); Dense glorot-uniform; bias 0; BN gamma 1 beta 0
-        self.tables = {}
+        self.deferred = cfg.optimizer == "adam_dense" and cfg.dense_impl == "deferred" and not self.sharded
+        self._stale = False                   # deferred: rows lag behind self.t until flush()
+        self._flush_t = 0
         self._init_tables(g, init_seed)
         self.theta = _Flat(cfg.dense_shapes(), dev)
         for k, (_, _, shp) in self.theta.offsets.items():
@@ -113,10 +119,10 @@ class NeuMFEngine:
         self.adam_v = _Flat(cfg.dense_shapes(), dev)
         self.fused_m = {k: torch.zeros_like(v) for k, v in self.fused.items()}
         self.fused_v = {k: torch.zeros_like(v) for k, v in self.fused.items()}
-        self.tab_m = {"user_mlp": self.fused_m["user"][:, :D], "user_mf": self.fused_m["user"][:, D:],
-                      "item_mlp": self.fused_m["item"][:, :D], "item_mf": self.fused_m["item"][:, D:]}
-        self.tab_v = {"user_mlp": self.fused_v["user"][:, :D], "user_mf": self.fused_v["user"][:, D:],
-                      "item_mlp": self.fused_v["item"][:, :D], "item_mf": self.fused_v["item"][:, D:]}
+        self._tab_m = {"user_mlp": self.fused_m["user"][:, :D], "user_mf": self.fused_m["user"][:, D:],
+                       "item_mlp": self.fused_m["item"][:, :D], "item_mf": self.fused_m["item"][:, D:]}
+        self._tab_v = {"user_mlp": self.fused_v["user"][:, :D], "user_mf": self.fused_v["user"][:, D:],
+                       "item_mlp": self.fused_v["item"][:, :D], "item_mf": self.fused_v["item"][:, D:]}
         self.moving_buf = torch.zeros(2 * n1 + 2 * n2, device=dev)      # [mm1 | mv1 | mm2 | mv2]
         self.moving = {"mm1": self.moving_buf[:n1], "mv1": self.moving_buf[n1:2 * n1],
                        "mm2": self.moving_buf[2 * n1:2 * n1 + n2], "mv2": self.moving_buf[2 * n1 + n2:]}
@@ -147,8 +153,37 @@ class NeuMFEngine:
 
     def _make_views(self):
         D = self.cfg.dim
-        self.tables = {"user_mlp": self.fused["user"][:, :D], "user_mf": self.fused["user"][:, D:],
-                       "item_mlp": self.fused["item"][:, :D], "item_mf": self.fused["item"][:, D:]}
+        self._tables = {"user_mlp": self.fused["user"][:, :D], "user_mf": self.fused["user"][:, D:],
+                        "item_mlp": self.fused["item"][:, :D], "item_mf": self.fused["item"][:, D:]}
+
+    # the four reference tables / their Adam slots as column views; reading them brings a deferred table up
+    # to date first (self.fused* are the raw buffers)
+    @property
+    def tables(self):
+        self.flush()
+        return self._tables
+
+    @property
+    def tab_m(self):
+        self.flush()
+        return self._tab_m
+
+    @property
+    def tab_v(self):
+        self.flush()
+        return self._tab_v
+
+    def flush(self):
+        """Deferred dense Adam: apply the pending g = 0 steps to every row (brAdamFlush).  No-op otherwise."""
+        if not (self.deferred and self._stale):
+            return
+        cfg, lib = self.cfg, _lib.load()
+        for k in ("user", "item"):
+            t = self.fused[k]
+            _lib.check(lib.brAdamFlush(t.data_ptr(), self.fused_m[k].data_ptr(), self.fused_v[k].data_ptr(), self.last[k].data_ptr(),
+                                       t.shape[0], t.shape[1], self.step_state.data_ptr(), cfg.beta1, cfg.beta2, cfg.adam_eps, ops._stream()),
+                       "brAdamFlush")
+        self._stale, self._flush_t = False, self.t
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, B):
@@ -200,15 +235,18 @@ class NeuMFEngine:
         st.act, st.loss = ops.ACT[cfg.act], ops.LOSS[cfg.loss]
         st.item_first, st.mf_first = cfg.item_first, cfg.mf_first
         st.id_type = ops.I64 if self.id_dtype == torch.int64 else ops.I32
-        st.adam_dense = 1 if cfg.optimizer == "adam_dense" else 0
+        st.adam_dense = 2 if self.deferred else 1 if cfg.optimizer == "adam_dense" else 0
         st.dropout, st.bn_eps, st.bn_momentum = cfg.dropout, cfg.bn_eps, cfg.bn_momentum
         st.seed = cfg.seed
         st.beta1, st.beta2, st.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
         P = lambda t: t.data_ptr()
         st.user_tab, st.user_m, st.user_v = P(self.fused["user"]), P(self.fused_m["user"]), P(self.fused_v["user"])
         st.item_tab, st.item_m, st.item_v = P(self.fused["item"]), P(self.fused_m["item"]), P(self.fused_v["item"])
-        if st.adam_dense:
+        if st.adam_dense == 1:
             st.user_mark, st.item_mark = P(self.user_mark), P(self.item_mark)
+        if self.deferred:
+            st.user_last, st.item_last = P(self.last["user"]), P(self.last["item"])
+            self._alloc_step_state(st)
         st.theta, st.grad, st.adam_m, st.adam_v = P(self.theta.buf), P(self.grad.buf), P(self.adam_m.buf), P(self.adam_v.buf)
         st.moving = P(self.moving_buf)
         for k in ("x0", "dot", "a1", "a2", "a3", "logit", "prob", "da3", "ddot", "gh2", "gh1", "dx0", "g_user", "g_item"):
@@ -249,10 +287,20 @@ class NeuMFEngine:
         dev = self.device
         self.user_index = ops.RowIndex(B, self.id_dtype, dev)
         self.item_index = ops.RowIndex(B, self.id_dtype, dev)
-        if self.cfg.optimizer == "adam_dense":
+        if self.deferred:
+            self.last = {k: torch.zeros(self.local_rows(k + "_mf"), dtype=torch.int32, device=dev) for k in ("user", "item")}
+        elif self.cfg.optimizer == "adam_dense":
             self.user_mark = torch.zeros(self.local_rows("user_mf"), dtype=torch.uint8, device=dev)
             self.item_mark = torch.zeros(self.local_rows("item_mf"), dtype=torch.uint8, device=dev)
 
+    def _alloc_step_state(self, st):
+        """device step state (include/binrec.h brStepStateBytes): {step, alpha_t, alpha ring}."""
+        if getattr(self, "step_state", None) is None:
+            self.step_state = torch.zeros(_lib.load().brStepStateBytes() // 4, dtype=torch.int32, device=self.device)
+        st.lr, st.step_state = self.cfg.lr, self.step_state.data_ptr()
+        self._sync_step_state()
+
+    ALPHA_RING = _lib.parse_enums()["BR_ALPHA_RING"]
     sharded = False   # the row-sharded subclass runs its own embed exchange (parallel.py)
 
     def _embed_forward(self, users, items, B):
@@ -270,6 +318,10 @@ class NeuMFEngine:
         if B == 0:
             return
         batch_total = B if batch_total is None else batch_total
+        if self.deferred:
+            if self.t + 1 - self._flush_t >= self.ALPHA_RING - 8:      # the replay reads alpha_j from a ring
+                self.flush()
+            self._stale = True
         self.t += 1
         if self._graph is not None and B == self._graph["batch"] and row0 == 0 and batch_total == B:
             self._replay(users, items, labels)
@@ -305,19 +357,23 @@ class NeuMFEngine:
         if self.sharded:
             self._embed_backward_apply(users, items, B)
         else:
-            self._run(PH["OPT_TABLES"] | PH["EMBED"] | PH["OPT_ROWS"])
+            self._run(PH["OPT_TABLES"] | PH["EMBED"] | PH["INDEX"] | PH["OPT_ROWS"])
         self._run(PH["OPT_DENSE"])
 
     # ------------------------------------------------------------------ hipGraph replay of the step
-    def enable_graph(self, batch: int | None = None, eager_sweep: bool = False):
+    PHASE_ORDER = ("FWD1", "FWD2", "FWD3", "BWD2", "BWD1", "BNG", "OPT_TABLES", "ROWS_USER", "SWEEP_USER", "ROWS_ITEM",
+                   "SWEEP_ITEM", "OPT_DENSE")
+
+    def enable_graph(self, batch: int | None = None, eager_phases: tuple = ()):
         """Capture the single-GPU training step for batches of exactly `batch` pairs into a hipGraph and
         replay it from `train_step` (other batch sizes keep the eager launch sequence).  The two per-step
         scalars (dropout step counter, Adam alpha_t) then live in device memory (brNeumfStep.step_state)
         and are advanced by a 1-thread kernel at the top of the step; ids/labels are read from the static
         buffers `in_users / in_items / in_labels` (train_step copies into them unless it is handed
         exactly those tensors).
-        eager_sweep: keep the user-table Adam sweep OUTSIDE the graphs (graph A -> eager launch -> graph B)
-        so that HIP events can bracket it; timed events cannot be recorded inside a capture on ROCm 7.2."""
+        eager_phases: consecutive names from PHASE_ORDER that stay OUTSIDE the graphs (graph A -> eager launches
+        -> graph B) so that HIP events can bracket them; timed events cannot be recorded inside a capture on
+        ROCm 7.2 (bench.py keeps its dominant kernel there)."""
         if self.dist is not None:
             raise ValueError("graph replay covers the single-GPU step (collectives run between the phases otherwise)")
         B = self.max_batch if batch is None else int(batch)
@@ -327,8 +383,7 @@ class NeuMFEngine:
         self.in_users = torch.zeros(B, dtype=self.id_dtype, device=dev)
         self.in_items = torch.zeros(B, dtype=self.id_dtype, device=dev)
         self.in_labels = torch.zeros(B, dtype=torch.float32, device=dev)
-        self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)      # {uint32 step; float alpha_t}
-        st.lr, st.step_state = self.cfg.lr, self.step_state.data_ptr()
+        self._alloc_step_state(st)
         # every kernel of the step runs once outside a capture first (code objects load on first launch);
         # the model state is put back afterwards
         keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state_dict().items()}
@@ -341,20 +396,27 @@ class NeuMFEngine:
         self.msums.copy_(keep_sums)
         del keep
         self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, 0, B)
-        if eager_sweep and self.cfg.optimizer == "adam_dense":
-            tail = PH["ROWS_ITEM"] | PH["SWEEP_ITEM"] | PH["OPT_DENSE"]
-            parts = [PH["ALL"] & ~(tail | PH["SWEEP_USER"]), PH["SWEEP_USER"], tail]
+        if eager_phases:
+            order = self.PHASE_ORDER
+            idx = sorted(order.index(n) for n in eager_phases)
+            if idx != list(range(idx[0], idx[-1] + 1)):
+                raise ValueError("eager_phases must be consecutive in PHASE_ORDER")
+            mask = lambda names: sum(PH[n] for n in names)
+            # EMBED modifies FWD1 / OPT_TABLES wherever they land; the dedup sorts go with FWD1 (aux stream)
+            parts = [(mask(order[:idx[0]]), True), (mask(order[idx[0]:idx[-1] + 1]), False), (mask(order[idx[-1] + 1:]), True)]
+            parts = [(m | PH["EMBED"] | (PH["INDEX"] if m & PH["FWD1"] else 0), cap) for m, cap in parts if m]
         else:
-            parts = [PH["ALL"]]
+            parts = [(PH["ALL"], True)]
         graphs = []
-        for i, ph in enumerate(parts):
-            if len(parts) == 3 and i == 1:
+        for ph, cap in parts:
+            if not cap:
                 graphs.append(None)
                 continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._run(ph)
             graphs.append(g)
+        parts = [ph for ph, _ in parts]
         # the capture itself executes nothing, but the dry run above advanced the device step counter
         self._sync_step_state()
         self._graph = {"batch": B, "parts": parts, "graphs": graphs}
@@ -395,7 +457,7 @@ class NeuMFEngine:
 
     def _embed_backward_apply(self, users, items, B):
         """B1 row gradients of the 4 tables, S1 dedup index, O1 Adam on the (fused) tables."""
-        cfg, t, D = self.cfg, self.tables, self.cfg.dim
+        cfg, t, D = self.cfg, self._tables, self.cfg.dim
         ops.neumf_embed_backward(t["user_mf"], t["item_mf"], users, items, cfg.item_first, None, self.ddot[:B],
                                  self.g_user[:B, D:], self.g_item[:B, D:])
         self.user_index.build(users, self.num_user_rows)
@@ -423,6 +485,7 @@ class NeuMFEngine:
     # ------------------------------------------------------------------ inference
     def _infer(self, users, items, labels, n):
         PH = self.PH
+        self.flush()
         self._set_batch(users, items, labels, n, False, 0, n)
         if self.sharded:
             self._embed_forward(users, items, n)
@@ -457,6 +520,7 @@ class NeuMFEngine:
 
     # ------------------------------------------------------------------ state
     def state_dict(self) -> dict:
+        self.flush()
         sd = {"t": self.t, "theta": self.theta.buf, "adam_m": self.adam_m.buf, "adam_v": self.adam_v.buf}
         for k in ("user", "item"):
             sd["table." + k], sd["table." + k + ".m"], sd["table." + k + ".v"] = self.fused[k], self.fused_m[k], self.fused_v[k]
@@ -471,6 +535,10 @@ class NeuMFEngine:
             self.fused[k].copy_(sd["table." + k]); self.fused_m[k].copy_(sd["table." + k + ".m"]); self.fused_v[k].copy_(sd["table." + k + ".v"])
         for k in self.moving:
             self.moving[k].copy_(sd[k])
+        if self.deferred:                   # a checkpoint holds flushed tables: every row includes step t
+            for k in ("user", "item"):
+                self.last[k].fill_(self.t)
+            self._stale, self._flush_t = False, self.t
         self._sync_step_state()
 
     def load_numpy_params(self, p: dict):

@@ -251,7 +251,7 @@ int brTopKRows(const float* scores, int64_t n_users, int64_t n_items, int k, flo
  *   FWD3 BN2 finalize, dense L3, head (+ loss/metric sums, head grads), backward L3 (+ BN2-bwd sums)
  *   BWD2 backward L2 (+ BN1-bwd sums)        BWD1 backward L1
  *   BNG  gamma/beta grads from the BN-backward sums
- *   OPT_TABLES [EMBED] embed backward, dedup index   ROWS_USER / SWEEP_USER / ROWS_ITEM / SWEEP_ITEM the table
+ *   OPT_TABLES [EMBED] embed backward   INDEX the dedup indexes   ROWS_USER / SWEEP_USER / ROWS_ITEM / SWEEP_ITEM the table
  *   optimizer launches (separate bits so a host can keep one of them outside a captured hipGraph)
  *   OPT_DENSE Adam on theta
  * EMBED: include the table-side embed forward/backward (single GPU); cleared by the row-sharded
@@ -260,10 +260,12 @@ int brTopKRows(const float* scores, int64_t n_users, int64_t n_items, int k, flo
  *   [W1 2*dim x n1 | b1 n1 | g1 n1 | be1 n1 | W2 n1 x n2 | b2 n2 | g2 n2 | be2 n2 | W3 n2 x n3 | b3 n3 | W4 n3+1 | b4 1] */
 enum {
   BR_PH_FWD1 = 1, BR_PH_FWD2 = 2, BR_PH_FWD3 = 4, BR_PH_BWD2 = 8, BR_PH_BWD1 = 16, BR_PH_BNG = 32,
-  BR_PH_OPT_TABLES = 64,      /* embed backward + dedup index (or the join of the aux-stream sorts) */
+  BR_PH_OPT_TABLES = 64,      /* [EMBED] embed backward */
   BR_PH_OPT_DENSE = 128, BR_PH_EMBED = 256,
   BR_PH_ROWS_USER = 512, BR_PH_SWEEP_USER = 1024, BR_PH_ROWS_ITEM = 2048, BR_PH_SWEEP_ITEM = 4096,
-  BR_PH_ALL = 8191
+  BR_PH_INDEX = 8192,         /* build the two dedup indexes in this call: on aux_stream beside the forward when the
+                                 call also holds FWD1 (joined before ROWS_* or at the end of the call), else inline */
+  BR_PH_ALL = 16383
 };
 typedef struct brNeumfStep {
   int64_t batch, batch_total, row0, user_rows, item_rows;
@@ -290,16 +292,46 @@ typedef struct brNeumfStep {
   void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;
   void* i_sorted_ids; int32_t* i_sorted_pos; void* i_ws; int64_t i_ws_bytes;
   double lr;          /* learning rate (only used with step_state) */
-  void* step_state;   /* optional device {uint32 step; float alpha_t}: when non-NULL the step advances it in
+  void* step_state;   /* optional device step state (brStepStateBytes()): when non-NULL the step advances it in
                          FWD1 (step += 1, alpha_t = lr*sqrt(1-b2^step)/(1-b1^step)) and every kernel reads the
                          dropout step / Adam alpha from there instead of `step` / `alpha_t` above, so the whole
                          call can be captured once in a hipGraph and replayed */
-  void* aux_stream;   /* optional second hipStream_t: the two dedup sorts depend only on the ids, so with
-                         BR_PH_FWD1|BR_PH_OPT_TABLES in one call they run here beside the forward/backward
-                         and are joined (event) before the Adam-rows kernels; NULL = same stream */
+  int32_t* user_last; int32_t* item_last;   /* [rows], adam_dense == 2 only (deferred dense Adam, see brAdamFlush) */
+  void* aux_stream;   /* optional second hipStream_t: the two dedup sorts depend only on the ids, so a call that
+                         holds BR_PH_INDEX together with BR_PH_FWD1 runs them here beside the forward/backward and
+                         joins them (event) before the Adam-rows kernels; NULL = same stream */
 } brNeumfStep;
-/* step_state (device {uint32 step; float alpha_t}): step += 1, alpha_t = lr*sqrt(1-b2^step)/(1-b1^step). */
+/* step_state: device {uint32 step; float alpha_t; float alpha_hist[BR_ALPHA_RING]}, brStepStateBytes() bytes,
+ * zero-initialised (or step / alpha_t set by the host after a reload).
+ * Advance: step += 1, alpha_t = alpha_hist[step % BR_ALPHA_RING] = lr*sqrt(1-b2^step)/(1-b1^step). */
+enum { BR_ALPHA_RING = 1024 };
+int64_t brStepStateBytes(void);
 int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream);
+
+/* ---- Deferred dense Adam (brNeumfStep.adam_dense == 2) --------------------------------------------------
+ * Keras' Adam applies the g = 0 update to every row of an embedding table on every step ([TF-sem], the
+ * reference's trainers/NFC_plain.py:155 optimizer on Embedding variables): a 6-floats-per-element sweep of the
+ * table per step.  The deferred form produces the SAME values without the sweep: last[row] = last step the
+ * stored (theta, m, v) of that row include; the lookup replays the missing g = 0 steps in registers
+ * (brNeumfEmbedForwardDeferred, nothing written), the optimizer replays them and applies this step's
+ * gradient for the rows of the batch (brAdamRowsSortedDeferred, last[row] = step), and brAdamFlush brings the
+ * whole table to the current step — required before anything else reads the table, and at least every
+ * BR_ALPHA_RING - 1 steps (the replay takes each step's alpha_t from the ring in step_state).
+ * Same fp32 operations in the same order as brAdamDenseSweep => bit-equal tables after a flush. */
+int brNeumfEmbedForwardDeferred(const float* user_tab, const float* user_m, const float* user_v, const int32_t* user_last,
+                                const float* item_tab, const float* item_m, const float* item_v, const int32_t* item_last,
+                                int64_t user_rows, int64_t item_rows, const void* users, const void* items, int id_type,
+                                int dim, int64_t batch, int item_first, const void* step_state, double beta1, double beta2,
+                                double eps, float* x0, float* dot, float* stash_user, float* stash_item, int64_t ld_stash,
+                                int* err_flag, brStream stream);
+/* B1 of the GMF dot on the MF rows the deferred forward stashed, in place: (u_b, i_b) -> (ddot_b i_b, ddot_b u_b). */
+int brMfGradInplace(float* stash_user, float* stash_item, int64_t ld, const float* ddot, int64_t batch, int dim, brStream stream);
+int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,
+                             const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                             const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
+                             const void* step_state, double beta1, double beta2, double eps, brStream stream);
+int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,
+                double beta1, double beta2, double eps, brStream stream);
 int64_t brNeumfStepSizeof(void);
 int brNeumfStepRun(const brNeumfStep* s, uint32_t phases, brStream stream);
 

@@ -24,7 +24,7 @@ def _close(got, ref, name, rtol=RTOL, atol_frac=5e-6):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol_frac * scale, err_msg=name)
 
 
-def _setup(variant, dim, B, dev, U=97, I=53, seed=3, optimizer="adam_lazy", hidden=None):
+def _setup(variant, dim, B, dev, U=97, I=53, seed=3, optimizer="adam_lazy", hidden=None, dense_impl="deferred"):
     ops, neumf = _mods()
     spec = O.NeuMFSpec(variant, dim=dim, hidden=hidden)
     p = O.neumf_init(spec, U, I, seed=seed, dt=np.float32)
@@ -37,7 +37,7 @@ def _setup(variant, dim, B, dev, U=97, I=53, seed=3, optimizer="adam_lazy", hidd
         p[k] = rng.normal(0.4, 0.1, p[k].shape).astype(np.float32)
     for k in ("mv1", "mv2"):
         p[k] = rng.uniform(0.05, 0.3, p[k].shape).astype(np.float32)
-    cfg = neumf.NeuMFConfig(variant=variant, dim=dim, hidden=hidden, optimizer=optimizer, seed=0xABCDEF12345)
+    cfg = neumf.NeuMFConfig(variant=variant, dim=dim, hidden=hidden, optimizer=optimizer, seed=0xABCDEF12345, dense_impl=dense_impl)
     eng = neumf.NeuMFEngine(cfg, U, I, dev, max_batch=B)
     eng.load_numpy_params(p)
     u = rng.integers(0, U, B); i = rng.integers(0, I, B)
@@ -86,8 +86,9 @@ def test_forward_backward_parity(dev, variant, dim, B):
         _close(eng.moving[k].cpu().numpy(), ns[k], k)
 
 
-@pytest.mark.parametrize("variant,dim,optimizer", [("A", 64, "adam_dense"), ("A", 64, "adam_lazy"), ("B", 32, "adam_dense"), ("A", 10, "adam_dense")])
-def test_three_optimizer_steps(dev, variant, dim, optimizer):
+@pytest.mark.parametrize("variant,dim,optimizer,impl", [("A", 64, "adam_dense", "deferred"), ("A", 64, "adam_dense", "sweep"), ("A", 64, "adam_lazy", "sweep"),
+                                                        ("B", 32, "adam_dense", "deferred"), ("A", 10, "adam_dense", "deferred"), ("A", 10, "adam_dense", "sweep")])
+def test_three_optimizer_steps(dev, variant, dim, optimizer, impl):
     """Parameters after 3 steps of Keras-Adam (dense = non-lazy sparse apply [TF-sem]).
     Adam divides by sqrt(v): a gradient that is itself a nearly cancelled fp32 sum (pre-BN biases,
     a few W1 entries) turns its rounding noise into an O(lr) difference, so the end-to-end bound
@@ -96,7 +97,7 @@ def test_three_optimizer_steps(dev, variant, dim, optimizer):
     single-step gradients above and the optimizer kernels on identical inputs
     (test_gpu_sparse_optim.py)."""
     B = 200
-    ops, eng, spec, cfg, p, u, i, y = _setup(variant, dim, B, dev, optimizer=optimizer)
+    ops, eng, spec, cfg, p, u, i, y = _setup(variant, dim, B, dev, optimizer=optimizer, dense_impl=impl)
     td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
     rng = np.random.default_rng(11)
     P = {k: v.astype(np.float64) for k, v in p.items()}
@@ -186,16 +187,17 @@ def test_empty_batch_is_noop(dev):
     assert torch.equal(before, eng.theta.buf) and eng.t == 0
 
 
-@pytest.mark.parametrize("optimizer,eager_sweep", [("adam_dense", False), ("adam_dense", True), ("adam_lazy", False)])
-def test_graph_replay_matches_eager_steps(dev, optimizer, eager_sweep):
+@pytest.mark.parametrize("optimizer,impl,eager", [("adam_dense", "sweep", ()), ("adam_dense", "sweep", ("SWEEP_USER",)), ("adam_lazy", "sweep", ("BWD1",)),
+                                                  ("adam_dense", "deferred", ()), ("adam_dense", "deferred", ("BWD2", "BWD1"))])
+def test_graph_replay_matches_eager_steps(dev, optimizer, impl, eager):
     """hipGraph replay of the step (NeuMFEngine.enable_graph) against the eager launch sequence over 4
     steps with fresh batches, a ragged (eager) batch in between, and a state reload.  The only arithmetic
     difference is alpha_t: computed on the device in double and rounded to fp32 (eager: on the host),
     so parameters agree to an fp32 ulp of alpha (1e-6 relative), everything else is the same launches."""
     B = 192
-    ops, eg, spec, cfg, p, u, i, y = _setup("A", 64, B, dev, optimizer=optimizer)
-    _, gr, *_ = _setup("A", 64, B, dev, optimizer=optimizer)
-    gr.enable_graph(B, eager_sweep=eager_sweep)
+    ops, eg, spec, cfg, p, u, i, y = _setup("A", 64, B, dev, optimizer=optimizer, dense_impl=impl)
+    _, gr, *_ = _setup("A", 64, B, dev, optimizer=optimizer, dense_impl=impl)
+    gr.enable_graph(B, eager_phases=eager)
     assert gr.t == 0
     rng = np.random.default_rng(11)
     td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
@@ -211,6 +213,7 @@ def test_graph_replay_matches_eager_steps(dev, optimizer, eager_sweep):
     gr.check_ids()
     assert gr.t == eg.t == 5
     assert int(gr.step_state[0].item()) == 5
+    gr.flush(); eg.flush()
     for k in ("user", "item"):
         _close(gr.fused[k].cpu().numpy(), eg.fused[k].cpu().numpy(), "table " + k, rtol=2e-6, atol_frac=1e-6)
         _close(gr.fused_v[k].cpu().numpy(), eg.fused_v[k].cpu().numpy(), "v " + k, rtol=2e-6, atol_frac=1e-6)
@@ -249,3 +252,72 @@ def test_graph_replay_against_oracle(dev):
     for k in names:
         np.testing.assert_allclose(eng.tables[k].cpu().numpy(), P[k], rtol=1e-5, atol=5e-3 * travel, err_msg=k)
         assert np.median(np.abs(eng.tables[k].cpu().numpy() - P[k])) <= 1e-7
+
+
+def _two_engines(dev, B, U, I, dim=16):
+    """the same model twice: dense Adam by per-step sweep and by deferred replay, both reading alpha_t from
+    the device step state (so the two use the same fp32 alpha)."""
+    _, sw, spec, cfg, *_ = _setup("A", dim, B, dev, U=U, I=I, optimizer="adam_dense", dense_impl="sweep")
+    _, de, *_ = _setup("A", dim, B, dev, U=U, I=I, optimizer="adam_dense", dense_impl="deferred")
+    sw._alloc_step_state(sw.step_struct)
+    return sw, de
+
+
+def _assert_same_state(sw, de):
+    de.flush()
+    for k in ("user", "item"):
+        assert torch.equal(sw.fused[k], de.fused[k]), "table " + k
+        assert torch.equal(sw.fused_m[k], de.fused_m[k]), "m " + k
+        assert torch.equal(sw.fused_v[k], de.fused_v[k]), "v " + k
+    assert torch.equal(sw.theta.buf, de.theta.buf)
+
+
+def test_deferred_adam_is_bit_equal_to_the_sweep(dev):
+    """O1, Keras non-lazy sparse apply [TF-sem]: the deferred replay must give the SAME tables as sweeping
+    every row every step — bit for bit (same fp32 operations, adam_math.h).  1500 users, 48 pairs per step:
+    most rows sit out many steps between two touches; an inference call in the middle flushes."""
+    B, U, I = 48, 1500, 400
+    sw, de = _two_engines(dev, B, U, I)
+    rng = np.random.default_rng(5)
+    td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
+    for step in range(40):
+        n = B if step % 7 else B - 11
+        uu, ii = rng.integers(0, U, n), rng.integers(0, I, n)
+        uu[:5] = uu[0]
+        yy = (rng.random(n) < 0.3).astype(np.float32)
+        for e in (sw, de):
+            e.train_step(td(uu, torch.int32), td(ii, torch.int32), td(yy, torch.float32))
+        if step == 17:
+            q = td(rng.integers(0, U, 64), torch.int32), td(rng.integers(0, I, 64), torch.int32)
+            assert torch.equal(sw.predict(*q), de.predict(*q))
+    torch.cuda.synchronize()
+    de.check_ids()
+    assert de._stale
+    _assert_same_state(sw, de)
+    # a reload (all rows at step t) and more steps
+    de.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in de.state_dict().items()})
+    for step in range(5):
+        uu, ii = rng.integers(0, U, B), rng.integers(0, I, B)
+        yy = (rng.random(B) < 0.3).astype(np.float32)
+        for e in (sw, de):
+            e.train_step(td(uu, torch.int32), td(ii, torch.int32), td(yy, torch.float32))
+    _assert_same_state(sw, de)
+
+
+def test_deferred_adam_survives_the_alpha_ring(dev):
+    """more steps than BR_ALPHA_RING: the engine flushes before a replay could read an overwritten alpha."""
+    B, U, I = 16, 300, 200
+    sw, de = _two_engines(dev, B, U, I, dim=8)
+    rng = np.random.default_rng(9)
+    steps = de.ALPHA_RING + 40
+    us = torch.from_numpy(rng.integers(0, U, (steps, B))).to(dev).to(torch.int32)
+    its = torch.from_numpy(rng.integers(0, I, (steps, B))).to(dev).to(torch.int32)
+    ys = torch.from_numpy((rng.random((steps, B)) < 0.3).astype(np.float32)).to(dev)
+    us[:, 0] = 7      # row 7 every step; rows >= 290 of the user table never
+    us.clamp_(max=289)
+    for s in range(steps):
+        for e in (sw, de):
+            e.train_step(us[s], its[s], ys[s])
+    torch.cuda.synchronize()
+    assert de._flush_t > 0
+    _assert_same_state(sw, de)
