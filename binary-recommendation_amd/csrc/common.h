@@ -69,7 +69,16 @@ __device__ __forceinline__ float sigmoidf_stable(float x) {
   return x >= 0.f ? r : e * r;
 }
 
-// accurate forms used where the loss / gradient tolerance is tight
+// hidden-layer activation on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each, |rel err| < 4e-7):
+// the accurate expf + IEEE division cost ~40 VALU ops per element in the dense_fwd epilogue (2 us of a 36 us
+// launch); parity with the oracle's exact sigmoid stays inside the 1e-5 budget (tests/test_gpu_neumf.py).
+__device__ __forceinline__ float sigmoidf_hw(float x) {
+  const float e = __expf(-fabsf(x));
+  const float r = __builtin_amdgcn_rcpf(1.0f + e);
+  return x >= 0.f ? r : e * r;
+}
+
+// accurate forms used where the loss / gradient tolerance is tight (head logit -> probability -> loss)
 __device__ __forceinline__ float sigmoidf_acc(float x) {
   float e = expf(-fabsf(x));
   float r = 1.0f / (1.0f + e);
@@ -77,7 +86,7 @@ __device__ __forceinline__ float sigmoidf_acc(float x) {
 }
 
 __device__ __forceinline__ float act_apply(float z, int act) {
-  if (act == BR_ACT_SIGMOID) return sigmoidf_acc(z);
+  if (act == BR_ACT_SIGMOID) return sigmoidf_hw(z);
   if (act == BR_ACT_RELU) return fmaxf(z, 0.f);
   return z;
 }

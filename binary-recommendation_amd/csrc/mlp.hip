@@ -145,16 +145,32 @@ __global__ __launch_bounds__(kThreads, 2) void dense_fwd_kernel(const float* __r
   float4 a[KJ], an[KJ];
   load_a(a, tile);                                    // first tile's loads fly while W is staged
 
-  // W image: thread -> (j, g, n): 4 coalesced loads (k = 16j+4g+s) -> one conflict-free ds_write_b128
-  for (int idx = threadIdx.x; idx < KJ * 4 * Np; idx += kThreads) {
-    const int jg = idx / Np, n = idx - jg * Np;
-    const int k0 = 4 * jg;
-    const int nc = n < N ? n : N - 1;
-    const float t0 = W[(k0 + 0 < K ? k0 + 0 : K - 1) * N + nc], t1 = W[(k0 + 1 < K ? k0 + 1 : K - 1) * N + nc];
-    const float t2 = W[(k0 + 2 < K ? k0 + 2 : K - 1) * N + nc], t3 = W[(k0 + 3 < K ? k0 + 3 : K - 1) * N + nc];
-    const bool nin = n < N;
-    *reinterpret_cast<float4*>(Ws + (jg * Np + n) * 4) =
-        make_float4((nin && k0 + 0 < K) ? t0 : 0.f, (nin && k0 + 1 < K) ? t1 : 0.f, (nin && k0 + 2 < K) ? t2 : 0.f, (nin && k0 + 3 < K) ? t3 : 0.f);
+  // W image: thread -> (j, g, n): 4 coalesced loads (k = 16j+4g+s) -> one conflict-free ds_write_b128.
+  // ALL loads of the image are issued before the first LDS write (compile-time trip count, clamped
+  // addresses): a rolled load->write loop costs one L2 round trip per trip (measured: ~6 us of a 32 us launch).
+  {
+    constexpr int TOT = KJ * 4 * Np, TR = (TOT + kThreads - 1) / kThreads;
+    float wv[TR][4];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      const int idc = idx < TOT ? idx : 0;
+      const int jg = idc / Np, n = idc - jg * Np;
+      const int k0 = 4 * jg;
+      const int nc = n < N ? n : N - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[i][q] = W[(k0 + q < K ? k0 + q : K - 1) * N + nc];
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      const int jg = idx / Np, n = idx - jg * Np;
+      const int k0 = 4 * jg;
+      const bool nin = n < N;
+      if (idx < TOT)
+        *reinterpret_cast<float4*>(Ws + idx * 4) = make_float4((nin && k0 + 0 < K) ? wv[i][0] : 0.f, (nin && k0 + 1 < K) ? wv[i][1] : 0.f,
+                                                                (nin && k0 + 2 < K) ? wv[i][2] : 0.f, (nin && k0 + 3 < K) ? wv[i][3] : 0.f);
+    }
   }
   if (tin.scale)
     for (int k = threadIdx.x; k < Kp; k += kThreads) {
@@ -414,16 +430,28 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
   int64_t tile = (int64_t)blockIdx.x * 8 + wave;
   float4 dz[NT], dzn[NT];
   load_dz(dz, tile);                                  // first tile's loads fly while W is staged
-  if (gx)
-    for (int idx = threadIdx.x; idx < Kp * (Np / 4); idx += kThreads) {
-      const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
+  if (gx) {     // all loads of the W image before the first LDS write (see dense_fwd_kernel)
+    constexpr int TOT = Kp * (Np / 4), TR = (TOT + kThreads - 1) / kThreads;
+    float wv[TR][4];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      const int idc = idx < TOT ? idx : 0;
+      const int k = idc / (Np / 4), n = (idc - k * (Np / 4)) * 4;
       const float* wr = W + (int64_t)(k < K ? k : K - 1) * N;
-      const float t0 = wr[n + 0 < N ? n + 0 : N - 1], t1 = wr[n + 1 < N ? n + 1 : N - 1];
-      const float t2 = wr[n + 2 < N ? n + 2 : N - 1], t3 = wr[n + 3 < N ? n + 3 : N - 1];
-      const bool kin = k < K;
-      *reinterpret_cast<float4*>(Ws + k * ldw + n) =
-          make_float4((kin && n + 0 < N) ? t0 : 0.f, (kin && n + 1 < N) ? t1 : 0.f, (kin && n + 2 < N) ? t2 : 0.f, (kin && n + 3 < N) ? t3 : 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[i][q] = wr[n + q < N ? n + q : N - 1];
     }
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
+      const bool kin = k < K;
+      if (idx < TOT)
+        *reinterpret_cast<float4*>(Ws + k * ldw + n) = make_float4((kin && n + 0 < N) ? wv[i][0] : 0.f, (kin && n + 1 < N) ? wv[i][1] : 0.f,
+                                                                    (kin && n + 2 < N) ? wv[i][2] : 0.f, (kin && n + 3 < N) ? wv[i][3] : 0.f);
+    }
+  }
   __syncthreads();
 
   float isum[KT], isq[KT];

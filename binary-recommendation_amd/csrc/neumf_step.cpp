@@ -125,20 +125,13 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   double *stats1 = s->dstat, *stats2 = stats1 + R * 2 * n1, *bsum1 = stats2 + R * 2 * n2, *bsum2 = bsum1 + R * 2 * n1;
   float *mm1 = s->moving, *mv1 = mm1 + n1, *mm2 = mv1 + n1, *mv2 = mm2 + n2;
   const int uoff = s->item_first ? D : 0, ioff = s->item_first ? 0 : D;
-  // dedup sorts on the aux stream: forked at the top of the step, joined before the Adam-rows kernels
+  // dedup sorts on the aux stream: forked after the embedding lookup, joined before the Adam-rows kernels.
+  // (Forked at the very top, a hipGraph replay ran the first sort BEFORE the step's first main-stream node
+  // instead of beside it - rocprofv3 timeline, ROCm 7.2 - which put ~70 us of launch-bound sort passes on the
+  // critical path; behind the lookup they overlap the MLP.)
   const bool build_index = train && (ph & BR_PH_INDEX);
   const bool aux_index = build_index && s->aux_stream && (ph & BR_PH_FWD1);
   bool joined = !aux_index;
-  if (aux_index) {
-    if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
-    hipStream_t as = (hipStream_t)s->aux_stream;
-    (void)hipEventRecord(g_fork, hs);                 // previous step's readers of the index buffers are done
-    (void)hipStreamWaitEvent(as, g_fork, 0);
-    int rc = brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, s->aux_stream);
-    if (rc == BR_OK) rc = brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, s->aux_stream);
-    if (rc != BR_OK) return rc;
-    (void)hipEventRecord(g_join, as);
-  }
   if ((ph & BR_PH_FWD1) && train && s->step_state)
     RUN(BR_TAG_SMALL, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, stream));
   if (ph & BR_PH_FWD1) {
@@ -153,6 +146,16 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     else if (ph & BR_PH_EMBED)   /* deferred + inference: the host flushed the tables (brAdamFlush) first */
       RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForward(s->user_tab, s->item_tab, s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows,
                               s->users, s->items, s->id_type, D, B, s->item_first, s->x0, s->dot, s->err_flag, stream));
+    if (aux_index) {
+      if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
+      hipStream_t as = (hipStream_t)s->aux_stream;
+      (void)hipEventRecord(g_fork, hs);                 // the previous step's readers of the index buffers are done
+      (void)hipStreamWaitEvent(as, g_fork, 0);
+      const int rc = brRowIndexBuildPair(s->users, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes,
+                                         s->items, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, s->id_type, B, s->aux_stream);
+      if (rc != BR_OK) return rc;
+      (void)hipEventRecord(g_join, as);
+    }
     RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, n1, B, 2 * D, n1, s->act, nullptr, nullptr, p, s->seed,
                        (uint32_t)s->step, 0, s->row0, train ? stats1 : nullptr, stream));
   }
@@ -210,8 +213,8 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
                                B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, stream));
   }
   if (build_index && !aux_index) {
-    RUN(BR_TAG_INDEX_USER, brRowIndexBuild(s->users, s->id_type, B, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, stream));
-    RUN(BR_TAG_INDEX_ITEM, brRowIndexBuild(s->items, s->id_type, B, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, stream));
+    RUN(BR_TAG_INDEX_USER, brRowIndexBuildPair(s->users, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes,
+                                               s->items, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, s->id_type, B, stream));
   }
   if (!joined && (ph & (BR_PH_ROWS_USER | BR_PH_ROWS_ITEM))) {
     (void)hipStreamWaitEvent(hs, g_join, 0);

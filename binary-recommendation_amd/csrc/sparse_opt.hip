@@ -16,9 +16,16 @@
 
 namespace br {
 
-__global__ void iota_kernel(int32_t* p, int64_t n) {
+// positions 0..n-1 and the sort keys: ids outside [0, upper) become `upper` so that they sort behind every
+// valid id instead of aliasing one in the low key bits (the optimizer kernels skip ids >= table rows)
+template <typename IdT>
+__global__ void sort_prep_kernel(const IdT* __restrict__ ids, int64_t upper, IdT* __restrict__ keys, int32_t* __restrict__ p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (int32_t)i;
+  if (i < n) {
+    p[i] = (int32_t)i;
+    const int64_t id = (int64_t)ids[i];
+    keys[i] = (upper > 0 && (uint64_t)id >= (uint64_t)upper) ? (IdT)upper : (IdT)id;
+  }
 }
 
 // one row group per sorted position; only segment heads do work
@@ -237,11 +244,118 @@ using namespace br;
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
+// ---- dedup index for small batches: 2 launches instead of hipcub's ~10 per id stream ------------------------
+// hipcub::DeviceRadixSort on 65 536 pairs is a block sort + 6 merge passes (+ iota): ~10 launches of ~5 us each,
+// and a hipGraph replay runs them on the critical path (rocprofv3 timeline, ROCm 7.2).  For n <= kRankMaxN:
+//   K1 chunk_sort_kernel : every workgroup radix-sorts one chunk of 2048 (id, position) pairs in LDS (stable);
+//   K2 chunk_rank_kernel : the final rank of an element = its index in its chunk + for every other chunk the
+//                          number of keys that sort before it (binary search: "<=" in earlier chunks, "<" in
+//                          later ones = stable), then one scatter.  32 chunks x 12 probes per element at n = 65 536, all in L2.
+// Both id streams of a step share the two launches (blockIdx.y).  Out-of-range ids get the key `upper`
+// (>= table rows: the optimizer kernels skip them), so only bits_for(upper + 2) key bits are sorted.
+constexpr int kChunk = 2048, kSortThreads = 256, kRankMaxChunks = 64;
+constexpr int64_t kRankMaxN = (int64_t)kChunk * kRankMaxChunks;
+struct IdxJob {
+  const void* ids;
+  void* sorted_ids;
+  int32_t* sorted_pos;
+  uint32_t* ck;       // [n] chunk-sorted keys
+  uint32_t* cp;       // [n] their positions
+  uint32_t upper;     // ids are valid in [0, upper)
+  int end_bit;
+};
+struct IdxJobs { IdxJob j[2]; };
+
+template <typename IdT>
+__global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, int64_t n) {
+  constexpr int IPT = kChunk / kSortThreads;
+  using Sort = hipcub::BlockRadixSort<uint32_t, kSortThreads, IPT, uint32_t>;
+  __shared__ typename Sort::TempStorage tmp;
+  const IdxJob& job = jobs.j[blockIdx.y];
+  const IdT* ids = (const IdT*)job.ids;
+  const int64_t base = (int64_t)blockIdx.x * kChunk + threadIdx.x * IPT;
+  uint32_t k[IPT], p[IPT];
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) {
+    const int64_t e = base + q;
+    const int64_t id = e < n ? (int64_t)ids[e] : -1;
+    k[q] = e < n ? (((uint64_t)id < (uint64_t)job.upper) ? (uint32_t)id : job.upper) : job.upper + 1u;   // padding sorts last
+    p[q] = (uint32_t)e;
+  }
+  Sort(tmp).Sort(k, p, 0, job.end_bit);
+#pragma unroll
+  for (int q = 0; q < IPT; ++q)
+    if (base + q < n) { job.ck[base + q] = k[q]; job.cp[base + q] = p[q]; }
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n, int n_chunks) {
+  const IdxJob& job = jobs.j[blockIdx.y];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int c = (int)(e / kChunk);
+  const uint32_t key = job.ck[e];
+  uint32_t rank = (uint32_t)(e - (int64_t)c * kChunk);
+  constexpr int G = 8;                                   // chunks searched together (independent load chains)
+  for (int c0 = 0; c0 < n_chunks; c0 += G) {
+    uint32_t lo[G], len[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int cc = c0 + u;
+      const int64_t left = n - (int64_t)cc * kChunk;
+      len[u] = (cc < n_chunks && cc != c) ? (uint32_t)(left < kChunk ? left : kChunk) : 0u;
+      lo[u] = 0u;
+    }
+#pragma unroll
+    for (int step = kChunk; step > 0; step >>= 1) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t idx = lo[u] + (uint32_t)step;
+        const uint32_t at = idx <= len[u] ? idx - 1u : 0u;                          // clamped probe, branch-free
+        const uint32_t v = job.ck[(int64_t)(c0 + u < n_chunks ? c0 + u : 0) * kChunk + at];
+        const bool before = (c0 + u < c) ? (v <= key) : (v < key);
+        if (idx <= len[u] && before) lo[u] = idx;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) rank += lo[u];
+  }
+  ((IdT*)job.sorted_ids)[rank] = (IdT)key;
+  job.sorted_pos[rank] = (int32_t)job.cp[e];
+}
+
+static bool rank_path_ok(int64_t n, int64_t upper) { return n <= kRankMaxN && upper > 0 && upper < ((int64_t)1 << 31) - 2; }
+
+static int index_build_rank(IdxJobs& jobs, int n_jobs, int id_type, int64_t n, hipStream_t s) {
+  const int n_chunks = (int)ceil_div(n, kChunk);
+  const dim3 g1((unsigned)n_chunks, (unsigned)n_jobs), g2((unsigned)ceil_div(n, 256), (unsigned)n_jobs);
+  if (id_type == BR_IDS_I32) {
+    chunk_sort_kernel<int32_t><<<g1, kSortThreads, 0, s>>>(jobs, n);
+    chunk_rank_kernel<int32_t><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
+  } else {
+    chunk_sort_kernel<int64_t><<<g1, kSortThreads, 0, s>>>(jobs, n);
+    chunk_rank_kernel<int64_t><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
+  }
+  BR_CHECK_LAUNCH("brRowIndexBuild");
+  return BR_OK;
+}
+static IdxJob make_job(const void* ids, void* sorted_ids, int32_t* sorted_pos, void* workspace, int64_t n, int64_t upper) {
+  IdxJob j;
+  j.ids = ids; j.sorted_ids = sorted_ids; j.sorted_pos = sorted_pos;
+  j.ck = (uint32_t*)workspace;
+  j.cp = (uint32_t*)((char*)workspace + align256(n * 4));
+  j.upper = (uint32_t)upper;
+  j.end_bit = bits_for(upper + 2);
+  return j;
+}
+
 extern "C" int64_t brRowIndexWorkspaceBytes(int64_t n, int id_type) {
   if (n <= 0) return 256;
   const int64_t iota = align256(n * 4);
   const int64_t tmp = id_type == BR_IDS_I64 ? sort_temp_bytes<int64_t>(n) : sort_temp_bytes<int32_t>(n);
-  return iota + align256(tmp) + 256;
+  const int64_t rank = 2 * align256(n * 4);       // chunk-sorted keys + positions (small-batch path)
+  const int64_t sort = iota + align256(n * 8) + align256(tmp);
+  return (sort > rank ? sort : rank) + 256;
 }
 
 extern "C" int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t id_upper_bound, void* sorted_ids,
@@ -256,26 +370,55 @@ extern "C" int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t 
     return BR_ERR_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (rank_path_ok(n, id_upper_bound)) {
+    IdxJobs jobs;
+    jobs.j[0] = jobs.j[1] = make_job(ids, sorted_ids, sorted_pos, workspace, n, id_upper_bound);
+    return index_build_rank(jobs, 1, id_type, n, s);
+  }
   int32_t* iota = (int32_t*)workspace;
-  void* tmp = (char*)workspace + align256(n * 4);
-  size_t tmp_bytes = (size_t)(workspace_bytes - align256(n * 4));
-  iota_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, s>>>(iota, n);
+  void* keys = (char*)workspace + align256(n * 4);
+  void* tmp = (char*)keys + align256(n * 8);
+  size_t tmp_bytes = (size_t)(workspace_bytes - align256(n * 4) - align256(n * 8));
   const int end_bit_cap = (id_type == BR_IDS_I64 ? 64 : 32);
-  int end_bit = id_upper_bound > 0 ? bits_for(id_upper_bound) : end_bit_cap;
+  int end_bit = id_upper_bound > 0 ? bits_for(id_upper_bound + 1) : end_bit_cap;
   if (end_bit > end_bit_cap) end_bit = end_bit_cap;
   hipError_t e;
-  if (id_type == BR_IDS_I64)
-    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const int64_t*)ids, (int64_t*)sorted_ids, (const int32_t*)iota,
+  if (id_type == BR_IDS_I64) {
+    sort_prep_kernel<int64_t><<<(unsigned)ceil_div(n, 256), 256, 0, s>>>((const int64_t*)ids, id_upper_bound, (int64_t*)keys, iota, n);
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const int64_t*)keys, (int64_t*)sorted_ids, (const int32_t*)iota,
                                            sorted_pos, (int)n, 0, end_bit, s);
-  else
-    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const int32_t*)ids, (int32_t*)sorted_ids, (const int32_t*)iota,
+  } else {
+    sort_prep_kernel<int32_t><<<(unsigned)ceil_div(n, 256), 256, 0, s>>>((const int32_t*)ids, id_upper_bound, (int32_t*)keys, iota, n);
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const int32_t*)keys, (int32_t*)sorted_ids, (const int32_t*)iota,
                                            sorted_pos, (int)n, 0, end_bit, s);
+  }
   if (e != hipSuccess) {
     set_error("brRowIndexBuild: radix sort failed: %s", hipGetErrorString(e));
     return BR_ERR_HIP;
   }
   BR_CHECK_LAUNCH("brRowIndexBuild");
   return BR_OK;
+}
+
+extern "C" int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
+                                   const void* ids_b, int64_t upper_b, void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes,
+                                   int id_type, int64_t n, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brRowIndexBuildPair: bad id_type");
+  if (n == 0) return BR_OK;
+  if (rank_path_ok(n, upper_a) && rank_path_ok(n, upper_b)) {
+    BR_CHECK_ARG(ids_a && ids_b && sorted_ids_a && sorted_ids_b && sorted_pos_a && sorted_pos_b && ws_a && ws_b, "brRowIndexBuildPair: null pointer");
+    const int64_t need = brRowIndexWorkspaceBytes(n, id_type);
+    if (ws_a_bytes < need || ws_b_bytes < need) {
+      set_error("brRowIndexBuildPair: workspace < required %lld", (long long)need);
+      return BR_ERR_WORKSPACE;
+    }
+    IdxJobs jobs;
+    jobs.j[0] = make_job(ids_a, sorted_ids_a, sorted_pos_a, ws_a, n, upper_a);
+    jobs.j[1] = make_job(ids_b, sorted_ids_b, sorted_pos_b, ws_b, n, upper_b);
+    return index_build_rank(jobs, 2, id_type, n, (hipStream_t)stream);
+  }
+  const int rc = brRowIndexBuild(ids_a, id_type, n, upper_a, sorted_ids_a, sorted_pos_a, ws_a, ws_a_bytes, stream);
+  return rc != BR_OK ? rc : brRowIndexBuild(ids_b, id_type, n, upper_b, sorted_ids_b, sorted_pos_b, ws_b, ws_b_bytes, stream);
 }
 
 extern "C" int brSegmentSumRows(const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,

@@ -101,6 +101,12 @@ int64_t brRowIndexWorkspaceBytes(int64_t n, int id_type);
 int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t id_upper_bound,
                     void* sorted_ids, int32_t* sorted_pos, void* workspace,
                     int64_t workspace_bytes, brStream stream);
+/* Both id streams of a step (same n) in shared launches: for n <= 131 072 (64 chunks of 2048) and id bounds < 2^31 the index is
+ * built in TWO launches for the pair (chunk sort in LDS + rank-by-binary-search scatter) instead of one device
+ * radix sort (~10 launches) per stream.  Same outputs as two brRowIndexBuild calls. */
+int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
+                        const void* ids_b, int64_t upper_b, void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes,
+                        int id_type, int64_t n, brStream stream);
 /* Materialised dedup: for each segment head h (sorted position), out_rows[h] = ordered sum of
  * row_grads[sorted_pos[j]] over the segment, head_flag[h]=1; non-head rows untouched, flag 0. */
 int brSegmentSumRows(const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,

@@ -132,3 +132,49 @@ def test_adam_flat_and_adagrad(dev):
     rt, ra = O.adagrad_sparse(tb, ac, ids, gg, 0.1, dt=np.float64)
     np.testing.assert_allclose(tbd.cpu().numpy(), rt, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(acd.cpu().numpy(), ra, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n,rows,idt", [(1, 5, torch.int32), (2047, 300, torch.int32), (2049, 1 << 20, torch.int32), (65536, 1_000_000, torch.int32),
+                                        (65536, 100, torch.int64), (131072, 4000, torch.int32), (131073, 4000, torch.int32), (200000, 77, torch.int64)])
+def test_row_index_is_the_stable_sort(dev, n, rows, idt):
+    """S1: (sorted_ids, sorted_pos) == numpy's stable argsort of the ids, bit for bit - on the 2-launch
+    chunk-sort + rank path (n <= 131072) and on the device radix sort above it; ids outside [0, rows)
+    (flagged by the forward, skipped by the optimizer) sort behind every valid id."""
+    ops = _ops()
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, rows, n)
+    ids[: n // 5] = ids[0]                        # a hot id
+    if n > 10:
+        ids[7] = rows + 3                         # out of range
+        ids[n // 2] = -1
+    idx = ops.RowIndex(n, idt, dev).build(torch.from_numpy(ids).to(dev).to(idt), rows)
+    torch.cuda.synchronize()
+    sid, spos = idx.sorted_ids.cpu().numpy().astype(np.int64), idx.sorted_pos.cpu().numpy().astype(np.int64)
+    valid = (ids >= 0) & (ids < rows)
+    order = np.argsort(np.where(valid, ids, rows), kind="stable")
+    nv = int(valid.sum())
+    np.testing.assert_array_equal(spos[:nv], order[:nv])
+    np.testing.assert_array_equal(sid[:nv], ids[order[:nv]])
+    assert sorted(spos[nv:].tolist()) == sorted(order[nv:].tolist())          # the invalid ones: all present, behind
+    assert np.all((sid[nv:] < 0) | (sid[nv:] >= rows))
+
+
+def test_row_index_pair_matches_two_builds(dev):
+    from importlib import import_module
+    ops = _ops()
+    lib = import_module("binary-recommendation_amd._lib").load()
+    n, ru, ri = 50000, 1_000_000, 3000
+    rng = np.random.default_rng(2)
+    u = torch.from_numpy(rng.integers(0, ru, n)).to(dev).int()
+    i = torch.from_numpy(rng.integers(0, ri, n)).to(dev).int()
+    a, b = ops.RowIndex(n, torch.int32, dev), ops.RowIndex(n, torch.int32, dev)
+    rc = lib.brRowIndexBuildPair(u.data_ptr(), ru, a.sorted_ids.data_ptr(), a.sorted_pos.data_ptr(), a.ws.data_ptr(), a.ws_bytes,
+                                 i.data_ptr(), ri, b.sorted_ids.data_ptr(), b.sorted_pos.data_ptr(), b.ws.data_ptr(), b.ws_bytes,
+                                 ops.I32, n, ops._stream())
+    assert rc == 0
+    ra, rb = ops.RowIndex(n, torch.int32, dev).build(u, ru), ops.RowIndex(n, torch.int32, dev).build(i, ri)
+    torch.cuda.synchronize()
+    for x, y in ((a, ra), (b, rb)):
+        assert torch.equal(x.sorted_ids, y.sorted_ids) and torch.equal(x.sorted_pos, y.sorted_pos)
+    su = np.argsort(u.cpu().numpy(), kind="stable")
+    np.testing.assert_array_equal(a.sorted_pos.cpu().numpy(), su)
