@@ -17,6 +17,7 @@ void set_error(const char* fmt, ...);
 struct StepStateDev {
   uint32_t step;
   float alpha_t;
+  double pow_b1, pow_b2;             // beta1^step, beta2^step (running products: no pow() on the step's critical path)
   float alpha_hist[BR_ALPHA_RING];   // alpha_j at [j & (BR_ALPHA_RING-1)] for the last BR_ALPHA_RING steps
 };
 const StepStateDev* current_step_state();

@@ -324,7 +324,10 @@ __global__ void bn_inference_kernel(const float* __restrict__ gamma, const float
   shift[n] = beta[n] - mm[n] * sc;
 }
 
-__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int N) {
+// blockIdx.y selects the layer (the two BatchNorms of a tower share one launch)
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                      const double* __restrict__ sums_b, float* __restrict__ dgamma_b, float* __restrict__ dbeta_b, int Nb) {
+  if (blockIdx.y == 1) { sums = sums_b; dgamma = dgamma_b; dbeta = dbeta_b; N = Nb; }
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   double s1 = 0.0, s2 = 0.0;
@@ -473,6 +476,21 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
       }
       __builtin_amdgcn_wave_barrier();
     }
+    // raw x of this tile's outputs (for xhat in the epilogues): ALL k-tiles are requested here, before the
+    // Philox and MFMA work of the tile - loaded per pass they cost one exposed HBM round trip per pass
+    float xv[4][KT];
+    if (ibn.mean) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gr = rbase + 4 * g + r;
+        const float* xr = x + (gr < batch ? gr : batch - 1) * ldx_g;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const int k = kt * 16 + c16;
+          xv[r][kt] = xr[k < K ? k : K - 1];
+        }
+      }
+    }
     // ---- dx = dz · W^T in passes of 2 k-tiles: two independent chains alternate (revisit distance
     //      64 cycles >= the 40-cycle dependent latency), B fragments double-buffered; 2 instead of 4 keeps the
     //      kernel inside the 128-VGPR budget of 4 waves/SIMD without scratch traffic in the loop ----
@@ -482,19 +500,6 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
       const int Wn = (KT - kt0) < WMAX ? (KT - kt0) : WMAX;
       f32x4 acc[WMAX];
       float4 bc[WMAX], bn[WMAX];
-      float xv[4][WMAX];      // raw x of this pass's outputs (for xhat): loaded now, used after the MFMAs
-      if (ibn.mean) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gr = rbase + 4 * g + r;
-          const float* xr = x + (gr < batch ? gr : batch - 1) * ldx_g;
-#pragma unroll
-          for (int w = 0; w < WMAX; ++w) {
-            const int k = (kt0 + w) * 16 + c16;
-            xv[r][w] = xr[k < K ? k : K - 1];
-          }
-        }
-      }
 #pragma unroll
       for (int w = 0; w < WMAX; ++w) {
         acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
                 const float dh = keep ? acc[w][r] * tin.drop.inv_keep : 0.f;
                 gx[gr * ldgx + k] = dh;
                 if (ibn.mean && keep) {
-                  const float xhat = (xv[r][w] - Is[k]) * Is[Kp + k];
+                  const float xhat = (xv[r][kt0 + w] - Is[k]) * Is[Kp + k];
                   isum[kt0 + w] += dh;
                   isq[kt0 + w] += dh * xhat;
                 }
@@ -942,8 +947,16 @@ extern "C" int brBnInference(const float* gamma, const float* beta, const float*
 
 extern "C" int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta, int N, brStream stream) {
   BR_CHECK_ARG(bn_sums && dgamma && dbeta && N >= 1, "brBnParamGrads: bad args");
-  bn_param_grads_kernel<<<(unsigned)ceil_div(N, 128), 128, 0, (hipStream_t)stream>>>(bn_sums, dgamma, dbeta, N);
+  bn_param_grads_kernel<<<(unsigned)ceil_div(N, 128), 128, 0, (hipStream_t)stream>>>(bn_sums, dgamma, dbeta, N, nullptr, nullptr, nullptr, 0);
   BR_CHECK_LAUNCH("brBnParamGrads");
+  return BR_OK;
+}
+extern "C" int brBnParamGradsPair(const double* sums_a, float* dgamma_a, float* dbeta_a, int Na, const double* sums_b, float* dgamma_b,
+                                  float* dbeta_b, int Nb, brStream stream) {
+  BR_CHECK_ARG(sums_a && dgamma_a && dbeta_a && Na >= 1 && sums_b && dgamma_b && dbeta_b && Nb >= 1, "brBnParamGradsPair: bad args");
+  const dim3 grid((unsigned)ceil_div(Na > Nb ? Na : Nb, 128), 2);
+  bn_param_grads_kernel<<<grid, 128, 0, (hipStream_t)stream>>>(sums_a, dgamma_a, dbeta_a, Na, sums_b, dgamma_b, dbeta_b, Nb);
+  BR_CHECK_LAUNCH("brBnParamGradsPair");
   return BR_OK;
 }
 

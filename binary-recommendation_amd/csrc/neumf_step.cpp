@@ -77,7 +77,6 @@ bool ensure_events() {
 
 extern "C" int64_t brNeumfStepSizeof(void) { return (int64_t)sizeof(brNeumfStep); }
 
-extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream);
 
 static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream);
 
@@ -132,10 +131,11 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const bool build_index = train && (ph & BR_PH_INDEX);
   const bool aux_index = build_index && s->aux_stream && (ph & BR_PH_FWD1);
   bool joined = !aux_index;
+  const int64_t n_dstat = (int64_t)BR_STAT_REPLICAS * (4 * n1 + 4 * n2);
   if ((ph & BR_PH_FWD1) && train && s->step_state)
-    RUN(BR_TAG_SMALL, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, stream));
+    RUN(BR_TAG_SMALL, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, s->dstat, n_dstat, stream));
   if (ph & BR_PH_FWD1) {
-    if (train) {
+    if (train && !s->step_state) {
       hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(BR_STAT_REPLICAS * (4 * n1 + 4 * n2)), hs);
       if (e != hipSuccess) { br::set_error("brNeumfStepRun: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
     }
@@ -172,17 +172,16 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       RUN(BR_TAG_SMALL, brBnFinalize(stats2, bt, th + og2, th + obe2, s->bn_eps, s->bn_momentum, mm2, mv2, scale2, shift2, mean2, rstd2, n2, stream));
     else
       RUN(BR_TAG_SMALL, brBnInference(th + og2, th + obe2, mm2, mv2, s->bn_eps, scale2, shift2, n2, stream));
-    RUN(BR_TAG_FWD_L3, brDenseForward(s->a2, n2, th + oW3, th + ob3, s->a3, n3, B, n2, n3, s->act, scale2, shift2, p, s->seed, (uint32_t)s->step, 2,
-                       s->row0, nullptr, stream));
+    if (!train)
+      RUN(BR_TAG_FWD_L3, brDenseForward(s->a2, n2, th + oW3, th + ob3, s->a3, n3, B, n2, n3, s->act, scale2, shift2, 0.f, s->seed, (uint32_t)s->step, 2,
+                         s->row0, nullptr, stream));
     if (train) {
-      const int nsh = brHeadSlabs(B);
-      RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob, s->msums,
-                      s->da3, n3, s->ddot, s->hslabs, nsh, stream));
-      RUN(BR_TAG_REDUCE, brReduceSlabs(s->hslabs, nsh, n3 + 2, gr + oW4, stream));
-      const int ns3 = brDenseBackwardSlabs(B, n2, n3);
-      RUN(BR_TAG_BWD_L3, brDenseBackward(s->da3, n3, s->a3, n3, s->a2, n2, th + oW3, B, n2, n3, s->act, nullptr, nullptr, nullptr, nullptr, bt, scale2,
-                          shift2, mean2, rstd2, p, 2, s->seed, (uint32_t)s->step, s->row0, s->gh2, n2, s->dz_ws, s->slabs, ns3, bsum2, stream));
-      RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns3, (int64_t)n2 * n3 + n3, gr + oW3, stream));
+      // L3 forward, head, loss and their backward in one launch; W3|b3|W4|b4 are adjacent in theta / grad
+      const int nst = brNeumfTailSlabs(B);
+      RUN(BR_TAG_HEAD, brNeumfTailFused(s->a2, n2, th + oW3, th + ob3, th + oW4, th + ob4, s->dot, s->labels, scale2, shift2, mean2, rstd2, p, s->seed,
+                      (uint32_t)s->step, 2, s->row0, B, n2, n3, s->act, s->mf_first, s->loss, inv_b, s->a3, s->logit, s->prob, s->msums, s->ddot,
+                      s->gh2, n2, bsum2, s->slabs, nst, stream));
+      RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, nst, brNeumfTailSlabElems(n2, n3), gr + oW3, stream));
     } else {
       RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob,
                       s->labels ? s->msums : nullptr, nullptr, 0, nullptr, nullptr, 0, stream));
@@ -202,8 +201,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns1, (int64_t)2 * D * n1 + n1, gr + oW1, stream));
   }
   if (ph & BR_PH_BNG) {
-    RUN(BR_TAG_SMALL, brBnParamGrads(bsum2, gr + og2, gr + obe2, n2, stream));
-    RUN(BR_TAG_SMALL, brBnParamGrads(bsum1, gr + og1, gr + obe1, n1, stream));
+    RUN(BR_TAG_SMALL, brBnParamGradsPair(bsum2, gr + og2, gr + obe2, n2, bsum1, gr + og1, gr + obe1, n1, stream));
   }
   if (ph & BR_PH_OPT_TABLES) {
     if ((ph & BR_PH_EMBED) && deferred)

@@ -12,6 +12,8 @@
 #include "adam_math.h"
 
 #include <algorithm>
+#include <math.h>
+#include <stddef.h>
 #include <hipcub/hipcub.hpp>
 
 namespace br {
@@ -26,6 +28,13 @@ __global__ void sort_prep_kernel(const IdT* __restrict__ ids, int64_t upper, IdT
     const int64_t id = (int64_t)ids[i];
     keys[i] = (upper > 0 && (uint64_t)id >= (uint64_t)upper) ? (IdT)upper : (IdT)id;
   }
+}
+
+__global__ __launch_bounds__(256) void zero_bytes_kernel(uint8_t* __restrict__ p, int64_t n) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (i0 + q < n) p[i0 + q] = 0;
 }
 
 // one row group per sorted position; only segment heads do work
@@ -216,12 +225,33 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ gt
   atomicAdd(gt + id * dim + d, rows[e]);
 }
 
-__global__ void step_state_advance_kernel(StepStateDev* st, double lr, double b1, double b2) {
-  const uint32_t t = st->step + 1;
-  st->step = t;
-  const float a = (float)(lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
-  st->alpha_t = a;
-  st->alpha_hist[t & (BR_ALPHA_RING - 1)] = a;
+// top of a training step: step += 1, alpha_t (thread 0), and the step's double scratch zeroed (all threads) -
+// one launch instead of a memset node plus a kernel
+__global__ __launch_bounds__(256) void step_state_advance_kernel(StepStateDev* st, double lr, double b1, double b2,
+                                                                  double* __restrict__ zero, int64_t n_zero) {
+  for (int64_t i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0.0;
+  if (threadIdx.x == 0) {
+    const uint32_t t = st->step + 1;
+    const double p1 = st->pow_b1 * b1, p2 = st->pow_b2 * b2;
+    const float a = (float)(lr * sqrt(1.0 - p2) / (1.0 - p1));
+    st->step = t;
+    st->pow_b1 = p1;
+    st->pow_b2 = p2;
+    st->alpha_t = a;
+    st->alpha_hist[t & (BR_ALPHA_RING - 1)] = a;
+  }
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void stage_batch_kernel(IdT* __restrict__ du, IdT* __restrict__ di, float* __restrict__ dy,
+                                                           const IdT* __restrict__ su, const IdT* __restrict__ si,
+                                                           const float* __restrict__ sy, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const IdT u = su[i], it = si[i];
+  const float y = sy ? sy[i] : 0.f;
+  du[i] = u; di[i] = it;
+  if (dy) dy[i] = y;
 }
 
 static inline int bits_for(int64_t upper) {
@@ -296,7 +326,7 @@ __global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n
   const int c = (int)(e / kChunk);
   const uint32_t key = job.ck[e];
   uint32_t rank = (uint32_t)(e - (int64_t)c * kChunk);
-  constexpr int G = 8;                                   // chunks searched together (independent load chains)
+  constexpr int G = 8;                                   // chunks searched together (independent probes in flight per step)
   for (int c0 = 0; c0 < n_chunks; c0 += G) {
     uint32_t lo[G], len[G];
 #pragma unroll
@@ -531,11 +561,10 @@ extern "C" int brAdamDenseSweep(float* table, float* m, float* v, int64_t table_
   BR_DISPATCH_VEC(g.vec, (adam_dense_sweep_kernel<VEC><<<(unsigned)blocks, 256, 0, s>>>(table, m, v, n_vec, g.chunks, h, mark)));
   BR_CHECK_LAUNCH("brAdamDenseSweep");
   if (mark) {
-    hipError_t e = hipMemsetAsync(mark, 0, (size_t)table_rows, s);
-    if (e != hipSuccess) {
-      set_error("brAdamDenseSweep: memset failed: %s", hipGetErrorString(e));
-      return BR_ERR_HIP;
-    }
+    // not hipMemsetAsync: a memset NODE of this (odd) size inside a captured hipGraph left garbage in the marks
+    // on ROCm 7.2 when the graph started with it (tests/test_gpu_neumf.py, split replay) - a kernel node is safe
+    zero_bytes_kernel<<<(unsigned)ceil_div(table_rows, 1024), 256, 0, s>>>(mark, table_rows);
+    BR_CHECK_LAUNCH("brAdamDenseSweep(marks)");
   }
   return BR_OK;
 }
@@ -581,9 +610,43 @@ extern "C" int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n
 
 extern "C" int64_t brStepStateBytes(void) { return (int64_t)sizeof(StepStateDev); }
 
-extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream) {
-  BR_CHECK_ARG(step_state != nullptr, "brStepStateAdvance: null state");
-  step_state_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>((StepStateDev*)step_state, lr, beta1, beta2);
+extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, double* zero, int64_t n_zero, brStream stream) {
+  BR_CHECK_ARG(step_state != nullptr && n_zero >= 0 && (zero || n_zero == 0), "brStepStateAdvance: bad args");
+  step_state_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>((StepStateDev*)step_state, lr, beta1, beta2, zero, n_zero);
   BR_CHECK_LAUNCH("brStepStateAdvance");
+  return BR_OK;
+}
+
+extern "C" int brStepStateSet(void* step_state, uint32_t step, double lr, double beta1, double beta2, brStream stream) {
+  BR_CHECK_ARG(step_state != nullptr, "brStepStateSet: null state");
+  struct { uint32_t step; float alpha_t; double p1, p2; } h;
+  static_assert(sizeof(h) == offsetof(StepStateDev, alpha_hist), "StepStateDev head layout");
+  h.step = step;
+  h.p1 = pow(beta1, (double)step);
+  h.p2 = pow(beta2, (double)step);
+  const double tt = step > 0 ? (double)step : 1.0;
+  h.alpha_t = (float)(lr * sqrt(1.0 - pow(beta2, tt)) / (1.0 - pow(beta1, tt)));
+  // pageable source: hipMemcpyAsync returns after the copy has been staged, `h` may leave scope
+  if (hipMemcpyAsync(step_state, &h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+    set_error("brStepStateSet: copy failed");
+    return BR_ERR_HIP;
+  }
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  return BR_OK;
+}
+
+extern "C" int brStageBatch(void* dst_users, void* dst_items, float* dst_labels, const void* users, const void* items,
+                            const float* labels, int id_type, int64_t n, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brStageBatch: bad id_type");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(dst_users && dst_items && users && items && n > 0, "brStageBatch: bad args");
+  const unsigned grid = (unsigned)ceil_div(n, 256);
+  if (id_type == BR_IDS_I32)
+    stage_batch_kernel<int32_t><<<grid, 256, 0, (hipStream_t)stream>>>((int32_t*)dst_users, (int32_t*)dst_items, dst_labels, (const int32_t*)users,
+                                                                        (const int32_t*)items, labels, n);
+  else
+    stage_batch_kernel<int64_t><<<grid, 256, 0, (hipStream_t)stream>>>((int64_t*)dst_users, (int64_t*)dst_items, dst_labels, (const int64_t*)users,
+                                                                        (const int64_t*)items, labels, n);
+  BR_CHECK_LAUNCH("brStageBatch");
   return BR_OK;
 }

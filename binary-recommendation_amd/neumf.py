@@ -211,7 +211,9 @@ class NeuMFEngine:
         for k, n in (("scale1", n1), ("shift1", n1), ("mean1", n1), ("rstd1", n1), ("scale2", n2), ("shift2", n2), ("mean2", n2), ("rstd2", n2)):
             self.bn[k] = self.bn_buf[o:o + n]; o += n
         layers = ((2 * D, n1), (n1, n2), (n2, n3))
-        self.slabs = f(max(ops.dense_backward_slabs(B, k, n) * (k * n + n) for k, n in layers))
+        lib = _lib.load()
+        self.slabs = f(max(max(ops.dense_backward_slabs(B, k, n) * (k * n + n) for k, n in layers),
+                           lib.brNeumfTailSlabs(B) * lib.brNeumfTailSlabElems(n2, n3)))
         self.dz_ws = f(max(ops.dense_backward_ws_floats(B, k, n) for k, n in layers))
         self.nsh = ops.head_slabs(B)
         self.hslabs = f(self.nsh * (n3 + 2))
@@ -270,13 +272,16 @@ class NeuMFEngine:
     def _run(self, phases: int):
         _lib.check(_lib.load().brNeumfStepRun(ctypes.byref(self.step_struct), phases, ops._stream()), "brNeumfStepRun")
 
-    def _set_batch(self, users, items, labels, B, training, row0, batch_total):
-        st = self.step_struct
+    def _check_batch(self, users, items, labels):
         for t in (users, items):
             if t.dtype != self.id_dtype or not t.is_cuda or not t.is_contiguous():
                 raise TypeError(f"ids must be contiguous {self.id_dtype} device tensors")
         if labels is not None and (labels.dtype != torch.float32 or not labels.is_contiguous()):
             raise TypeError("labels must be contiguous float32")
+
+    def _set_batch(self, users, items, labels, B, training, row0, batch_total):
+        st = self.step_struct
+        self._check_batch(users, items, labels)
         st.batch, st.batch_total, st.row0 = B, batch_total, row0
         st.users, st.items = users.data_ptr(), items.data_ptr()
         st.labels = labels.data_ptr() if labels is not None else None
@@ -425,20 +430,17 @@ class NeuMFEngine:
         self._graph = None
 
     def _sync_step_state(self):
-        """device step counter := self.t (after enable_graph / load_state_dict)."""
+        """device step state := (self.t, alpha_t, beta^t) (after enable_graph / load_state_dict)."""
         if getattr(self, "step_state", None) is not None:
-            a = ops.adam_alpha(self.cfg.lr, max(self.t, 1), self.cfg.beta1, self.cfg.beta2)
-            host = torch.tensor([self.t], dtype=torch.int32)
-            self.step_state[0:1].copy_(host)
-            self.step_state[1:2].view(torch.float32).fill_(a)
+            cfg = self.cfg
+            _lib.check(_lib.load().brStepStateSet(self.step_state.data_ptr(), self.t, cfg.lr, cfg.beta1, cfg.beta2, ops._stream()), "brStepStateSet")
 
     def _replay(self, users, items, labels):
-        if users.data_ptr() != self.in_users.data_ptr():
-            self.in_users.copy_(users)
-        if items.data_ptr() != self.in_items.data_ptr():
-            self.in_items.copy_(items)
-        if labels.data_ptr() != self.in_labels.data_ptr():
-            self.in_labels.copy_(labels)
+        if users.data_ptr() != self.in_users.data_ptr() or items.data_ptr() != self.in_items.data_ptr() or labels.data_ptr() != self.in_labels.data_ptr():
+            self._check_batch(users, items, labels)
+            _lib.check(_lib.load().brStageBatch(self.in_users.data_ptr(), self.in_items.data_ptr(), self.in_labels.data_ptr(), users.data_ptr(),
+                                                items.data_ptr(), labels.data_ptr(), self.step_struct.id_type, users.shape[0], ops._stream()),
+                       "brStageBatch")
         gr = self._graph
         for ph, g in zip(gr["parts"], gr["graphs"]):
             if g is None:

@@ -200,7 +200,26 @@ int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, 
                     double* in_bn_sums, brStream stream);
 /* dgamma = sum gy*xhat, dbeta = sum gy: the BN-backward column sums as fp32 parameter grads. */
 int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta, int N, brStream stream);
+int brBnParamGradsPair(const double* sums_a, float* dgamma_a, float* dbeta_a, int Na, const double* sums_b, float* dgamma_b,
+                       float* dbeta_b, int Nb, brStream stream);
 int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* out, brStream stream);
+
+/* ---- fused tail of the training step: T(a2) -> Dense(n3) -> concat [dot | a3] -> Dense(1) -> sigmoid -> loss and the
+ * backward of all of it, one launch (trainers/NFC_plain.py:143-155, src/models/NeuMFModel.py:75-93) ----
+ * Same results as brDenseForward(layer 3) + brNeumfHead + brDenseBackward(layer 3) (fp32 sums in a different
+ * order).  a2: (B x n2) raw output of layer 2; scale2/shift2/mean2/rstd2 from brBnFinalize; dropout site `site`.
+ * Outputs: a3 (B x n3, may be NULL), logit/prob/ddot (B), gh2 (B x n2) = gradient w.r.t. BN2's output,
+ * bn_sums (double[BR_STAT_REPLICAS][2*n2]) += (sum gh2, sum gh2*xhat2), sums as brNeumfHead, and one slab per
+ * workgroup [dW3 (n2*n3) | db3 (n3) | dW4 (n3+1, concat order) | db4]: n_slabs = brNeumfTailSlabs(batch),
+ * brNeumfTailSlabElems(n2, n3) floats each, reduced by ONE brReduceSlabs into the adjacent W3|b3|W4|b4 grads. */
+int brNeumfTailSlabs(int64_t batch);
+int64_t brNeumfTailSlabElems(int n2, int n3);
+int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, const float* b3, const float* w4, const float* b4,
+                     const float* dot, const float* labels, const float* scale2, const float* shift2, const float* mean2,
+                     const float* rstd2, float drop_p, uint64_t seed, uint32_t step, uint32_t site, int64_t row0,
+                     int64_t batch, int n2, int n3, int act, int mf_first, int loss, float inv_batch, float* a3,
+                     float* logit, float* prob, double* sums, float* ddot, float* gh2, int64_t ldgh2, double* bn_sums,
+                     float* slabs, int n_slabs, brStream stream);
 
 /* ---- head: concat [GMF dot | MLP out] -> Dense(1) -> sigmoid -> loss, and its backward --------
  * NFC_plain.py:149-155 (mf_first=1, BCE) / NeuMFModel.py:80-91 (mf_first=0, MSE).
@@ -309,10 +328,16 @@ typedef struct brNeumfStep {
 } brNeumfStep;
 /* step_state: device {uint32 step; float alpha_t; float alpha_hist[BR_ALPHA_RING]}, brStepStateBytes() bytes,
  * zero-initialised (or step / alpha_t set by the host after a reload).
- * Advance: step += 1, alpha_t = alpha_hist[step % BR_ALPHA_RING] = lr*sqrt(1-b2^step)/(1-b1^step). */
+ * Advance: step += 1, alpha_t = alpha_hist[step % BR_ALPHA_RING] = lr*sqrt(1-b2^step)/(1-b1^step) (b^step kept as a
+ * running double product), and `zero[0..n_zero)` (the step's double scratch) cleared in the same launch. */
 enum { BR_ALPHA_RING = 1024 };
 int64_t brStepStateBytes(void);
-int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, brStream stream);
+int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, double* zero, int64_t n_zero, brStream stream);
+/* host -> device: step, alpha_t and the running beta powers for that step (after a reload); synchronises the stream */
+int brStepStateSet(void* step_state, uint32_t step, double lr, double beta1, double beta2, brStream stream);
+/* one launch that copies a batch (ids, ids, labels) into the static input buffers a captured hipGraph reads */
+int brStageBatch(void* dst_users, void* dst_items, float* dst_labels, const void* users, const void* items,
+                 const float* labels, int id_type, int64_t n, brStream stream);
 
 /* ---- Deferred dense Adam (brNeumfStep.adam_dense == 2) --------------------------------------------------
  * Keras' Adam applies the g = 0 update to every row of an embedding table on every step ([TF-sem], the
