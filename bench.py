@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--variant", default="A")
     ap.add_argument("--optimizer", default="adam_dense", choices=["adam_dense", "adam_lazy"])
     ap.add_argument("--dense-impl", default=None, choices=["deferred", "sweep"],
-                    help="adam_dense: per-row deferred replay (default on one GPU) or one table sweep per step (row-sharded runs)")
+                    help="adam_dense: per-row deferred replay (default) or one table sweep per step")
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) ids instead of uniform")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,7 +200,7 @@ def main():
     batch_total = B * world
     row0 = rank * B
 
-    impl = args.dense_impl or ("deferred" if world == 1 else "sweep")
+    impl = args.dense_impl or "deferred"
 
     def build(optimizer, dense_impl=impl):
         cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl)
@@ -252,6 +252,7 @@ def main():
             users_rows = eng.local_rows("user_mf")
             pyprobe = PyProbe({"brAdamDenseSweep": lambda a: TAG["SWEEP_USER"] if int(a[3]) == users_rows else TAG["SWEEP_ITEM"],
                                "brAdamRowsSorted": lambda a: TAG["ADAM_ROWS_USER"] if int(a[3]) == users_rows else TAG["ADAM_ROWS_ITEM"],
+                               "brAdamRowsSortedDeferred": lambda a: TAG["ADAM_ROWS_USER"] if int(a[4]) == users_rows else TAG["ADAM_ROWS_ITEM"],
                                "brNeumfEmbedForward": lambda a: TAG["EMBED_FWD"], "brNeumfEmbedBackward": lambda a: TAG["EMBED_BWD"]})
             _lib.set_probe(pyprobe)
         dt = timed(eng, batches, args.steps, 0, ctx, row0, batch_total)

@@ -174,6 +174,37 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_deferred_kernel(
   if (live && lir == 0) dot[b] = s;
 }
 
+// G1 on a deferred-Adam table (adam_math.h): out[b] = the row of ids[b] brought up to step t-1 in registers,
+// nothing written back (the row-sharded owner serves lookups with it; the single-GPU step uses the fused
+// neumf_embed_fwd_deferred_kernel).
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void gather_rows_deferred_kernel(
+    const float* __restrict__ table, const float* __restrict__ M, const float* __restrict__ Vv, const int32_t* __restrict__ last,
+    int64_t rows, int dim, int chunks, int lpr_log2, const IdT* __restrict__ ids, int64_t n, const StepStateDev* __restrict__ ss,
+    AdamHp h, float* __restrict__ out, int64_t ld_out, int* err) {
+  using V = typename VecT<VEC>::type;
+  __shared__ float ring[BR_ALPHA_RING];
+  stage_alpha_ring(ring, ss);
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (b >= n) return;
+  int64_t r = load_id(ids, b);
+  const bool ok = (uint64_t)r < (uint64_t)rows;
+  if (!ok) { if (err && lir == 0) *err = 1; r = 0; }
+  const uint32_t t = ss->step, seen = (uint32_t)last[r];
+  for (int c = lir; c < chunks; c += lpr) {
+    const int64_t off = r * dim + c * VEC;
+    V th = vload<VEC>(table + off);
+    if (seen + 1 < t) {
+      V m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
+      adam_replay(th, m, v, seen, t - 1, ring, h);
+    }
+    vstore<VEC>(out + b * ld_out + c * VEC, ok ? th : vzero<VEC>());
+  }
+}
+
 // B1 of the GMF dot on the stashed MF rows, in place: (u, i) -> (ddot * i, ddot * u).  No __restrict__: the
 // two outputs ARE the two inputs.
 template <int VEC>
@@ -420,6 +451,28 @@ extern "C" int brNeumfEmbedForwardDeferred(const float* user_tab, const float* u
                                stash_user, stash_item, ld_stash, err_flag)));
   }
   BR_CHECK_LAUNCH("brNeumfEmbedForwardDeferred");
+  return BR_OK;
+}
+
+extern "C" int brGatherRowsDeferred(const float* table, const float* m, const float* v, const int32_t* last, int64_t table_rows, int dim,
+                                    const void* ids, int id_type, int64_t n, const void* step_state, double beta1, double beta2,
+                                    double eps, float* out, int64_t ld_out, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(table && m && v && last && step_state && out && dim >= 1 && table_rows > 0 && n >= 0 && ld_out >= dim, "brGatherRowsDeferred: bad args");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brGatherRowsDeferred: bad id_type");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(ids != nullptr, "brGatherRowsDeferred: null ids");
+  const RowGeom g = row_geom_ld(dim, ld_out);
+  const unsigned grid = grid_for_rows(n, g.lpr_log2);
+  const AdamHp h = make_hp(0.0, beta1, beta2, eps);
+  const StepStateDev* ss = (const StepStateDev*)step_state;
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(g.vec, (gather_rows_deferred_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(table, m, v, last, table_rows, dim, g.chunks, g.lpr_log2,
+                                                                                           (const int32_t*)ids, n, ss, h, out, ld_out, err_flag)));
+  else
+    BR_DISPATCH_VEC(g.vec, (gather_rows_deferred_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(table, m, v, last, table_rows, dim, g.chunks, g.lpr_log2,
+                                                                                           (const int64_t*)ids, n, ss, h, out, ld_out, err_flag)));
+  BR_CHECK_LAUNCH("brGatherRowsDeferred");
   return BR_OK;
 }
 

@@ -132,7 +132,8 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const bool aux_index = build_index && s->aux_stream && (ph & BR_PH_FWD1);
   bool joined = !aux_index;
   const int64_t n_dstat = (int64_t)BR_STAT_REPLICAS * (4 * n1 + 4 * n2);
-  if ((ph & BR_PH_FWD1) && train && s->step_state)
+  // (a host that runs the embedding exchange itself - no EMBED bit - advanced the state before its lookup)
+  if ((ph & BR_PH_FWD1) && (ph & BR_PH_EMBED) && train && s->step_state)
     RUN(BR_TAG_SMALL, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, s->dstat, n_dstat, stream));
   if (ph & BR_PH_FWD1) {
     if (train && !s->step_state) {

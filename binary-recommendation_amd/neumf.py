@@ -102,7 +102,7 @@ class NeuMFEngine:
         dev = self.device
         g = torch.Generator(device="cpu").manual_seed(init_seed)
         # [TF-sem] Embedding init U(-0.05, 0.05); Dense glorot-uniform; bias 0; BN gamma 1 beta 0
-        self.deferred = cfg.optimizer == "adam_dense" and cfg.dense_impl == "deferred" and not self.sharded
+        self.deferred = cfg.optimizer == "adam_dense" and cfg.dense_impl == "deferred"
         self._stale = False                   # deferred: rows lag behind self.t until flush()
         self._flush_t = 0
         self._init_tables(g, init_seed)
@@ -237,7 +237,8 @@ class NeuMFEngine:
         st.act, st.loss = ops.ACT[cfg.act], ops.LOSS[cfg.loss]
         st.item_first, st.mf_first = cfg.item_first, cfg.mf_first
         st.id_type = ops.I64 if self.id_dtype == torch.int64 else ops.I32
-        st.adam_dense = 2 if self.deferred else 1 if cfg.optimizer == "adam_dense" else 0
+        # (row-sharded: the table optimizer runs from Python on the owner's shard, the driver never sees it)
+        st.adam_dense = (2 if self.deferred else 1 if cfg.optimizer == "adam_dense" else 0) if not self.sharded else 0
         st.dropout, st.bn_eps, st.bn_momentum = cfg.dropout, cfg.bn_eps, cfg.bn_momentum
         st.seed = cfg.seed
         st.beta1, st.beta2, st.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
@@ -247,7 +248,8 @@ class NeuMFEngine:
         if st.adam_dense == 1:
             st.user_mark, st.item_mark = P(self.user_mark), P(self.item_mark)
         if self.deferred:
-            st.user_last, st.item_last = P(self.last["user"]), P(self.last["item"])
+            if not self.sharded:
+                st.user_last, st.item_last = P(self.last["user"]), P(self.last["item"])
             self._alloc_step_state(st)
         st.theta, st.grad, st.adam_m, st.adam_v = P(self.theta.buf), P(self.grad.buf), P(self.adam_m.buf), P(self.adam_v.buf)
         st.moving = P(self.moving_buf)
@@ -338,6 +340,11 @@ class NeuMFEngine:
         d, sync = self.dist, cfg.sync_bn
         emb = 0 if self.sharded else PH["EMBED"]
         if self.sharded:
+            if getattr(self, "step_state", None) is not None:
+                # the lookup below replays against the device step counter: advance it first (the driver only does
+                # so in a call that holds FWD1|EMBED); the same launch clears the step's double scratch
+                _lib.check(_lib.load().brStepStateAdvance(self.step_state.data_ptr(), cfg.lr, cfg.beta1, cfg.beta2, self.dstat.data_ptr(),
+                                                          self.dstat.numel(), ops._stream()), "brStepStateAdvance")
             self._embed_forward(users, items, B)
         self._run(PH["FWD1"] | emb)
         if sync:
@@ -474,11 +481,15 @@ class NeuMFEngine:
         cfg, D = self.cfg, self.cfg.dim
         a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
         hp = dict(beta1=cfg.beta1, beta2=cfg.beta2, eps=cfg.adam_eps)
-        dense = cfg.optimizer == "adam_dense"
+        dense = cfg.optimizer == "adam_dense" and not self.deferred      # per-step sweep of the untouched rows
         for stream in ("user", "item"):
             idx = self.user_index if stream == "user" else self.item_index
             mark = (self.user_mark if stream == "user" else self.item_mark) if dense else None
             g0, ld0, g1, ld1 = rg[stream]
+            if self.deferred:
+                ops.adam_rows_sorted_deferred(self.fused[stream], self.fused_m[stream], self.fused_v[stream], self.last[stream], idx, g0, ld0,
+                                              self.step_state, row_grads_hi=g1, ldg_hi=ld1, split=D if g1 is not None else 0, **hp)
+                continue
             ops.adam_rows_sorted(self.fused[stream], self.fused_m[stream], self.fused_v[stream], idx, g0, ld0, a, mark=mark,
                                  row_grads_hi=g1, ldg_hi=ld1, split=D if g1 is not None else 0, **hp)
             if dense:

@@ -81,6 +81,26 @@ def gather_rows(tables, ids, outs=None, err_flag=None):
     return outs
 
 
+def gather_rows_deferred(table, m, v, last, ids, step_state, beta1=0.9, beta2=0.999, eps=1e-7, out=None, err_flag=None):
+    """Lookup on a deferred-Adam table (include/binrec.h "Deferred dense Adam"): rows as of the previous step."""
+    t, ty = _ids(ids, "ids")
+    n, dim = t.shape[0], table.shape[1]
+    if out is None:
+        out = torch.empty((n, dim), dtype=torch.float32, device=table.device)
+    check(_lib.load().brGatherRowsDeferred(_f32(table, "table").data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), table.shape[0], dim,
+                                           t.data_ptr(), ty, n, step_state.data_ptr(), beta1, beta2, eps, out.data_ptr(), out.stride(0),
+                                           _p(err_flag), _stream()), "brGatherRowsDeferred")
+    return out
+
+
+def adam_rows_sorted_deferred(table, m, v, last, index, row_grads, ldg, step_state, beta1=0.9, beta2=0.999, eps=1e-7,
+                              row_grads_hi=None, ldg_hi=0, split=0):
+    check(_lib.load().brAdamRowsSortedDeferred(table.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), table.shape[0], table.shape[1],
+                                               index.sorted_ids.data_ptr(), index.id_type, index.sorted_pos.data_ptr(), index.n,
+                                               row_grads.data_ptr(), ldg, _p(row_grads_hi), ldg_hi, split, step_state.data_ptr(),
+                                               beta1, beta2, eps, _stream()), "brAdamRowsSortedDeferred")
+
+
 def row_dot(a, b, out=None):
     _f32(a, "a"); _f32(b, "b")
     if out is None:

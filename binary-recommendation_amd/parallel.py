@@ -172,7 +172,9 @@ def make_sharded_engine(base_cls):
             # an owner can receive more than B ids in a step; indexes are (re)grown on demand
             self._idx_cap = 0
             self._grow_index(2 * B)
-            if self.cfg.optimizer == "adam_dense":
+            if self.deferred:
+                self.last = {k: torch.zeros(self.local_rows(k + "_mf"), dtype=torch.int32, device=self.device) for k in ("user", "item")}
+            elif self.cfg.optimizer == "adam_dense":
                 self.user_mark = torch.zeros(self.local_rows("user_mf"), dtype=torch.uint8, device=self.device)
                 self.item_mark = torch.zeros(self.local_rows("item_mf"), dtype=torch.uint8, device=self.device)
 
@@ -191,14 +193,22 @@ def make_sharded_engine(base_cls):
             ru, ri = xu.send_ids(), xi.send_ids()      # all-to-all #1
             empty = torch.empty(0, 2 * D, device=self.device)
             # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64)
-            gu = ops.gather_rows([self.fused["user"]], [ru], err_flag=self.err)[0] if ru.numel() else empty
-            gi = ops.gather_rows([self.fused["item"]], [ri], err_flag=self.err)[0] if ri.numel() else empty
+            gu = self._serve_rows("user", ru) if ru.numel() else empty
+            gi = self._serve_rows("item", ri) if ri.numel() else empty
             self.r_user, self.r_item = xu.return_rows(gu), xi.return_rows(gi)      # all-to-all #2
             self.pos_u = xu.inv.to(self.id_dtype)
             self.pos_i = xi.inv.to(self.id_dtype)
             # requester-side: same fused embed kernel, "tables" = received rows, ids = bucket slots
             ops.neumf_embed_forward(self.r_user[:, :D], self.r_item[:, :D], self.r_user[:, D:], self.r_item[:, D:], self.pos_u,
                                     self.pos_i, self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
+
+        def _serve_rows(self, stream, local_ids):
+            """owner side of the lookup: rows of this rank's shard for the ids its peers asked for."""
+            if self.deferred:      # rows as of the previous step, replayed in registers (binrec.h "Deferred dense Adam")
+                cfg = self.cfg
+                return ops.gather_rows_deferred(self.fused[stream], self.fused_m[stream], self.fused_v[stream], self.last[stream], local_ids,
+                                                self.step_state, cfg.beta1, cfg.beta2, cfg.adam_eps, err_flag=self.err)
+            return ops.gather_rows([self.fused[stream]], [local_ids], err_flag=self.err)[0]
 
         def _embed_backward_apply(self, users, items, B):
             cfg, D = self.cfg, self.cfg.dim

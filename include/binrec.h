@@ -317,7 +317,8 @@ typedef struct brNeumfStep {
   void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;
   void* i_sorted_ids; int32_t* i_sorted_pos; void* i_ws; int64_t i_ws_bytes;
   double lr;          /* learning rate (only used with step_state) */
-  void* step_state;   /* optional device step state (brStepStateBytes()): when non-NULL the step advances it in
+  void* step_state;   /* optional device step state (brStepStateBytes()): when non-NULL (and the call holds
+                         BR_PH_FWD1|BR_PH_EMBED; a host that runs the lookup itself advances it itself, before the lookup) the step advances it in
                          FWD1 (step += 1, alpha_t = lr*sqrt(1-b2^step)/(1-b1^step)) and every kernel reads the
                          dropout step / Adam alpha from there instead of `step` / `alpha_t` above, so the whole
                          call can be captured once in a hipGraph and replayed */
@@ -355,6 +356,10 @@ int brNeumfEmbedForwardDeferred(const float* user_tab, const float* user_m, cons
                                 int dim, int64_t batch, int item_first, const void* step_state, double beta1, double beta2,
                                 double eps, float* x0, float* dot, float* stash_user, float* stash_item, int64_t ld_stash,
                                 int* err_flag, brStream stream);
+/* G1 on one deferred table: out[b] = row ids[b] as of step-1 (replayed in registers, nothing written back). */
+int brGatherRowsDeferred(const float* table, const float* m, const float* v, const int32_t* last, int64_t table_rows, int dim,
+                         const void* ids, int id_type, int64_t n, const void* step_state, double beta1, double beta2,
+                         double eps, float* out, int64_t ld_out, int* err_flag, brStream stream);
 /* B1 of the GMF dot on the MF rows the deferred forward stashed, in place: (u_b, i_b) -> (ddot_b i_b, ddot_b u_b). */
 int brMfGradInplace(float* stash_user, float* stash_item, int64_t ld, const float* ddot, int64_t batch, int dim, brStream stream);
 int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,

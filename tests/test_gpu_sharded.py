@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, variant, dim, optimizer, q):
+def _worker(rank, world, port, variant, dim, optimizer, impl, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -38,7 +38,7 @@ def _worker(rank, world, port, variant, dim, optimizer, q):
         B = Bl * world
         spec = O.NeuMFSpec(variant, dim=dim)
         p = O.neumf_init(spec, U, I, seed=5, dt=np.float32)
-        cfg = neumf.NeuMFConfig(variant=variant, dim=dim, optimizer=optimizer, seed=777)
+        cfg = neumf.NeuMFConfig(variant=variant, dim=dim, optimizer=optimizer, seed=777, dense_impl=impl)
         Sharded = par.make_sharded_engine(neumf.NeuMFEngine)
         full = {k: torch.from_numpy(p[k]) for k in neumf.TABLES}
         eng = Sharded(cfg, U, I, dev, Bl, ctx, full_tables=full)
@@ -50,7 +50,8 @@ def _worker(rank, world, port, variant, dim, optimizer, q):
         M = {k: np.zeros_like(P[k]) for k in keys}
         V = {k: np.zeros_like(P[k]) for k in keys}
         td = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
-        for t in (1, 2):
+        nsteps = 4      # rows sit out up to 3 steps: the deferred owners replay them on lookup
+        for t in range(1, nsteps + 1):
             u = rng.integers(0, U, B); i = rng.integers(0, I, B); u[:30] = 4
             y = (rng.random(B) < 0.25).astype(np.float32)
             sl = slice(rank * Bl, (rank + 1) * Bl)
@@ -70,7 +71,7 @@ def _worker(rank, world, port, variant, dim, optimizer, q):
             P.update(ns)
         torch.cuda.synchronize()
         eng.check_ids()
-        travel = 2 * cfg.lr
+        travel = nsteps * cfg.lr
         for k in neumf.TABLES:
             ref = P[k][rank::world]
             got = eng.tables[k].cpu().numpy()[: ref.shape[0]]
@@ -90,12 +91,12 @@ def _worker(rank, world, port, variant, dim, optimizer, q):
             pass
 
 
-@pytest.mark.parametrize("variant,dim,optimizer", [("A", 64, "adam_dense"), ("B", 32, "adam_lazy")])
-def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer):
+@pytest.mark.parametrize("variant,dim,optimizer,impl", [("A", 64, "adam_dense", "deferred"), ("A", 64, "adam_dense", "sweep"), ("B", 32, "adam_lazy", "sweep")])
+def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer, impl):
     world, port = 2, _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, variant, dim, optimizer, q)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, variant, dim, optimizer, impl, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
