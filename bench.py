@@ -284,8 +284,13 @@ def main():
 
     # algorithmic work per launch: gather 4*D*4 B + 8 B ids per pair; Adam sweep 6*4 B per
     # table element; Adam rows: g row + read/write theta,m,v = 7*4 B per element of a touched row (upper bound: no dups)
-    hbm("neumf_embed_fwd(gather4+dot+concat)", "EMBED_FWD", B * (4 * D * 4 + 8))
-    hbm("neumf_embed_bwd", "EMBED_BWD", B * (4 * D * 4 + 8))
+    if getattr(eng, "deferred", False):
+        # deferred lookup: a lagging row also brings its m and v (upper bound: every row lags), plus x0 and the MF stash out
+        hbm("neumf_embed_fwd_deferred(gather4 + replay + dot + concat)", "EMBED_FWD", B * (3 * 4 * D * 4 + 4 * D * 4 + 16))
+        hbm("mf_grad_inplace", "EMBED_BWD", B * (2 * 2 * D * 4 + 4))
+    else:
+        hbm("neumf_embed_fwd(gather4+dot+concat)", "EMBED_FWD", B * (4 * D * 4 + 8))
+        hbm("neumf_embed_bwd", "EMBED_BWD", B * (4 * D * 4 + 8))
     hbm(f"adam_dense_sweep[user {loc_users}x{2 * D}]", "SWEEP_USER", 6 * 4 * loc_users * 2 * D)
     hbm(f"adam_dense_sweep[item {loc_items}x{2 * D}]", "SWEEP_ITEM", 6 * 4 * loc_items * 2 * D)
     hbm("adam_rows_sorted[user]", "ADAM_ROWS_USER", B * 7 * 2 * D * 4)
@@ -296,7 +301,7 @@ def main():
     mfma(f"dense_bwd[{2 * D}x{n1}]", "BWD_L1", 4.0 * B * 2 * D * n1)
     mfma(f"dense_bwd[{n1}x{n2}]", "BWD_L2", 4.0 * B * n1 * n2)
     mfma(f"dense_bwd[{n2}x{n3}]", "BWD_L3", 4.0 * B * n2 * n3)
-    for name, tag in (("row_index_build[user]", "INDEX_USER"), ("row_index_build[item]", "INDEX_ITEM"), ("head+loss", "HEAD"),
+    for name, tag in (("row_index_build[user]", "INDEX_USER"), ("row_index_build[item]", "INDEX_ITEM"), ("tail: dense 3 fwd + head + loss + their backward (one launch)", "HEAD"),
                       ("reduce_slabs (each)", "REDUCE"), ("bn/small (each)", "SMALL"), ("adam_flat", "ADAM_FLAT")):
         if TAG[tag] in per_tag:
             kernels[name] = {"_tag": TAG[tag], "us": per_tag[TAG[tag]][0], "launches": per_tag[TAG[tag]][1]}
