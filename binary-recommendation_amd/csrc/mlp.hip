@@ -43,6 +43,7 @@ struct InXform {       // T(x): BatchNorm affine of the producer + dropout, appl
   const float* scale;  // (K) or null (global; the kernels stage scale|shift into LDS once)
   const float* shift;  // (K) or null
   DropoutCfg drop;
+  uint32_t c8off;      // first 8-column dropout chunk of this launch (split-K: the second half of a K > 128 layer)
 };
 
 // Branch-free guarded loads.  Every load below is issued UNCONDITIONALLY from an address clamped
@@ -90,7 +91,7 @@ __device__ __forceinline__ uint32_t xform8(float (&v)[8], const InXform& t, cons
   }
   uint32_t bits = 0xFFu;
   if (t.drop.thr) {
-    bits = dropout_keep8(t.drop, grow, (uint32_t)(c >> 3));
+    bits = dropout_keep8(t.drop, grow, (uint32_t)(c >> 3) + t.c8off);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ((bits >> i) & 1u) ? v[i] * t.drop.inv_keep : 0.f;
   }
@@ -112,9 +113,9 @@ __device__ __forceinline__ void store8_lds(float* dst, const float (&v)[8]) {
 // Per-wave scratch in LDS: dropout keep-bytes [16 rows][2*KJ] (4 Philox calls per lane per tile).
 template <int NT, int KJ>
 __global__ __launch_bounds__(kThreads, 2) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
-                                                                 const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
+                                                                 const float* __restrict__ bias, float* y, int64_t ldy,
                                                                  int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
-                                                                 double* __restrict__ stats) {
+                                                                 double* __restrict__ stats, const float* yin) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   dropout_resolve(tin.drop);
   constexpr int Np = NT * 16, Kp = KJ * 16, NCH = 2 * KJ;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_fwd_kernel(const float* __r
 #pragma unroll
       for (int i = 0; i < (16 * NCH + 63) / 64; ++i) {
         const int q = lane + 64 * i;
-        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH));
+        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH) + tin.c8off);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -256,8 +257,9 @@ __global__ __launch_bounds__(kThreads, 2) void dense_fwd_kernel(const float* __r
         for (int w = 0; w < WMAX; ++w) {
           if (w < Wn) {
             const int n = (nt0 + w) * 16 + c16;
-            const float v = act_apply(acc[w][r] + bcol[nt0 + w], act);
             if (gr < batch && n < N) {
+              // yin: the other K-half's partial sums (split-K for K > 128; same element, read before it is written)
+              const float v = act_apply(acc[w][r] + bcol[nt0 + w] + (yin ? yin[gr * ldy + n] : 0.f), act);
               y[gr * ldy + n] = v;
               ssum[nt0 + w] += v;
               ssq[nt0 + w] += v * v;
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
 #pragma unroll
       for (int i = 0; i < (16 * NCH + 63) / 64; ++i) {
         const int q = lane + 64 * i;
-        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH));
+        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH) + tin.c8off);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
 template <int NT, int KTP>
 __global__ __launch_bounds__(kThreads, 2) void dense_dw_kernel(const float* __restrict__ dzbuf, const float* __restrict__ x, int64_t ldx_g,
                                                                 int64_t batch, int K, int N, InXform tin, int64_t row0,
-                                                                float* __restrict__ slabs) {
+                                                                float* __restrict__ slabs, int64_t slab_elems, int64_t db_off) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   dropout_resolve(tin.drop);
   constexpr int Np = NT * 16, ldz = Np + 4;
@@ -697,8 +699,8 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dw_kernel(const float* __re
     __syncthreads();
     tile = next;
   }
-  // ---- slab (workgroup, row group): [dW (K x N) | db (N)] ----
-  const int64_t slab_elems = (int64_t)K * N + N;
+  // ---- slab (workgroup, row group): [dW (K x N) | db (N)]; split-K: `slabs` points at this half's first row of dW,
+  //      slab_elems is the whole layer's slab, db sits db_off floats behind (db_off < 0: the other half writes db) ----
   if (kt_live) {
     float* slab = slabs + ((int64_t)blockIdx.x * RGN + rg) * slab_elems;
 #pragma unroll
@@ -711,9 +713,9 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dw_kernel(const float* __re
       }
     }
   }
-  if ((int)threadIdx.x < N) {
+  if ((int)threadIdx.x < N && db_off >= 0) {
     for (int r = 0; r < RGN; ++r)
-      slabs[((int64_t)blockIdx.x * RGN + r) * slab_elems + (int64_t)K * N + threadIdx.x] = (r == 0) ? db_acc : 0.f;
+      slabs[((int64_t)blockIdx.x * RGN + r) * slab_elems + db_off + threadIdx.x] = (r == 0) ? db_acc : 0.f;
   }
 }
 
@@ -887,32 +889,21 @@ static inline unsigned grid_for(int64_t batch, int tm) {
 constexpr int kMaxDynLds = 150 * 1024;
 template <int NT, int KJ>
 static void launch_fwd(unsigned grid, size_t shmem, hipStream_t s, const float* x, int64_t ldx, const float* W, const float* bias, float* y,
-                       int64_t ldy, int64_t batch, int K, int N, int act, InXform t, int64_t row0, double* stats) {
+                       int64_t ldy, int64_t batch, int K, int N, int act, InXform t, int64_t row0, double* stats, const float* yin) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     attr_set = true;
   }
-  dense_fwd_kernel<NT, KJ><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats);
+  dense_fwd_kernel<NT, KJ><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats, yin);
 }
 
-extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
-                              int64_t batch, int K, int N, int act, const float* in_scale, const float* in_shift,
-                              float drop_p, uint64_t seed, uint32_t step, uint32_t site, int64_t row0, double* stats,
-                              brStream stream) {
-  BR_CHECK_ARG(x && W && y && batch >= 0 && K >= 1 && N >= 1, "brDenseForward: bad args");
-  BR_CHECK_ARG(K <= kMaxT * 16 && N <= kMaxT * 16, "brDenseForward: K=%d N=%d exceed %d", K, N, kMaxT * 16);
-  BR_CHECK_ARG(ldx >= K && ldy >= N, "brDenseForward: bad leading dims");
-  BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
-  BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
-  if (batch == 0) return BR_OK;
+static int dense_forward_one(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy, int64_t batch, int K, int N,
+                             int act, InXform t, int64_t row0, double* stats, const float* yin, hipStream_t s) {
   const int NT = tiles16(N), KJ = tiles16(K), Kp = KJ * 16, Np = NT * 16;
   const size_t shmem = ((size_t)Kp * Np + 2 * (size_t)Kp) * sizeof(float) + (size_t)8 * 16 * 2 * KJ + 16;
-  InXform t{in_scale, in_shift, make_dropout(drop_p, seed, step, site)};
-  if (const StepStateDev* ss = current_step_state()) t.drop.step_ptr = &ss->step;
-  hipStream_t s = (hipStream_t)stream;
   const unsigned grid = grid_for(batch, 16 * 8);
-#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(grid, shmem, s, x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats); break;
+#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(grid, shmem, s, x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats, yin); break;
 #define BR_FWD(NTv)                                                                                        \
   case NTv:                                                                                                \
     switch (KJ) { BR_FWD_KJ(NTv, 1) BR_FWD_KJ(NTv, 2) BR_FWD_KJ(NTv, 3) BR_FWD_KJ(NTv, 4) BR_FWD_KJ(NTv, 5) \
@@ -924,6 +915,34 @@ extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const
   }
   BR_CHECK_LAUNCH("brDenseForward");
   return BR_OK;
+}
+
+// K > 128 (config 5: 2 x embed_dim 128 = 256 inputs) runs as two K-halves: the first launch leaves the raw partial
+// sums in y, the second adds them in its epilogue (bias, activation, BatchNorm column sums only there).  The split
+// point is a multiple of 8 so that the dropout chunks (8 columns per Philox call) keep their global numbering.
+static inline int split_k(int K) { return ((K / 2 + 7) / 8) * 8; }
+
+extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
+                              int64_t batch, int K, int N, int act, const float* in_scale, const float* in_shift,
+                              float drop_p, uint64_t seed, uint32_t step, uint32_t site, int64_t row0, double* stats,
+                              brStream stream) {
+  BR_CHECK_ARG(x && W && y && batch >= 0 && K >= 1 && N >= 1, "brDenseForward: bad args");
+  BR_CHECK_ARG(K <= 2 * kMaxT * 16 && N <= kMaxT * 16, "brDenseForward: K=%d N=%d exceed %d / %d", K, N, 2 * kMaxT * 16, kMaxT * 16);
+  BR_CHECK_ARG(ldx >= K && ldy >= N, "brDenseForward: bad leading dims");
+  BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
+  BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
+  if (batch == 0) return BR_OK;
+  InXform t{in_scale, in_shift, make_dropout(drop_p, seed, step, site), 0u};
+  if (const StepStateDev* ss = current_step_state()) t.drop.step_ptr = &ss->step;
+  hipStream_t s = (hipStream_t)stream;
+  if (K <= kMaxT * 16) return dense_forward_one(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats, nullptr, s);
+  const int Ka = split_k(K);
+  int rc = dense_forward_one(x, ldx, W, nullptr, y, ldy, batch, Ka, N, BR_ACT_LINEAR, t, row0, nullptr, nullptr, s);
+  if (rc != BR_OK) return rc;
+  InXform tb = t;
+  if (in_scale) { tb.scale = in_scale + Ka; tb.shift = in_shift + Ka; }
+  tb.c8off = (uint32_t)(Ka >> 3);
+  return dense_forward_one(x + Ka, ldx, W + (int64_t)Ka * N, bias, y, ldy, batch, K - Ka, N, act, tb, row0, stats, y, s);
 }
 
 extern "C" int brBnFinalize(const double* stats, double batch_total, const float* gamma, const float* beta, float eps,
@@ -968,7 +987,7 @@ static inline unsigned dw_grid(int64_t batch, int ktp) {
 
 extern "C" int brDenseBackwardSlabs(int64_t batch, int K, int N) {
   (void)N;
-  const int KTP = pow2_ge(tiles16(K < 1 ? 1 : K));
+  const int KTP = K > kMaxT * 16 ? 8 : pow2_ge(tiles16(K < 1 ? 1 : K));   // K > 128: two K-halves, both as 8 k-tile strips
   return (int)dw_grid(batch, KTP) * (8 / KTP);
 }
 
@@ -990,47 +1009,28 @@ static void launch_dx(unsigned grid, size_t shmem, hipStream_t s, const float* g
 }
 
 template <int NT, int KTP>
-static void launch_dw(unsigned grid, size_t shmem, hipStream_t s, const float* dzbuf, const float* x, int64_t ldx, int64_t batch, int K, int N,
+static void launch_dw(unsigned grid, size_t shmem, hipStream_t s, int64_t slab_elems, int64_t db_off, const float* dzbuf, const float* x, int64_t ldx, int64_t batch, int K, int N,
                       InXform tin, int64_t row0, float* slabs) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dense_dw_kernel<NT, KTP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     attr_set = true;
   }
-  dense_dw_kernel<NT, KTP><<<grid, kThreads, shmem, s>>>(dzbuf, x, ldx, batch, K, N, tin, row0, slabs);
+  dense_dw_kernel<NT, KTP><<<grid, kThreads, shmem, s>>>(dzbuf, x, ldx, batch, K, N, tin, row0, slabs, slab_elems, db_off);
 }
 
-extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
-                               const float* W, int64_t batch, int K, int N, int act, const float* out_mean,
-                               const float* out_rstd, const float* out_gamma, const double* bn_sums, double batch_total,
-                               const float* in_scale, const float* in_shift, const float* in_mean, const float* in_rstd,
-                               float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0, float* gx,
-                               int64_t ldgx, float* dz_ws, float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream) {
-  BR_CHECK_ARG(gy && y && x && W && dW_slabs && dz_ws && batch >= 0 && K >= 1 && N >= 1, "brDenseBackward: bad args");
-  BR_CHECK_ARG(K <= kMaxT * 16 && N <= kMaxT * 16, "brDenseBackward: K=%d N=%d exceed %d", K, N, kMaxT * 16);
-  BR_CHECK_ARG(ldgy >= N && ldy >= N && ldx >= K && (!gx || ldgx >= K), "brDenseBackward: bad leading dims");
-  BR_CHECK_ARG((out_mean == nullptr) == (out_rstd == nullptr) && (out_mean == nullptr) == (out_gamma == nullptr) &&
-               (out_mean == nullptr) == (bn_sums == nullptr), "brDenseBackward: out BN pointers all or none");
-  BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseBackward: in_scale/in_shift both or neither");
-  BR_CHECK_ARG((in_mean == nullptr) == (in_rstd == nullptr) && (in_mean == nullptr) == (in_bn_sums == nullptr),
-               "brDenseBackward: in BN pointers all or none");
-  BR_CHECK_ARG(!in_mean || gx, "brDenseBackward: in BN sums need gx");
-  BR_CHECK_ARG((reinterpret_cast<uintptr_t>(dz_ws) & 15) == 0, "brDenseBackward: dz_ws must be 16-byte aligned");
-  if (batch == 0) return BR_OK;
-  const int KT = tiles16(K), NT = tiles16(N);
+// one K-range of a layer's backward: dx for columns [k0, k0+Kc) of gx, dW rows [k0, k0+Kc)
+static int dense_backward_part(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* W,
+                               int64_t batch, int Kc, int N, int act, const OutXform& to, InXform tin, InBn ibn, int64_t row0, float* gx,
+                               int64_t ldgx, float* dz_ws, float* slabs, int64_t slab_elems, int64_t db_off, int KTP, double* in_bn_sums,
+                               bool run_dx, bool run_dw, hipStream_t s) {
+  const int KT = tiles16(Kc), NT = tiles16(N);
   const int Kp = KT * 16, Np = NT * 16;
-  const int KTP = pow2_ge(KT);
-  const int want = brDenseBackwardSlabs(batch, K, N);
-  BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
-  OutXform to{out_mean, out_rstd, out_gamma, bn_sums, (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch))};
-  InXform tin{in_scale, in_shift, make_dropout(in_drop_p, seed, step, in_site)};
-  if (const StepStateDev* ss = current_step_state()) tin.drop.step_ptr = &ss->step;
-  InBn ibn{in_mean, in_rstd};
-  hipStream_t s = (hipStream_t)stream;
-  {
+  const float* W_ = W;
+  if (run_dx) {
     const unsigned grid = grid_for(batch, 16 * 8);
     const size_t shmem = ((size_t)Kp * (Np + 4) + 4 * (size_t)Np + 2 * (size_t)Kp) * sizeof(float) + (size_t)8 * 16 * 2 * KT + 16;
-#define BR_DX_K(NTv, KTv) case KTv: launch_dx<NTv, KTv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, in_bn_sums); break;
+#define BR_DX_K(NTv, KTv) case KTv: launch_dx<NTv, KTv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W_, batch, Kc, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, in_bn_sums); break;
 #define BR_DX(NTv) \
   case NTv:        \
     switch (KT) { BR_DX_K(NTv, 1) BR_DX_K(NTv, 2) BR_DX_K(NTv, 3) BR_DX_K(NTv, 4) BR_DX_K(NTv, 5) BR_DX_K(NTv, 6) BR_DX_K(NTv, 7) BR_DX_K(NTv, 8) default: break; } \
@@ -1041,11 +1041,11 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
     }
     BR_CHECK_LAUNCH("brDenseBackward(dx)");
   }
-  {
+  if (run_dw) {
     const unsigned grid = dw_grid(batch, KTP);
     const int tm = dw_tm(KTP);
     const size_t shmem = ((size_t)tm * (Kp + 4) + (size_t)tm * (Np + 4) + 2 * (size_t)Kp) * sizeof(float);
-#define BR_DW_K(NTv, KTPv) case KTPv: launch_dw<NTv, KTPv>(grid, shmem, s, dz_ws, x, ldx, batch, K, N, tin, row0, dW_slabs); break;
+#define BR_DW_K(NTv, KTPv) case KTPv: launch_dw<NTv, KTPv>(grid, shmem, s, slab_elems, db_off, dz_ws, x, ldx, batch, Kc, N, tin, row0, slabs); break;
 #define BR_DW(NTv) \
   case NTv:        \
     switch (KTP) { BR_DW_K(NTv, 1) BR_DW_K(NTv, 2) BR_DW_K(NTv, 4) BR_DW_K(NTv, 8) default: break; } \
@@ -1057,6 +1057,57 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
     BR_CHECK_LAUNCH("brDenseBackward(dW)");
   }
   return BR_OK;
+}
+
+extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                               const float* W, int64_t batch, int K, int N, int act, const float* out_mean,
+                               const float* out_rstd, const float* out_gamma, const double* bn_sums, double batch_total,
+                               const float* in_scale, const float* in_shift, const float* in_mean, const float* in_rstd,
+                               float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0, float* gx,
+                               int64_t ldgx, float* dz_ws, float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream) {
+  BR_CHECK_ARG(gy && y && x && W && dW_slabs && dz_ws && batch >= 0 && K >= 1 && N >= 1, "brDenseBackward: bad args");
+  BR_CHECK_ARG(K <= 2 * kMaxT * 16 && N <= kMaxT * 16, "brDenseBackward: K=%d N=%d exceed %d / %d", K, N, 2 * kMaxT * 16, kMaxT * 16);
+  BR_CHECK_ARG(ldgy >= N && ldy >= N && ldx >= K && (!gx || ldgx >= K), "brDenseBackward: bad leading dims");
+  BR_CHECK_ARG((out_mean == nullptr) == (out_rstd == nullptr) && (out_mean == nullptr) == (out_gamma == nullptr) &&
+               (out_mean == nullptr) == (bn_sums == nullptr), "brDenseBackward: out BN pointers all or none");
+  BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseBackward: in_scale/in_shift both or neither");
+  BR_CHECK_ARG((in_mean == nullptr) == (in_rstd == nullptr) && (in_mean == nullptr) == (in_bn_sums == nullptr),
+               "brDenseBackward: in BN pointers all or none");
+  BR_CHECK_ARG(!in_mean || gx, "brDenseBackward: in BN sums need gx");
+  BR_CHECK_ARG(K <= kMaxT * 16 || !in_mean, "brDenseBackward: K > %d is supported for inputs without a BatchNorm (first layer of a tower)", kMaxT * 16);
+  BR_CHECK_ARG((reinterpret_cast<uintptr_t>(dz_ws) & 15) == 0, "brDenseBackward: dz_ws must be 16-byte aligned");
+  if (batch == 0) return BR_OK;
+  const int want = brDenseBackwardSlabs(batch, K, N);
+  BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
+  OutXform to{out_mean, out_rstd, out_gamma, bn_sums, (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch))};
+  InXform tin{in_scale, in_shift, make_dropout(in_drop_p, seed, step, in_site), 0u};
+  if (const StepStateDev* ss = current_step_state()) tin.drop.step_ptr = &ss->step;
+  InBn ibn{in_mean, in_rstd};
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t slab_elems = (int64_t)K * N + N;
+  if (K <= kMaxT * 16)
+    return dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, dW_slabs, slab_elems,
+                               (int64_t)K * N, pow2_ge(tiles16(K)), in_bn_sums, true, true, s);
+  // two K-halves (see brDenseForward): dx A, dx B (dz is formed - identically - by both), then dW A, dW B
+  const int Ka = split_k(K), Kb = K - Ka;
+  InXform tb = tin;
+  if (in_scale) { tb.scale = in_scale + Ka; tb.shift = in_shift + Ka; }
+  tb.c8off = (uint32_t)(Ka >> 3);
+  int rc = BR_OK;
+  if (gx) {
+    rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, nullptr, 0, 0, 8, nullptr, true, false, s);
+    if (rc != BR_OK) return rc;
+    rc = dense_backward_part(gy, ldgy, y, ldy, x + Ka, ldx, W + (int64_t)Ka * N, batch, Kb, N, act, to, tb, ibn, row0, gx + Ka, ldgx, dz_ws, nullptr, 0, 0,
+                             8, nullptr, true, false, s);
+  } else {   // no input gradient wanted: one dx launch still forms dz for the dW kernels
+    rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, row0, nullptr, ldgx, dz_ws, nullptr, 0, 0, 8, nullptr, true, false, s);
+  }
+  if (rc != BR_OK) return rc;
+  rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, row0, nullptr, ldgx, dz_ws, dW_slabs, slab_elems, (int64_t)K * N, 8,
+                           nullptr, false, true, s);
+  if (rc != BR_OK) return rc;
+  return dense_backward_part(gy, ldgy, y, ldy, x + Ka, ldx, W, batch, Kb, N, act, to, tb, ibn, row0, nullptr, ldgx, dz_ws, dW_slabs + (int64_t)Ka * N, slab_elems,
+                             -1, 8, nullptr, false, true, s);
 }
 
 extern "C" int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* out, brStream stream) {

@@ -97,8 +97,8 @@ class NeuMFEngine:
         self.num_user_rows, self.num_item_rows = int(num_user_rows), int(num_item_rows)
         self.dist = dist                      # None or a parallel.DataParallelCtx
         D, (n1, n2, n3) = cfg.dim, cfg.hidden
-        if 2 * D > 128 or max(n1, n2) > 128 or n3 > 32:
-            raise ValueError("tower widths: 2*dim, n1, n2 <= 128 and n3 <= 32 in this build")
+        if 2 * D > 256 or max(n1, n2) > 128 or n3 > 32:
+            raise ValueError("tower widths: 2*dim <= 256 (first layer, split-K above 128), n1, n2 <= 128 and n3 <= 32 in this build")
         dev = self.device
         g = torch.Generator(device="cpu").manual_seed(init_seed)
         # [TF-sem] Embedding init U(-0.05, 0.05); Dense glorot-uniform; bias 0; BN gamma 1 beta 0

@@ -51,7 +51,8 @@ def _masks(cfg, spec, step, B, row0=0):
     return [O.dropout_mask(cfg.seed, step, s, B, w, cfg.dropout, row0) for s, w in enumerate(widths)]
 
 
-@pytest.mark.parametrize("variant,dim,B", [("A", 64, 300), ("B", 64, 257), ("A", 10, 64), ("B", 32, 7), ("A", 8, 1000), ("A", 10, 2048)])
+@pytest.mark.parametrize("variant,dim,B", [("A", 64, 300), ("B", 64, 257), ("A", 10, 64), ("B", 32, 7), ("A", 8, 1000), ("A", 10, 2048),
+                                           ("A", 128, 300), ("B", 100, 129)])      # 2*dim > 128: the first layer runs as two K-halves (config 5)
 def test_forward_backward_parity(dev, variant, dim, B):
     ops, eng, spec, cfg, p, u, i, y = _setup(variant, dim, B, dev)
     td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
@@ -87,7 +88,8 @@ def test_forward_backward_parity(dev, variant, dim, B):
 
 
 @pytest.mark.parametrize("variant,dim,optimizer,impl", [("A", 64, "adam_dense", "deferred"), ("A", 64, "adam_dense", "sweep"), ("A", 64, "adam_lazy", "sweep"),
-                                                        ("B", 32, "adam_dense", "deferred"), ("A", 10, "adam_dense", "deferred"), ("A", 10, "adam_dense", "sweep")])
+                                                        ("B", 32, "adam_dense", "deferred"), ("A", 10, "adam_dense", "deferred"), ("A", 10, "adam_dense", "sweep"),
+                                                        ("A", 128, "adam_dense", "deferred")])
 def test_three_optimizer_steps(dev, variant, dim, optimizer, impl):
     """Parameters after 3 steps of Keras-Adam (dense = non-lazy sparse apply [TF-sem]).
     Adam divides by sqrt(v): a gradient that is itself a nearly cancelled fp32 sum (pre-BN biases,
@@ -136,7 +138,8 @@ def test_predict_inference_mode(dev, variant, dim):
     _close(out, c["prob"], "predict")
 
 
-@pytest.mark.parametrize("K,N,act", [(20, 100, "sigmoid"), (75, 50, "linear"), (128, 128, "relu"), (100, 50, "sigmoid"), (50, 10, "relu"), (3, 1, "linear")])
+@pytest.mark.parametrize("K,N,act", [(20, 100, "sigmoid"), (75, 50, "linear"), (128, 128, "relu"), (100, 50, "sigmoid"), (50, 10, "relu"), (3, 1, "linear"),
+                                     (256, 100, "sigmoid"), (200, 64, "relu"), (130, 17, "linear")])
 def test_dense_layer_shapes(dev, K, N, act):
     """brDenseForward / brDenseBackward alone on ragged K, N, B (padding paths), with input
     BN-affine + dropout and the BN-backward column sums."""
@@ -163,9 +166,10 @@ def test_dense_layer_shapes(dev, K, N, act):
     ns = ops.dense_backward_slabs(B, K, N)
     slabs = torch.empty(ns * (K * N + N), device=dev); gx = torch.empty(B, K, device=dev)
     insum = torch.zeros(8, 2 * K, dtype=torch.float64, device=dev)
+    wide = K > 128      # split-K layers (first layer of a tower): no BatchNorm on the input side
     ops.dense_backward(td(gy), y, td(x), td(W), act, slabs, ns, gx=gx, in_scale=td(sc), in_shift=td(sh),
-                       in_bn=(td(mean_in), td(rstd_in)), in_drop_p=p, in_site=site, seed=seed, step=step, row0=row0,
-                       in_bn_sums=insum)
+                       in_bn=None if wide else (td(mean_in), td(rstd_in)), in_drop_p=p, in_site=site, seed=seed, step=step, row0=row0,
+                       in_bn_sums=None if wide else insum)
     out = torch.empty(K * N + N, device=dev)
     ops.reduce_slabs(slabs, ns, K * N + N, out)
     dz = gy.astype(np.float64) * O.act_bwd_from_out(yr, act)
@@ -173,6 +177,8 @@ def test_dense_layer_shapes(dev, K, N, act):
     _close(out.cpu().numpy()[K * N:], dz.sum(0), "db", rtol=1e-4, atol_frac=1e-5)
     gxr = (dz @ W.astype(np.float64).T) * mask / (1 - p)
     _close(gx.cpu().numpy(), gxr, "gx", rtol=1e-4, atol_frac=1e-5)
+    if wide:
+        return
     xhat = (x.astype(np.float64) - mean_in) * rstd_in
     ins = insum.sum(0).cpu().numpy()
     _close(ins[:K], gxr.sum(0), "sum dh", rtol=1e-4, atol_frac=1e-5)
