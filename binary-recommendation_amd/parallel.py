@@ -295,3 +295,81 @@ def make_sharded_two_tower(base_cls):
             self._opt_rows(self.item_emb, self.item_acc, getattr(self, "item_v", None), self.item_index, oi)
 
     return ShardedTwoTowerEngine
+
+
+def make_sharded_bpr(base_cls):
+    """ShardedBPREngine = src/models/BPRModel.py on W GPUs: the user and the (shared) item table are row-sharded
+    (owner = id mod W).  Per step the three id streams travel as two exchanges - users (B ids) and [pos | neg] (2B ids):
+    ids -> owners, owner-side gather, rows back; the fused triplet kernel then runs on the received rows (positions as
+    ids), and the per-triplet row gradients go back to the owners, which dedup (one sort per table over the
+    contributions of all ranks) and apply Adam.  The loss is the mean over the GLOBAL batch (batch_total)."""
+    from . import ops
+
+    class ShardedBPREngine(base_cls):
+        def __init__(self, num_users, num_items, num_factor, device, max_batch, ctx: DistCtx, full_tables=None, **kw):
+            self.ctx = ctx
+            super().__init__(num_users, num_items, num_factor, device, max_batch, **kw)
+            r, W = ctx.rank, ctx.world
+            full = full_tables or {"user": self.user, "item": self.item}          # same seed on every rank
+            for name in ("user", "item"):
+                shard = full[name].to(self.device)[r::W].contiguous()
+                if shard.shape[0] == 0:
+                    shard = torch.zeros(1, self.dim, device=self.device)
+                setattr(self, name, shard)
+                setattr(self, name + "_m", torch.zeros_like(shard))
+                setattr(self, name + "_v", torch.zeros_like(shard))
+                if self.optimizer == "adam_dense":
+                    setattr(self, name + "_mark", torch.zeros(shard.shape[0], dtype=torch.uint8, device=self.device))
+            self.xu, self.xi = ShardExchange(ctx), ShardExchange(ctx)
+            B = self.max_batch
+            self._idx_cap = int(5 * B) + 64
+            self.user_index, self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device), ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
+            self.pos_b = torch.arange(B, device=self.device).to(self.id_dtype)
+
+        def train_step(self, users, pos, neg, batch_total: int | None = None):
+            B = users.shape[0]
+            if B > self.max_batch:
+                raise ValueError("batch exceeds max_batch")
+            ctx, D = self.ctx, self.dim
+            self.t += 1
+            bt = B * ctx.world if batch_total is None else batch_total
+            ids2 = self.item_ids[:2 * B]
+            ids2[:B].copy_(pos)
+            ids2[B:].copy_(neg)
+            xu, xi = self.xu.plan(users), self.xi.plan(ids2)
+            xu.exchange_counts(xi)                                   # the step's one host sync
+            ru, ri = xu.send_ids(), xi.send_ids()
+            empty = torch.empty(0, D, device=self.device)
+            gu = ops.gather_rows([self.user], [ru], err_flag=self.err)[0] if ru.numel() else empty
+            gi = ops.gather_rows([self.item], [ri], err_flag=self.err)[0] if ri.numel() else empty
+            bu, bi = xu.return_rows(gu), xi.return_rows(gi)          # bucket order
+            if B == 0:
+                eu, ei = empty, empty
+            else:
+                eu = ops.gather_rows([bu], [xu.inv.to(self.id_dtype)])[0]            # batch order (B x D)
+                ei = ops.gather_rows([bi], [xi.inv.to(self.id_dtype)])[0]            # [pos rows | neg rows] (2B x D)
+                ar = self.pos_b[:B]
+                ops.bpr_forward_backward(eu, ei, ar, ar, ar + B, 1.0 / bt, self.loss_slots, self.g_user[:B], self.g_item[:2 * B],
+                                         self.per_triplet[:B], self.err)
+            # row gradients: batch order -> bucket order -> owners
+            gub = ops.gather_rows([self.g_user[:B]], [xu.order.to(self.id_dtype)])[0] if B else empty
+            gib = ops.gather_rows([self.g_item[:2 * B]], [xi.order.to(self.id_dtype)])[0] if B else empty
+            ou, oi = xu.send_row_grads(gub), xi.send_row_grads(gib)
+            if max(xu.n_recv, xi.n_recv) > self._idx_cap:
+                self._idx_cap = int(1.25 * max(xu.n_recv, xi.n_recv)) + 64
+                self.user_index, self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device), ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
+            a = ops.adam_alpha(self.lr, self.t)
+            dense = self.optimizer == "adam_dense"
+            for tab, m, v, idx, ex, og, mark in ((self.user, self.user_m, self.user_v, self.user_index, xu, ou, getattr(self, "user_mark", None)),
+                                                 (self.item, self.item_m, self.item_v, self.item_index, xi, oi, getattr(self, "item_mark", None))):
+                if ex.n_recv:
+                    idx.build(ex.recv_local, tab.shape[0])
+                    ops.adam_rows_sorted(tab, m, v, idx, og, D, a, mark=mark if dense else None)
+                if dense:
+                    ops.adam_dense_sweep(tab, m, v, a, mark=mark)
+            self.n_seen += B
+
+        def predict_scores(self, user_ids, item_ids=None):
+            raise NotImplementedError("row-sharded scoring: gather the shards (state) or score per shard")
+
+    return ShardedBPREngine

@@ -168,3 +168,71 @@ def test_sharded_two_tower_global_negatives(dev):
         p.join(timeout=60)
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
+
+
+def _bpr_worker(rank, world, port, optimizer, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from importlib import import_module
+    from oracle import binrec_oracle as O
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        par = import_module("binary-recommendation_amd.parallel")
+        bpr = import_module("binary-recommendation_amd.bpr")
+        dev = torch.device("cuda:0")
+        ctx = par.DistCtx()
+        U, I, F, Bl = 211, 89, 32, 100
+        B = Bl * world
+        rng = np.random.default_rng(21)
+        ut = rng.uniform(-.05, .05, (U, F)).astype(np.float32); it = rng.uniform(-.05, .05, (I, F)).astype(np.float32)
+        Eng = par.make_sharded_bpr(bpr.BPREngine)
+        eng = Eng(U, I, F, dev, Bl, ctx, full_tables={"user": torch.from_numpy(ut), "item": torch.from_numpy(it)}, optimizer=optimizer)
+        ut, it = ut.astype(np.float64), it.astype(np.float64)
+        mu, vu, mi, vi = (np.zeros_like(x) for x in (ut, ut, it, it))
+        td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).int()
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        losses = []
+        for t in range(1, 4):
+            u, p, n = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+            p[:40] = 7; n[:10] = 7; n[B - 5:] = 7                # one item hit from both ranks, as positive and negative
+            eng.train_step(td(u[sl]), td(p[sl]), td(n[sl]))
+            loss, _, (gu, gp, gn) = O.bpr_step_grads(ut, it, u, p, n)           # ONE global batch
+            losses.append(loss)
+            lazy = optimizer == "adam_lazy"
+            ut, mu, vu = O.adam_sparse_tf(ut, mu, vu, u, gu, 1e-3, t, lazy=lazy)
+            it, mi, vi = O.adam_sparse_tf(it, mi, vi, np.concatenate([p, n]), np.concatenate([gp, gn]), 1e-3, t, lazy=lazy)
+        torch.cuda.synchronize(); eng.check_ids()
+        tot = torch.tensor([eng.loss_slots.sum().item()], dtype=torch.float64)
+        dist.all_reduce(tot)
+        assert abs(tot.item() / (3 * B) - np.mean(losses)) <= 1e-5 * np.mean(losses), (tot.item() / (3 * B), np.mean(losses))     # slots hold sum l
+        for got, ref in ((eng.user, ut), (eng.item, it)):
+            r = ref[rank::world]
+            g = got.cpu().numpy()[: r.shape[0]]
+            np.testing.assert_allclose(g, r, rtol=1e-5, atol=5e-3 * 3e-3)
+            assert np.median(np.abs(g - r)) <= 1e-7
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()[-1800:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+@pytest.mark.parametrize("optimizer", ["adam_dense", "adam_lazy"])
+def test_sharded_bpr_two_ranks(dev, optimizer):
+    """BPR (config 3) with both tables row-sharded over 2 ranks == the oracle's single global step."""
+    world, port = 2, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_bpr_worker, args=(r, world, port, optimizer, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
