@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--optimizer", default="adam_dense", choices=["adam_dense", "adam_lazy"])
     ap.add_argument("--dense-impl", default=None, choices=["deferred", "sweep"],
                     help="adam_dense: per-row deferred replay (default) or one table sweep per step")
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1: BatchNorm statistics over the global batch (4 extra all-reduces per step)")
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05) ids instead of uniform")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,7 +208,9 @@ def main():
     impl = args.dense_impl or "deferred"
 
     def build(optimizer, dense_impl=impl):
-        cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl)
+        # N > 1: per-replica BatchNorm = what the reference's MirroredStrategy does with a plain BatchNormalization
+        # [TF-sem] (and no BatchNorm collective in the step); --sync-bn makes the statistics global
+        cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl, sync_bn=args.sync_bn)
         if world == 1:
             return neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=1)
         return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1)
@@ -404,7 +407,7 @@ def main():
                                    f"{2 * D}->{'->'.join(map(str, eng_hidden(args, neumf)))}->1, BCE, Keras-Adam {args.optimizer}), "
                                    f"embed_dim={D}, {args.users} users x {args.items} items per GPU, batch {B} per GPU, "
                                    f"{'Zipf(1.05)' if args.zipf else 'uniform'} ids",
-                       "global_batch": batch_total, "parallelism": "single GPU" if world == 1 else f"row-sharded tables x{world} + dp{world}",
+                       "global_batch": batch_total, "parallelism": "single GPU" if world == 1 else f"row-sharded tables x{world} + dp{world}, {'global' if args.sync_bn else 'per-replica'} BatchNorm",
                        "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
             "roofline": roofline, "cpu_baseline": cpu, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
             "launch_mode": (f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)" if use_graph

@@ -100,6 +100,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const float p = train ? s->dropout : 0.f;
   const double bt = (double)(s->batch_total > 0 ? s->batch_total : B);
   const float inv_b = (float)(1.0 / bt);
+  const double bt_bn = s->bn_local ? (double)B : bt;       // rows behind the BatchNorm sums
   // dense parameter layout
   float* th = s->theta;
   float* gr = s->grad;
@@ -162,7 +163,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   }
   if (ph & BR_PH_FWD2) {
     if (train)
-      RUN(BR_TAG_SMALL, brBnFinalize(stats1, bt, th + og1, th + obe1, s->bn_eps, s->bn_momentum, mm1, mv1, scale1, shift1, mean1, rstd1, n1, stream));
+      RUN(BR_TAG_SMALL, brBnFinalize(stats1, bt_bn, th + og1, th + obe1, s->bn_eps, s->bn_momentum, mm1, mv1, scale1, shift1, mean1, rstd1, n1, stream));
     else
       RUN(BR_TAG_SMALL, brBnInference(th + og1, th + obe1, mm1, mv1, s->bn_eps, scale1, shift1, n1, stream));
     RUN(BR_TAG_FWD_L2, brDenseForward(s->a1, n1, th + oW2, th + ob2, s->a2, n2, B, n1, n2, s->act, scale1, shift1, p, s->seed, (uint32_t)s->step, 1,
@@ -170,7 +171,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   }
   if (ph & BR_PH_FWD3) {
     if (train)
-      RUN(BR_TAG_SMALL, brBnFinalize(stats2, bt, th + og2, th + obe2, s->bn_eps, s->bn_momentum, mm2, mv2, scale2, shift2, mean2, rstd2, n2, stream));
+      RUN(BR_TAG_SMALL, brBnFinalize(stats2, bt_bn, th + og2, th + obe2, s->bn_eps, s->bn_momentum, mm2, mv2, scale2, shift2, mean2, rstd2, n2, stream));
     else
       RUN(BR_TAG_SMALL, brBnInference(th + og2, th + obe2, mm2, mv2, s->bn_eps, scale2, shift2, n2, stream));
     if (!train)
@@ -191,13 +192,13 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   if (!train) return BR_OK;
   if (ph & BR_PH_BWD2) {
     const int ns2 = brDenseBackwardSlabs(B, n1, n2);
-    RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, n2, s->a2, n2, s->a1, n1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt, scale1, shift1,
+    RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, n2, s->a2, n2, s->a1, n1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt_bn, scale1, shift1,
                         mean1, rstd1, p, 1, s->seed, (uint32_t)s->step, s->row0, s->gh1, n1, s->dz_ws, s->slabs, ns2, bsum1, stream));
     RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns2, (int64_t)n1 * n2 + n2, gr + oW2, stream));
   }
   if (ph & BR_PH_BWD1) {
     const int ns1 = brDenseBackwardSlabs(B, 2 * D, n1);
-    RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, n1, s->a1, n1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt, nullptr,
+    RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, n1, s->a1, n1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt_bn, nullptr,
                         nullptr, nullptr, nullptr, p, 0, s->seed, (uint32_t)s->step, s->row0, s->dx0, 2 * D, s->dz_ws, s->slabs, ns1, nullptr, stream));
     RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns1, (int64_t)2 * D * n1 + n1, gr + oW1, stream));
   }

@@ -241,6 +241,7 @@ class NeuMFEngine:
         st.adam_dense = (2 if self.deferred else 1 if cfg.optimizer == "adam_dense" else 0) if not self.sharded else 0
         st.dropout, st.bn_eps, st.bn_momentum = cfg.dropout, cfg.bn_eps, cfg.bn_momentum
         st.seed = cfg.seed
+        st.bn_local = 1 if (self.dist is not None and not cfg.sync_bn) else 0
         st.beta1, st.beta2, st.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
         P = lambda t: t.data_ptr()
         st.user_tab, st.user_m, st.user_v = P(self.fused["user"]), P(self.fused_m["user"]), P(self.fused_v["user"])
@@ -346,25 +347,24 @@ class NeuMFEngine:
                 _lib.check(_lib.load().brStepStateAdvance(self.step_state.data_ptr(), cfg.lr, cfg.beta1, cfg.beta2, self.dstat.data_ptr(),
                                                           self.dstat.numel(), ops._stream()), "brStepStateAdvance")
             self._embed_forward(users, items, B)
-        self._run(PH["FWD1"] | emb)
-        if sync:
-            d.all_reduce_sum(self.stats1)
-        self._run(PH["FWD2"])
-        if sync:
-            d.all_reduce_sum(self.stats2)
-        self._run(PH["FWD3"])
-        if sync:
-            d.all_reduce_sum(self.bsum2)
-        self._run(PH["BWD2"])
-        if sync:
-            d.all_reduce_sum(self.bsum1)
-        self._run(PH["BWD1"])
-        # dgamma/dbeta are the BN-backward column sums.  With sync_bn those sums are already global,
-        # so they are written AFTER the dense all-reduce; per-replica BN sums are local like the rest.
         if not sync:
-            self._run(PH["BNG"])
-        d.all_reduce_sum(self.grad.buf)
-        if sync:
+            # per-replica BatchNorm (what MirroredStrategy does with a plain BatchNormalization [TF-sem]): no collective
+            # until the dense gradients, so the whole tower is one driver call
+            self._run(PH["FWD1"] | PH["FWD2"] | PH["FWD3"] | PH["BWD2"] | PH["BWD1"] | PH["BNG"] | emb)
+            d.all_reduce_sum(self.grad.buf)
+        else:
+            self._run(PH["FWD1"] | emb)
+            d.all_reduce_sum(self.stats1)
+            self._run(PH["FWD2"])
+            d.all_reduce_sum(self.stats2)
+            self._run(PH["FWD3"])
+            d.all_reduce_sum(self.bsum2)
+            self._run(PH["BWD2"])
+            d.all_reduce_sum(self.bsum1)
+            self._run(PH["BWD1"])
+            # dgamma/dbeta are the BN-backward column sums: global once the sums are, so they are written AFTER
+            # the sums' all-reduce and BEFORE nothing else needs them
+            d.all_reduce_sum(self.grad.buf)
             self._run(PH["BNG"])
         if self.sharded:
             self._embed_backward_apply(users, items, B)

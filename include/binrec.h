@@ -295,6 +295,10 @@ enum {
 typedef struct brNeumfStep {
   int64_t batch, batch_total, row0, user_rows, item_rows;
   int32_t dim, n1, n2, n3, act, loss, item_first, mf_first, id_type, adam_dense, training, step;
+  int32_t bn_local;   /* 1: BatchNorm statistics over THIS process' batch (per-replica BN, what MirroredStrategy does with a
+                         plain BatchNormalization [TF-sem]) while the loss is still scaled by 1/batch_total; 0: the column
+                         sums are all-reduced by the host and cover batch_total rows */
+  int32_t pad0_;
   float dropout, bn_eps, bn_momentum, pad0;
   uint64_t seed;
   double alpha_t, beta1, beta2, adam_eps;
