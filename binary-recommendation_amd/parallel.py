@@ -92,7 +92,8 @@ class ShardExchange:
         W = self.ctx.world
         dest = (ids % W).to(torch.int64)
         _, order = torch.sort(dest, stable=True)
-        counts = torch.bincount(dest, minlength=W)
+        # rows per destination; NOT torch.bincount: it sizes its output from a device max => a hidden host sync per call
+        counts = (dest.unsqueeze(1) == torch.arange(W, device=dest.device).unsqueeze(0)).sum(0)
         self.order = order
         self.inv = torch.empty_like(order)
         self.inv[order] = torch.arange(order.numel(), device=order.device, dtype=order.dtype)

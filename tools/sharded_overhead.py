@@ -1,0 +1,27 @@
+"""Per-GPU cost of the row-sharded step WITHOUT communication: the sharded engine on a 1-rank group (all-to-alls are
+local copies), next to the fused single-GPU engine.  Shows the host/launch overhead of the exchange bookkeeping."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+import torch, torch.distributed as dist
+from importlib import import_module
+neumf = import_module("binary-recommendation_amd.neumf"); par = import_module("binary-recommendation_amd.parallel")
+dist.init_process_group("gloo", rank=0, world_size=1)
+dev = torch.device("cuda:0"); B, U, I = 65536, 1_000_000, 100_000
+ctx = par.DistCtx()
+cfg = neumf.NeuMFConfig(variant="A", dim=64, seed=1, sync_bn=False)
+eng = par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1)
+g = torch.Generator(device=dev).manual_seed(3)
+batches = [(torch.randint(0, U, (B,), device=dev, dtype=torch.int32, generator=g), torch.randint(0, I, (B,), device=dev, dtype=torch.int32, generator=g),
+            (torch.rand(B, device=dev, generator=g) < 0.25).float()) for _ in range(16)]
+def run(n):
+    for s in range(n):
+        u, i, y = batches[s % 16]; eng.train_step(u, i, y)
+run(5); torch.cuda.synchronize()
+t0 = time.perf_counter(); run(30); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
+t0 = time.perf_counter(); run(30); host = (time.perf_counter() - t0) / 30; torch.cuda.synchronize()
+print(json.dumps({"sharded_engine_world1_ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": host * 1e3}))
+if os.environ.get("BR_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); run(20); pr.disable(); torch.cuda.synchronize()
+    st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(45)
