@@ -300,8 +300,11 @@ def main():
         hbm("neumf_embed_bwd", "EMBED_BWD", B * (4 * D * 4 + 8))
     hbm(f"adam_dense_sweep[user {loc_users}x{2 * D}]", "SWEEP_USER", 6 * 4 * loc_users * 2 * D)
     hbm(f"adam_dense_sweep[item {loc_items}x{2 * D}]", "SWEEP_ITEM", 6 * 4 * loc_items * 2 * D)
-    hbm("adam_rows_sorted[user]", "ADAM_ROWS_USER", B * 7 * 2 * D * 4)
-    hbm("adam_rows_sorted[item]", "ADAM_ROWS_ITEM", B * 7 * 2 * D * 4)
+    if world == 1:   # the step driver updates both fused tables in one launch
+        hbm("adam_rows_sorted[user + item, one launch]", "ADAM_ROWS_USER", 2 * B * 7 * 2 * D * 4)
+    else:
+        hbm("adam_rows_sorted[user]", "ADAM_ROWS_USER", B * 7 * 2 * D * 4)
+        hbm("adam_rows_sorted[item]", "ADAM_ROWS_ITEM", B * 7 * 2 * D * 4)
     mfma(f"dense_fwd[{2 * D}x{n1}]", "FWD_L1", 2.0 * B * 2 * D * n1)
     mfma(f"dense_fwd[{n1}x{n2}]", "FWD_L2", 2.0 * B * n1 * n2)
     mfma(f"dense_fwd[{n2}x{n3}]", "FWD_L3", 2.0 * B * n2 * n3)

@@ -67,15 +67,30 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const IdT* __restrict_
 
 // Row gradients may come from two buffers: columns [0,split) from g0, [split,dim) from g1 (the fused
 // NeuMF tables [mlp | mf] take their MLP half from dx0 and their MF half from the embed backward).
+// One launch may serve two tables of the same geometry (the user and the item table of a NeuMF step, blockIdx.y):
+// each alone leaves HBM half idle (random 512-B rows, a dependent chain per row), together they overlap.
+struct AdamRowsJob {
+  float* table; float* M; float* Vv;
+  int64_t table_rows;
+  const void* sid; const int32_t* spos;
+  const float* g0; int64_t ldg0;
+  const float* g1; int64_t ldg1;
+  uint8_t* mark; int32_t* last;
+};
+struct AdamRowsJobs { AdamRowsJob j[2]; };
+
 template <typename IdT, int VEC>
-__global__ __launch_bounds__(256) void adam_rows_sorted_kernel(float* __restrict__ table, float* __restrict__ M,
-                                                                float* __restrict__ Vv, int64_t table_rows, int dim,
-                                                                int chunks, int lpr_log2, const IdT* __restrict__ sid,
-                                                                const int32_t* __restrict__ spos, int64_t n,
-                                                                const float* __restrict__ g0, int64_t ldg0,
-                                                                const float* __restrict__ g1, int64_t ldg1, int split,
-                                                                AdamHp h, uint8_t* __restrict__ mark,
-                                                                int32_t* __restrict__ last, const StepStateDev* __restrict__ ss) {
+__global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs, int dim, int chunks, int lpr_log2, int64_t n, int split,
+                                                                AdamHp h, const StepStateDev* __restrict__ ss) {
+  const AdamRowsJob& jb = jobs.j[blockIdx.y];
+  float* __restrict__ table = jb.table; float* __restrict__ M = jb.M; float* __restrict__ Vv = jb.Vv;
+  const int64_t table_rows = jb.table_rows;
+  const IdT* __restrict__ sid = (const IdT*)jb.sid;
+  const int32_t* __restrict__ spos = jb.spos;
+  const float* __restrict__ g0 = jb.g0; const float* __restrict__ g1 = jb.g1;
+  const int64_t ldg0 = jb.ldg0, ldg1 = jb.ldg1;
+  uint8_t* __restrict__ mark = jb.mark;
+  int32_t* __restrict__ last = jb.last;
   using V = typename VecT<VEC>::type;
   __shared__ float ring[BR_ALPHA_RING];
   if (last) stage_alpha_ring(ring, ss);      // uniform branch: whole workgroup
@@ -485,32 +500,43 @@ extern "C" int brScatterAddRows(float* g_table, int64_t table_rows, const void* 
   return BR_OK;
 }
 
-static int adam_rows_launch(float* table, float* m, float* v, int64_t table_rows, int dim, const void* sorted_ids,
-                            int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
-                            const float* row_grads_hi, int64_t ldg_hi, int split, double alpha_t, double beta1,
-                            double beta2, double eps, uint8_t* mark, int32_t* last, const StepStateDev* ss, brStream stream) {
+struct AdamRowsArgs {      // one table's host-side arguments
+  float *table, *m, *v;
+  int64_t table_rows;
+  const void* sorted_ids; const int32_t* sorted_pos;
+  const float* row_grads; int64_t ldg;
+  const float* row_grads_hi; int64_t ldg_hi;
+  uint8_t* mark; int32_t* last;
+};
+
+static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_type, int64_t n, int split, double alpha_t, double beta1,
+                            double beta2, double eps, const StepStateDev* ss, brStream stream) {
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdamRowsSorted: bad id_type");
   if (n == 0) return BR_OK;
-  BR_CHECK_ARG(table && m && v && sorted_ids && sorted_pos && row_grads && dim >= 1 && table_rows > 0, "brAdamRowsSorted: bad args");
-  if (!row_grads_hi) { split = dim; ldg_hi = ldg; row_grads_hi = row_grads; }
-  BR_CHECK_ARG(split >= 1 && split <= dim && ldg >= split && ldg_hi >= dim - split, "brAdamRowsSorted: bad split / strides");
-  // widest vector (floats) that every row start of both sources and the split honour
-  const uintptr_t al = reinterpret_cast<uintptr_t>(row_grads) | reinterpret_cast<uintptr_t>(row_grads_hi);
-  int64_t ldmin = (ldg % 4 == 0 && ldg_hi % 4 == 0 && split % 4 == 0 && (al & 15) == 0) ? 4
-                  : (ldg % 2 == 0 && ldg_hi % 2 == 0 && split % 2 == 0 && (al & 7) == 0) ? 2 : 1;
+  AdamRowsJobs jobs;
+  int64_t ldmin = 4;
+  for (int q = 0; q < n_jobs; ++q) {
+    AdamRowsArgs t = a[q];
+    BR_CHECK_ARG(t.table && t.m && t.v && t.sorted_ids && t.sorted_pos && t.row_grads && dim >= 1 && t.table_rows > 0, "brAdamRowsSorted: bad args");
+    if (!t.row_grads_hi) { if (n_jobs == 1) split = dim; t.ldg_hi = t.ldg; t.row_grads_hi = t.row_grads; }
+    BR_CHECK_ARG(split >= 1 && split <= dim && t.ldg >= split && t.ldg_hi >= dim - split, "brAdamRowsSorted: bad split / strides");
+    // widest vector (floats) that every row start of both sources and the split honour
+    const uintptr_t al = reinterpret_cast<uintptr_t>(t.row_grads) | reinterpret_cast<uintptr_t>(t.row_grads_hi);
+    const int64_t lm = (t.ldg % 4 == 0 && t.ldg_hi % 4 == 0 && split % 4 == 0 && (al & 15) == 0) ? 4
+                       : (t.ldg % 2 == 0 && t.ldg_hi % 2 == 0 && split % 2 == 0 && (al & 7) == 0) ? 2 : 1;
+    ldmin = lm < ldmin ? lm : ldmin;
+    jobs.j[q] = AdamRowsJob{t.table, t.m, t.v, t.table_rows, t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.mark, t.last};
+  }
+  if (n_jobs == 1) jobs.j[1] = jobs.j[0];
   const RowGeom g = row_geom_ld(dim, ldmin);
-  const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
+  const dim3 grid((unsigned)ceil_div(n, 256 >> g.lpr_log2), (unsigned)n_jobs);
   AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
   if (ss) h.alpha_ptr = &ss->alpha_t;
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32)
-    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
-                               table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int32_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark, last, ss)));
+    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(jobs, dim, g.chunks, g.lpr_log2, n, split, h, ss)));
   else
-    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
-                               table, m, v, table_rows, dim, g.chunks, g.lpr_log2, (const int64_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, row_grads_hi, ldg_hi, split, h, mark, last, ss)));
+    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(jobs, dim, g.chunks, g.lpr_log2, n, split, h, ss)));
   BR_CHECK_LAUNCH("brAdamRowsSorted");
   return BR_OK;
 }
@@ -519,8 +545,8 @@ extern "C" int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_
                                 int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
                                 const float* row_grads_hi, int64_t ldg_hi, int split, double alpha_t, double beta1,
                                 double beta2, double eps, uint8_t* mark, brStream stream) {
-  return adam_rows_launch(table, m, v, table_rows, dim, sorted_ids, id_type, sorted_pos, n, row_grads, ldg, row_grads_hi, ldg_hi,
-                          split, alpha_t, beta1, beta2, eps, mark, nullptr, nullptr, stream);
+  const AdamRowsArgs a{table, m, v, table_rows, sorted_ids, sorted_pos, row_grads, ldg, row_grads_hi, ldg_hi, mark, nullptr};
+  return adam_rows_launch(&a, 1, dim, id_type, n, split, alpha_t, beta1, beta2, eps, nullptr, stream);
 }
 
 extern "C" int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,
@@ -528,8 +554,22 @@ extern "C" int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_
                                         const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
                                         const void* step_state, double beta1, double beta2, double eps, brStream stream) {
   BR_CHECK_ARG(last && step_state, "brAdamRowsSortedDeferred: last / step_state missing");
-  return adam_rows_launch(table, m, v, table_rows, dim, sorted_ids, id_type, sorted_pos, n, row_grads, ldg, row_grads_hi, ldg_hi,
-                          split, 0.0, beta1, beta2, eps, nullptr, last, (const StepStateDev*)step_state, stream);
+  const AdamRowsArgs a{table, m, v, table_rows, sorted_ids, sorted_pos, row_grads, ldg, row_grads_hi, ldg_hi, nullptr, last};
+  return adam_rows_launch(&a, 1, dim, id_type, n, split, 0.0, beta1, beta2, eps, (const StepStateDev*)step_state, stream);
+}
+
+// both fused tables of a NeuMF step in one launch (same dim / n / split; `last` arrays: deferred mode, `marks`: sweep mode)
+extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a, const void* sorted_ids_a, const int32_t* sorted_pos_a,
+                                    const float* grads_a, int64_t ldg_a, const float* grads_hi_a, int64_t ldg_hi_a, uint8_t* mark_a, int32_t* last_a,
+                                    float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
+                                    const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, uint8_t* mark_b, int32_t* last_b,
+                                    int dim, int id_type, int64_t n, int split, const void* step_state, double alpha_t, double beta1,
+                                    double beta2, double eps, brStream stream) {
+  BR_CHECK_ARG((last_a == nullptr) == (last_b == nullptr) && (last_a == nullptr || step_state), "brAdamRowsSortedPair: last arrays for both tables (with step_state) or neither");
+  BR_CHECK_ARG(grads_hi_a && grads_hi_b, "brAdamRowsSortedPair: both gradient halves required");
+  const AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, mark_a, last_a},
+                             {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, mark_b, last_b}};
+  return adam_rows_launch(a, 2, dim, id_type, n, split, alpha_t, beta1, beta2, eps, last_a ? (const StepStateDev*)step_state : nullptr, stream);
 }
 
 extern "C" int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,

@@ -370,6 +370,14 @@ int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, in
                              const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                              const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
                              const void* step_state, double beta1, double beta2, double eps, brStream stream);
+/* The user and the item table of one NeuMF step in ONE launch (same dim, n, split; each alone leaves HBM half idle).
+ * last_* non-NULL (both): deferred mode (step_state required, alpha_t ignored); else brAdamRowsSorted semantics with marks. */
+int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a, const void* sorted_ids_a, const int32_t* sorted_pos_a,
+                         const float* grads_a, int64_t ldg_a, const float* grads_hi_a, int64_t ldg_hi_a, uint8_t* mark_a, int32_t* last_a,
+                         float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
+                         const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, uint8_t* mark_b, int32_t* last_b,
+                         int dim, int id_type, int64_t n, int split, const void* step_state, double alpha_t, double beta1,
+                         double beta2, double eps, brStream stream);
 int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,
                 double beta1, double beta2, double eps, brStream stream);
 int64_t brNeumfStepSizeof(void);
