@@ -312,7 +312,8 @@ def main():
     mfma(f"dense_bwd[{n1}x{n2}]", "BWD_L2", 4.0 * B * n1 * n2)
     mfma(f"dense_bwd[{n2}x{n3}]", "BWD_L3", 4.0 * B * n2 * n3)
     for name, tag in (("row_index_build[user]", "INDEX_USER"), ("row_index_build[item]", "INDEX_ITEM"), ("tail: dense 3 fwd + head + loss + their backward (one launch)", "HEAD"),
-                      ("reduce_slabs (each)", "REDUCE"), ("bn/small (each)", "SMALL"), ("adam_flat", "ADAM_FLAT")):
+                      ("reduce_slabs (each)", "REDUCE"), ("bn/small (each)", "SMALL"),
+                      ("dense finalize: slab reduce x3 + BN grads + Adam (one launch)" if world == 1 else "adam_flat", "ADAM_FLAT")):
         if TAG[tag] in per_tag:
             kernels[name] = {"_tag": TAG[tag], "us": per_tag[TAG[tag]][0], "launches": per_tag[TAG[tag]][1]}
     gpu_us_per_step = 0.0

@@ -77,6 +77,23 @@ bool ensure_events() {
 
 extern "C" int64_t brNeumfStepSizeof(void) { return (int64_t)sizeof(brNeumfStep); }
 
+// slab regions of a step: [tail | layer 2 | layer 1], sized for the batch at hand (slab counts grow with the batch)
+namespace {
+struct SlabPlan { int ns_t, ns2, ns1; int64_t el_t, el2, el1, off_t, off2, off1, total; };
+inline SlabPlan slab_plan(int64_t B, int D, int n1, int n2, int n3) {
+  SlabPlan p;
+  p.ns_t = brNeumfTailSlabs(B); p.el_t = brNeumfTailSlabElems(n2, n3);
+  p.ns2 = brDenseBackwardSlabs(B, n1, n2); p.el2 = (int64_t)n1 * n2 + n2;
+  p.ns1 = brDenseBackwardSlabs(B, 2 * D, n1); p.el1 = (int64_t)2 * D * n1 + n1;
+  p.off_t = 0; p.off2 = p.off_t + p.ns_t * p.el_t; p.off1 = p.off2 + p.ns2 * p.el2;
+  p.total = p.off1 + p.ns1 * p.el1;
+  return p;
+}
+}  // namespace
+extern "C" int64_t brNeumfStepSlabFloats(int64_t batch, int dim, int n1, int n2, int n3) {
+  return slab_plan(batch > 0 ? batch : 1, dim, n1, n2, n3).total;
+}
+
 
 static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream);
 
@@ -96,6 +113,9 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   BR_CHECK_ARG(B > 0 && D >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1 && n3 <= 32, "brNeumfStepRun: bad geometry");
   const bool train = s->training != 0;
   const bool deferred = s->adam_dense == 2;
+  const bool fused_final = train && s->fused_final != 0;     // reductions / BN grads / dense Adam in one launch at OPT_DENSE
+  const SlabPlan sp = slab_plan(B, D, n1, n2, n3);
+  float *slabs_t = s->slabs + sp.off_t, *slabs2 = s->slabs + sp.off2, *slabs1 = s->slabs + sp.off1;
   BR_CHECK_ARG(!deferred || (s->step_state && s->user_last && s->item_last), "brNeumfStepRun: deferred Adam needs step_state and the last[] arrays");
   const float p = train ? s->dropout : 0.f;
   const double bt = (double)(s->batch_total > 0 ? s->batch_total : B);
@@ -179,11 +199,11 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
                          s->row0, nullptr, stream));
     if (train) {
       // L3 forward, head, loss and their backward in one launch; W3|b3|W4|b4 are adjacent in theta / grad
-      const int nst = brNeumfTailSlabs(B);
+      const int nst = sp.ns_t;
       RUN(BR_TAG_HEAD, brNeumfTailFused(s->a2, n2, th + oW3, th + ob3, th + oW4, th + ob4, s->dot, s->labels, scale2, shift2, mean2, rstd2, p, s->seed,
                       (uint32_t)s->step, 2, s->row0, B, n2, n3, s->act, s->mf_first, s->loss, inv_b, s->a3, s->logit, s->prob, s->msums, s->ddot,
-                      s->gh2, n2, bsum2, s->slabs, nst, stream));
-      RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, nst, brNeumfTailSlabElems(n2, n3), gr + oW3, stream));
+                      s->gh2, n2, bsum2, slabs_t, nst, stream));
+      if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs_t, nst, sp.el_t, gr + oW3, stream));
     } else {
       RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob,
                       s->labels ? s->msums : nullptr, nullptr, 0, nullptr, nullptr, 0, stream));
@@ -191,18 +211,18 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   }
   if (!train) return BR_OK;
   if (ph & BR_PH_BWD2) {
-    const int ns2 = brDenseBackwardSlabs(B, n1, n2);
+    const int ns2 = sp.ns2;
     RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, n2, s->a2, n2, s->a1, n1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt_bn, scale1, shift1,
-                        mean1, rstd1, p, 1, s->seed, (uint32_t)s->step, s->row0, s->gh1, n1, s->dz_ws, s->slabs, ns2, bsum1, stream));
-    RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns2, (int64_t)n1 * n2 + n2, gr + oW2, stream));
+                        mean1, rstd1, p, 1, s->seed, (uint32_t)s->step, s->row0, s->gh1, n1, s->dz_ws, slabs2, ns2, bsum1, stream));
+    if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs2, ns2, sp.el2, gr + oW2, stream));
   }
   if (ph & BR_PH_BWD1) {
-    const int ns1 = brDenseBackwardSlabs(B, 2 * D, n1);
+    const int ns1 = sp.ns1;
     RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, n1, s->a1, n1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt_bn, nullptr,
-                        nullptr, nullptr, nullptr, p, 0, s->seed, (uint32_t)s->step, s->row0, s->dx0, 2 * D, s->dz_ws, s->slabs, ns1, nullptr, stream));
-    RUN(BR_TAG_REDUCE, brReduceSlabs(s->slabs, ns1, (int64_t)2 * D * n1 + n1, gr + oW1, stream));
+                        nullptr, nullptr, nullptr, p, 0, s->seed, (uint32_t)s->step, s->row0, s->dx0, 2 * D, s->dz_ws, slabs1, ns1, nullptr, stream));
+    if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs1, ns1, sp.el1, gr + oW1, stream));
   }
-  if (ph & BR_PH_BNG) {
+  if ((ph & BR_PH_BNG) && !fused_final) {
     RUN(BR_TAG_SMALL, brBnParamGradsPair(bsum2, gr + og2, gr + obe2, n2, bsum1, gr + og1, gr + obe1, n1, stream));
   }
   if (ph & BR_PH_OPT_TABLES) {
@@ -251,8 +271,18 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     if ((ph & BR_PH_SWEEP_ITEM) && s->adam_dense == 1)
       RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
   }
-  if (ph & BR_PH_OPT_DENSE)
+  if ((ph & BR_PH_OPT_DENSE) && fused_final) {
+    const float* const rs[3] = {slabs1, slabs2, slabs_t};
+    const int rn[3] = {sp.ns1, sp.ns2, sp.ns_t};
+    const int64_t re[3] = {sp.el1, sp.el2, sp.el_t}, ro[3] = {oW1, oW2, oW3};
+    const double* const bs[2] = {bsum1, bsum2};
+    const int bn_n[2] = {n1, n2};
+    const int64_t bg[2] = {og1, og2}, bb[2] = {obe1, obe2};
+    RUN(BR_TAG_ADAM_FLAT, brDenseFinalize(rs, rn, re, ro, bs, bn_n, bg, bb, th, s->adam_m, s->adam_v, gr, n_dense, s->alpha_t, s->beta1, s->beta2,
+                        s->adam_eps, stream));
+  } else if (ph & BR_PH_OPT_DENSE) {
     RUN(BR_TAG_ADAM_FLAT, brAdamFlat(th, s->adam_m, s->adam_v, gr, n_dense, s->alpha_t, s->beta1, s->beta2, s->adam_eps, stream));
+  }
   if (!joined) (void)hipStreamWaitEvent(hs, g_join, 0);   // the consumers run in a later call: join the sorts here
   return BR_OK;
 }

@@ -211,9 +211,8 @@ class NeuMFEngine:
         for k, n in (("scale1", n1), ("shift1", n1), ("mean1", n1), ("rstd1", n1), ("scale2", n2), ("shift2", n2), ("mean2", n2), ("rstd2", n2)):
             self.bn[k] = self.bn_buf[o:o + n]; o += n
         layers = ((2 * D, n1), (n1, n2), (n2, n3))
-        lib = _lib.load()
-        self.slabs = f(max(max(ops.dense_backward_slabs(B, k, n) * (k * n + n) for k, n in layers),
-                           lib.brNeumfTailSlabs(B) * lib.brNeumfTailSlabElems(n2, n3)))
+        # three slab regions [tail | layer 2 | layer 1] (the step driver lays them out; include/binrec.h)
+        self.slabs = f(_lib.load().brNeumfStepSlabFloats(B, D, n1, n2, n3))
         self.dz_ws = f(max(ops.dense_backward_ws_floats(B, k, n) for k, n in layers))
         self.nsh = ops.head_slabs(B)
         self.hslabs = f(self.nsh * (n3 + 2))
@@ -242,6 +241,7 @@ class NeuMFEngine:
         st.dropout, st.bn_eps, st.bn_momentum = cfg.dropout, cfg.bn_eps, cfg.bn_momentum
         st.seed = cfg.seed
         st.bn_local = 1 if (self.dist is not None and not cfg.sync_bn) else 0
+        st.fused_final = 1 if self.dist is None else 0     # a data-parallel host all-reduces between reduction and optimizer
         st.beta1, st.beta2, st.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
         P = lambda t: t.data_ptr()
         st.user_tab, st.user_m, st.user_v = P(self.fused["user"]), P(self.fused_m["user"]), P(self.fused_v["user"])

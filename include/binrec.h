@@ -204,6 +204,15 @@ int brBnParamGradsPair(const double* sums_a, float* dgamma_a, float* dbeta_a, in
                        float* dbeta_b, int Nb, brStream stream);
 int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* out, brStream stream);
 
+/* End of the dense backward in one launch (single-process path): fixed-order reduction of three slab regions into their
+ * ranges of the flat gradient (region r: n_slabs[r] slabs of slab_elems[r] floats -> grad[grad_off[r] ...)), the two BatchNorm
+ * blocks' dgamma/dbeta from their backward column sums (as brBnParamGrads), then Adam on theta/m/v (as brAdamFlat).
+ * The regions and BatchNorm blocks must tile [0, n) exactly. */
+int brDenseFinalize(const float* const* slabs, const int* n_slabs, const int64_t* slab_elems, const int64_t* grad_off,
+                    const double* const* bn_sums, const int* bn_n, const int64_t* dgamma_off, const int64_t* dbeta_off,
+                    float* theta, float* m, float* v, float* grad, int64_t n, double alpha_t, double beta1, double beta2,
+                    double eps, brStream stream);
+
 /* ---- fused tail of the training step: T(a2) -> Dense(n3) -> concat [dot | a3] -> Dense(1) -> sigmoid -> loss and the
  * backward of all of it, one launch (trainers/NFC_plain.py:143-155, src/models/NeuMFModel.py:75-93) ----
  * Same results as brDenseForward(layer 3) + brNeumfHead + brDenseBackward(layer 3) (fp32 sums in a different
@@ -298,7 +307,9 @@ typedef struct brNeumfStep {
   int32_t bn_local;   /* 1: BatchNorm statistics over THIS process' batch (per-replica BN, what MirroredStrategy does with a
                          plain BatchNormalization [TF-sem]) while the loss is still scaled by 1/batch_total; 0: the column
                          sums are all-reduced by the host and cover batch_total rows */
-  int32_t pad0_;
+  int32_t fused_final;   /* 1 (single process): the slab reductions, the BatchNorm parameter gradients and the dense Adam run
+                            as ONE launch at BR_PH_OPT_DENSE (brDenseFinalize) instead of inside their phases; `slabs` then
+                            holds three regions [tail | layer 2 | layer 1] (brNeumfStepSlabFloats) */
   float dropout, bn_eps, bn_momentum, pad0;
   uint64_t seed;
   double alpha_t, beta1, beta2, adam_eps;
@@ -381,6 +392,8 @@ int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a,
 int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,
                 double beta1, double beta2, double eps, brStream stream);
 int64_t brNeumfStepSizeof(void);
+/* floats of brNeumfStep.slabs for batches up to `batch`: the three slab regions [tail | layer 2 | layer 1] back to back */
+int64_t brNeumfStepSlabFloats(int64_t batch, int dim, int n1, int n2, int n3);
 int brNeumfStepRun(const brNeumfStep* s, uint32_t phases, brStream stream);
 
 /* Optional launch probe for measurement (bench.py roofline leg): HIP events on the launch stream
