@@ -250,23 +250,24 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
               s->user_tab, s->user_m, s->user_v, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, um,
               deferred ? s->user_last : nullptr,
               s->item_tab, s->item_m, s->item_v, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, im,
-              deferred ? s->item_last : nullptr, 2 * D, s->id_type, B, D, s->step_state, s->alpha_t, s->beta1, s->beta2, s->adam_eps, stream));
+              deferred ? s->item_last : nullptr, 2 * D, s->id_type, B, D, s->step_state, s->alpha_t, s->beta1, s->beta2, s->adam_eps, s->u_seg_ws,
+              s->i_seg_ws, stream));
     } else if ((ph & BR_PH_ROWS_USER) && deferred) {
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type,
-                           s->u_sorted_pos, B, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, stream));
+                           s->u_sorted_pos, B, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, s->u_seg_ws, stream));
     } else if (ph & BR_PH_ROWS_USER) {
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSorted(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type, s->u_sorted_pos, B,
-                           s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
+                           s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, s->u_seg_ws, stream));
     }
     if ((ph & BR_PH_SWEEP_USER) && s->adam_dense == 1)
       RUN(BR_TAG_SWEEP_USER, brAdamDenseSweep(s->user_tab, s->user_m, s->user_v, s->user_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, um, stream));
     if (both_rows) {
     } else if ((ph & BR_PH_ROWS_ITEM) && deferred) {
       RUN(BR_TAG_ADAM_ROWS_ITEM, brAdamRowsSortedDeferred(s->item_tab, s->item_m, s->item_v, s->item_last, s->item_rows, 2 * D, s->i_sorted_ids, s->id_type,
-                           s->i_sorted_pos, B, s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, stream));
+                           s->i_sorted_pos, B, s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, s->i_seg_ws, stream));
     } else if (ph & BR_PH_ROWS_ITEM) {
       RUN(BR_TAG_ADAM_ROWS_ITEM, brAdamRowsSorted(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->i_sorted_ids, s->id_type, s->i_sorted_pos, B,
-                           s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
+                           s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, s->i_seg_ws, stream));
     }
     if ((ph & BR_PH_SWEEP_ITEM) && s->adam_dense == 1)
       RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));

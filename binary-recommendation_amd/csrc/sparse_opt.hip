@@ -43,11 +43,67 @@ __device__ __forceinline__ bool segment_head(const IdT* sid, int64_t i) {
   return i == 0 || sid[i - 1] != sid[i];
 }
 
+// ---- long id segments (hot ids: a Zipf batch puts thousands of positions on one row) ------------------------------
+// A segment head that adds its duplicates one by one is a chain of dependent loads as long as the segment (measured:
+// 2.3 ms for the Adam-rows launch on a Zipf(1.05) batch of 65 536).  With a partial buffer the walk is two-level:
+// segment_partials_kernel gives every kSegBlock-aligned block of the SORTED order that continues its predecessor's id
+// the ordered sum of its own run (<= 64 adds, all blocks in parallel); the head then adds its own positions up to the
+// next block boundary one by one and ONE partial row per later block.  Still a fixed order - (((g_i + ..) + P_b) + P_b+1)
+// with P_b = ((g_64b + g_64b+1) + ..) - restated by the oracle (ordered_segment_sum); without a buffer: one by one.
+constexpr int kSegBlock = 64;
+
+template <typename IdT, int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type seg_acc(const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n, int64_t i,
+                                                            IdT row, const float* __restrict__ g, int64_t ldg,
+                                                            const float* __restrict__ part, int pdim) {
+  using V = typename VecT<VEC>::type;
+  V acc = vload<VEC>(g + (int64_t)spos[i] * ldg);
+  const int64_t own_end = part ? ((i / kSegBlock + 1) * kSegBlock < n ? (i / kSegBlock + 1) * kSegBlock : n) : n;
+  int64_t j = i + 1;
+  for (; j < own_end && sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg));
+  if (part && j == own_end)
+    for (; j < n && sid[j] == row; j += kSegBlock) acc = vadd(acc, vload<VEC>(part + (j / kSegBlock) * pdim));
+  return acc;
+}
+
+struct SegJob {                // one table's gradient source for the partials
+  const void* sid; const int32_t* spos;
+  const float* g0; int64_t ldg0;
+  const float* g1; int64_t ldg1;
+  float* part;                 // [ceil(n / kSegBlock)][dim]
+};
+struct SegJobs { SegJob j[2]; };
+
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void segment_partials_kernel(SegJobs jobs, int64_t n, int dim, int chunks, int lpr_log2, int split) {
+  using V = typename VecT<VEC>::type;
+  const SegJob& jb = jobs.j[blockIdx.y];
+  const IdT* __restrict__ sid = (const IdT*)jb.sid;
+  const int32_t* __restrict__ spos = jb.spos;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = (tid >> lpr_log2) + 1;                 // block 0 starts at a head (or is walked by one)
+  const int lir = (int)(tid & (lpr - 1));
+  const int64_t i = b * kSegBlock;
+  if (i >= n) return;
+  const IdT row = sid[i];
+  if (sid[i - 1] != row) return;                            // a head starts here: nobody reads this block's partial
+  const int64_t end = i + kSegBlock < n ? i + kSegBlock : n;
+  for (int c = lir; c < chunks; c += lpr) {
+    const int col = c * VEC;
+    const float* g = col < split ? jb.g0 + col : jb.g1 + (col - split);
+    const int64_t ldg = col < split ? jb.ldg0 : jb.ldg1;
+    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg);
+    for (int64_t j = i + 1; j < end && sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg));
+    vstore<VEC>(jb.part + b * dim + col, acc);
+  }
+}
+
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const IdT* __restrict__ sid, const int32_t* __restrict__ spos,
                                                            int64_t n, const float* __restrict__ g, int64_t ldg, int dim,
                                                            int chunks, int lpr_log2, float* __restrict__ out,
-                                                           int32_t* __restrict__ head_flag) {
+                                                           int32_t* __restrict__ head_flag, const float* __restrict__ part) {
   using V = typename VecT<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,8 +115,7 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const IdT* __restrict_
   if (!head) return;
   const IdT row = sid[i];
   for (int c = lir; c < chunks; c += lpr) {
-    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg + c * VEC);
-    for (int64_t j = i + 1; j < n && sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg + c * VEC));
+    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, row, g + c * VEC, ldg, part ? part + c * VEC : nullptr, dim);
     vstore<VEC>(out + i * dim + c * VEC, acc);
   }
 }
@@ -75,6 +130,7 @@ struct AdamRowsJob {
   const void* sid; const int32_t* spos;
   const float* g0; int64_t ldg0;
   const float* g1; int64_t ldg1;
+  const float* part;          // segment partials of this table's gradient source (NULL: one-by-one walk)
   uint8_t* mark; int32_t* last;
 };
 struct AdamRowsJobs { AdamRowsJob j[2]; };
@@ -111,8 +167,7 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs
     const int col = c * VEC;
     const float* g = col < split ? g0 + col : g1 + (col - split);
     const int64_t ldg = col < split ? ldg0 : ldg1;
-    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg);
-    for (int64_t j = i + 1; j < n && (int64_t)sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg));
+    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, sid[i], g, ldg, jb.part ? jb.part + col : nullptr, dim);
     const int64_t off = row * dim + col;
     V th = vload<VEC>(table + off), m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
     if (last && seen + 1 < t) adam_replay(th, m, v, seen, t - 1, ring, h);
@@ -185,12 +240,22 @@ __device__ __forceinline__ void adagrad_update1(float& th, float& acc, float g, 
   th = th - lr * g / (sqrtf(acc) + eps);
 }
 
+__device__ __forceinline__ void adagrad_update(float4& th, float4& a, float4 g, float lr, float eps) {
+  adagrad_update1(th.x, a.x, g.x, lr, eps); adagrad_update1(th.y, a.y, g.y, lr, eps);
+  adagrad_update1(th.z, a.z, g.z, lr, eps); adagrad_update1(th.w, a.w, g.w, lr, eps);
+}
+__device__ __forceinline__ void adagrad_update(float2& th, float2& a, float2 g, float lr, float eps) {
+  adagrad_update1(th.x, a.x, g.x, lr, eps); adagrad_update1(th.y, a.y, g.y, lr, eps);
+}
+__device__ __forceinline__ void adagrad_update(float& th, float& a, float g, float lr, float eps) { adagrad_update1(th, a, g, lr, eps); }
+
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void adagrad_rows_sorted_kernel(float* __restrict__ table, float* __restrict__ A,
                                                                    int64_t table_rows, int dim, int chunks, int lpr_log2,
                                                                    const IdT* __restrict__ sid, const int32_t* __restrict__ spos,
                                                                    int64_t n, const float* __restrict__ g, int64_t ldg,
-                                                                   float lr, float eps) {
+                                                                   float lr, float eps, const float* __restrict__ part) {
+  using V = typename VecT<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = tid >> lpr_log2;
@@ -200,20 +265,12 @@ __global__ __launch_bounds__(256) void adagrad_rows_sorted_kernel(float* __restr
   const int64_t row = (int64_t)sid[i];
   if ((uint64_t)row >= (uint64_t)table_rows) return;
   for (int c = lir; c < chunks; c += lpr) {
-    float accg[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) accg[k] = g[(int64_t)spos[i] * ldg + c * VEC + k];
-    for (int64_t j = i + 1; j < n && (int64_t)sid[j] == row; ++j)
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) accg[k] += g[(int64_t)spos[j] * ldg + c * VEC + k];
+    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, sid[i], g + c * VEC, ldg, part ? part + c * VEC : nullptr, dim);
     const int64_t off = row * dim + c * VEC;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      float th = table[off + k], a = A[off + k];
-      adagrad_update1(th, a, accg[k], lr, eps);
-      table[off + k] = th;
-      A[off + k] = a;
-    }
+    V th = vload<VEC>(table + off), a = vload<VEC>(A + off);
+    adagrad_update(th, a, acc, lr, eps);
+    vstore<VEC>(table + off, th);
+    vstore<VEC>(A + off, a);
   }
 }
 
@@ -473,21 +530,43 @@ extern "C" int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sor
   return rc != BR_OK ? rc : brRowIndexBuild(ids_b, id_type, n, upper_b, sorted_ids_b, sorted_pos_b, ws_b, ws_b_bytes, stream);
 }
 
+extern "C" int64_t brSegmentScratchFloats(int64_t n, int dim) { return ceil_div(n > 0 ? n : 1, kSegBlock) * (int64_t)dim; }
+
+// partial rows of every kSegBlock-aligned block that continues a segment (see seg_acc); jobs share n / dim / split
+static int launch_partials(const SegJob* jobs, int n_jobs, int id_type, int64_t n, int dim, const RowGeom& g, int split, hipStream_t s) {
+  const int64_t blocks = ceil_div(n, kSegBlock) - 1;
+  if (blocks <= 0) return BR_OK;
+  SegJobs J;
+  for (int q = 0; q < 2; ++q) J.j[q] = jobs[q < n_jobs ? q : 0];
+  const dim3 grid((unsigned)ceil_div(blocks, 256 >> g.lpr_log2), (unsigned)n_jobs);
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(g.vec, (segment_partials_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(J, n, dim, g.chunks, g.lpr_log2, split)));
+  else
+    BR_DISPATCH_VEC(g.vec, (segment_partials_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(J, n, dim, g.chunks, g.lpr_log2, split)));
+  BR_CHECK_LAUNCH("segment partials");
+  return BR_OK;
+}
+
 extern "C" int brSegmentSumRows(const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                                 const float* row_grads, int64_t ldg, int dim, float* out_rows, int32_t* head_flag,
-                                brStream stream) {
+                                float* seg_ws, brStream stream) {
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brSegmentSumRows: bad id_type");
   if (n == 0) return BR_OK;
   BR_CHECK_ARG(sorted_ids && sorted_pos && row_grads && out_rows && dim >= 1 && ldg >= dim, "brSegmentSumRows: bad args");
   const RowGeom g = row_geom_ld(dim, ldg);
   const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
   hipStream_t s = (hipStream_t)stream;
+  if (seg_ws) {
+    const SegJob job{sorted_ids, sorted_pos, row_grads, ldg, row_grads, ldg, seg_ws};
+    const int rc = launch_partials(&job, 1, id_type, n, dim, g, dim, s);
+    if (rc != BR_OK) return rc;
+  }
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(g.vec, (segment_sum_kernel<int32_t, VEC><<<grid, 256, 0, s>>>((const int32_t*)sorted_ids, sorted_pos, n, row_grads,
-                                                                                   ldg, dim, g.chunks, g.lpr_log2, out_rows, head_flag)));
+                                                                                   ldg, dim, g.chunks, g.lpr_log2, out_rows, head_flag, seg_ws)));
   else
     BR_DISPATCH_VEC(g.vec, (segment_sum_kernel<int64_t, VEC><<<grid, 256, 0, s>>>((const int64_t*)sorted_ids, sorted_pos, n, row_grads,
-                                                                                   ldg, dim, g.chunks, g.lpr_log2, out_rows, head_flag)));
+                                                                                   ldg, dim, g.chunks, g.lpr_log2, out_rows, head_flag, seg_ws)));
   BR_CHECK_LAUNCH("brSegmentSumRows");
   return BR_OK;
 }
@@ -514,6 +593,7 @@ struct AdamRowsArgs {      // one table's host-side arguments
   const float* row_grads; int64_t ldg;
   const float* row_grads_hi; int64_t ldg_hi;
   uint8_t* mark; int32_t* last;
+  float* seg_ws;
 };
 
 static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_type, int64_t n, int split, double alpha_t, double beta1,
@@ -521,6 +601,8 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdamRowsSorted: bad id_type");
   if (n == 0) return BR_OK;
   AdamRowsJobs jobs;
+  SegJob segs[2];
+  bool with_partials = true;
   int64_t ldmin = 4;
   for (int q = 0; q < n_jobs; ++q) {
     AdamRowsArgs t = a[q];
@@ -532,10 +614,19 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     const int64_t lm = (t.ldg % 4 == 0 && t.ldg_hi % 4 == 0 && split % 4 == 0 && (al & 15) == 0) ? 4
                        : (t.ldg % 2 == 0 && t.ldg_hi % 2 == 0 && split % 2 == 0 && (al & 7) == 0) ? 2 : 1;
     ldmin = lm < ldmin ? lm : ldmin;
-    jobs.j[q] = AdamRowsJob{t.table, t.m, t.v, t.table_rows, t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.mark, t.last};
+    jobs.j[q] = AdamRowsJob{t.table, t.m, t.v, t.table_rows, t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws,
+                            t.mark, t.last};
+    segs[q] = SegJob{t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws};
+    with_partials = with_partials && t.seg_ws != nullptr;
   }
   if (n_jobs == 1) jobs.j[1] = jobs.j[0];
+  if (!with_partials)
+    for (int q = 0; q < 2; ++q) jobs.j[q].part = nullptr;     // all tables or none
   const RowGeom g = row_geom_ld(dim, ldmin);
+  if (with_partials) {
+    const int rc = launch_partials(segs, n_jobs, id_type, n, dim, g, split, (hipStream_t)stream);
+    if (rc != BR_OK) return rc;
+  }
   const dim3 grid((unsigned)ceil_div(n, 256 >> g.lpr_log2), (unsigned)n_jobs);
   AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
   if (ss) h.alpha_ptr = &ss->alpha_t;
@@ -551,17 +642,17 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
 extern "C" int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int dim, const void* sorted_ids,
                                 int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
                                 const float* row_grads_hi, int64_t ldg_hi, int split, double alpha_t, double beta1,
-                                double beta2, double eps, uint8_t* mark, brStream stream) {
-  const AdamRowsArgs a{table, m, v, table_rows, sorted_ids, sorted_pos, row_grads, ldg, row_grads_hi, ldg_hi, mark, nullptr};
+                                double beta2, double eps, uint8_t* mark, float* seg_ws, brStream stream) {
+  const AdamRowsArgs a{table, m, v, table_rows, sorted_ids, sorted_pos, row_grads, ldg, row_grads_hi, ldg_hi, mark, nullptr, seg_ws};
   return adam_rows_launch(&a, 1, dim, id_type, n, split, alpha_t, beta1, beta2, eps, nullptr, stream);
 }
 
 extern "C" int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,
                                         const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                                         const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
-                                        const void* step_state, double beta1, double beta2, double eps, brStream stream) {
+                                        const void* step_state, double beta1, double beta2, double eps, float* seg_ws, brStream stream) {
   BR_CHECK_ARG(last && step_state, "brAdamRowsSortedDeferred: last / step_state missing");
-  const AdamRowsArgs a{table, m, v, table_rows, sorted_ids, sorted_pos, row_grads, ldg, row_grads_hi, ldg_hi, nullptr, last};
+  const AdamRowsArgs a{table, m, v, table_rows, sorted_ids, sorted_pos, row_grads, ldg, row_grads_hi, ldg_hi, nullptr, last, seg_ws};
   return adam_rows_launch(&a, 1, dim, id_type, n, split, 0.0, beta1, beta2, eps, (const StepStateDev*)step_state, stream);
 }
 
@@ -571,11 +662,11 @@ extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int6
                                     float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
                                     const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, uint8_t* mark_b, int32_t* last_b,
                                     int dim, int id_type, int64_t n, int split, const void* step_state, double alpha_t, double beta1,
-                                    double beta2, double eps, brStream stream) {
+                                    double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream) {
   BR_CHECK_ARG((last_a == nullptr) == (last_b == nullptr) && (last_a == nullptr || step_state), "brAdamRowsSortedPair: last arrays for both tables (with step_state) or neither");
   BR_CHECK_ARG(grads_hi_a && grads_hi_b, "brAdamRowsSortedPair: both gradient halves required");
-  const AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, mark_a, last_a},
-                             {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, mark_b, last_b}};
+  const AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, mark_a, last_a, seg_ws_a},
+                             {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, mark_b, last_b, seg_ws_b}};
   return adam_rows_launch(a, 2, dim, id_type, n, split, alpha_t, beta1, beta2, eps, last_a ? (const StepStateDev*)step_state : nullptr, stream);
 }
 
@@ -627,7 +718,7 @@ extern "C" int brAdamFlat(float* theta, float* m, float* v, const float* g, int6
 
 extern "C" int brAdagradRowsSorted(float* table, float* acc, int64_t table_rows, int dim, const void* sorted_ids,
                                    int id_type, const int32_t* sorted_pos, int64_t n, const float* row_grads, int64_t ldg,
-                                   double lr, double eps, brStream stream) {
+                                   double lr, double eps, float* seg_ws, brStream stream) {
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdagradRowsSorted: bad id_type");
   if (n == 0) return BR_OK;
   BR_CHECK_ARG(table && acc && sorted_ids && sorted_pos && row_grads && dim >= 1 && ldg >= dim && table_rows > 0,
@@ -635,14 +726,19 @@ extern "C" int brAdagradRowsSorted(float* table, float* acc, int64_t table_rows,
   const RowGeom g = row_geom_ld(dim, ldg);
   const unsigned grid = (unsigned)ceil_div(n, 256 >> g.lpr_log2);
   hipStream_t s = (hipStream_t)stream;
+  if (seg_ws) {
+    const SegJob job{sorted_ids, sorted_pos, row_grads, ldg, row_grads, ldg, seg_ws};
+    const int rc = launch_partials(&job, 1, id_type, n, dim, g, dim, s);
+    if (rc != BR_OK) return rc;
+  }
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(g.vec, (adagrad_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
                                table, acc, table_rows, dim, g.chunks, g.lpr_log2, (const int32_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, (float)lr, (float)eps)));
+                               row_grads, ldg, (float)lr, (float)eps, seg_ws)));
   else
     BR_DISPATCH_VEC(g.vec, (adagrad_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
                                table, acc, table_rows, dim, g.chunks, g.lpr_log2, (const int64_t*)sorted_ids, sorted_pos, n,
-                               row_grads, ldg, (float)lr, (float)eps)));
+                               row_grads, ldg, (float)lr, (float)eps, seg_ws)));
   BR_CHECK_LAUNCH("brAdagradRowsSorted");
   return BR_OK;
 }

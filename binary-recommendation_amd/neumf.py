@@ -271,6 +271,7 @@ class NeuMFEngine:
         ui, ii = self.user_index, self.item_index
         st.u_sorted_ids, st.u_sorted_pos, st.u_ws, st.u_ws_bytes = ui.sorted_ids.data_ptr(), ui.sorted_pos.data_ptr(), ui.ws.data_ptr(), ui.ws_bytes
         st.i_sorted_ids, st.i_sorted_pos, st.i_ws, st.i_ws_bytes = ii.sorted_ids.data_ptr(), ii.sorted_pos.data_ptr(), ii.ws.data_ptr(), ii.ws_bytes
+        st.u_seg_ws, st.i_seg_ws = ui.seg_ws(2 * self.cfg.dim).data_ptr(), ii.seg_ws(2 * self.cfg.dim).data_ptr()
 
     def _run(self, phases: int):
         _lib.check(_lib.load().brNeumfStepRun(ctypes.byref(self.step_struct), phases, ops._stream()), "brNeumfStepRun")

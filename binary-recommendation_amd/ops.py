@@ -98,7 +98,7 @@ def adam_rows_sorted_deferred(table, m, v, last, index, row_grads, ldg, step_sta
     check(_lib.load().brAdamRowsSortedDeferred(table.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), table.shape[0], table.shape[1],
                                                index.sorted_ids.data_ptr(), index.id_type, index.sorted_pos.data_ptr(), index.n,
                                                row_grads.data_ptr(), ldg, _p(row_grads_hi), ldg_hi, split, step_state.data_ptr(),
-                                               beta1, beta2, eps, _stream()), "brAdamRowsSortedDeferred")
+                                               beta1, beta2, eps, index.seg_ws(table.shape[1]).data_ptr(), _stream()), "brAdamRowsSortedDeferred")
 
 
 def row_dot(a, b, out=None):
@@ -174,6 +174,16 @@ class RowIndex:
         self.ws_bytes = int(_lib.load().brRowIndexWorkspaceBytes(capacity, self.id_type))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.n = 0
+        self._seg = {}
+
+    def seg_ws(self, dim: int):
+        """scratch for the two-level ordered duplicate sum (brSegmentScratchFloats): hot ids cost a chain of
+        capacity/64 + 64 dependent adds instead of one as long as the segment"""
+        t = self._seg.get(dim)
+        if t is None:
+            t = self._seg[dim] = torch.empty(int(_lib.load().brSegmentScratchFloats(self.capacity, dim)), dtype=torch.float32,
+                                             device=self.sorted_ids.device)
+        return t
 
     def build(self, ids: torch.Tensor, id_upper_bound: int = 0):
         t, ty = _ids(ids, "ids")
@@ -186,7 +196,7 @@ class RowIndex:
         return self
 
 
-def segment_sum_rows(index: RowIndex, row_grads, dim=None, ldg=None, out=None, head_flag=None):
+def segment_sum_rows(index: RowIndex, row_grads, dim=None, ldg=None, out=None, head_flag=None, two_level=True):
     dim = row_grads.shape[1] if dim is None else dim
     ldg = row_grads.stride(0) if ldg is None else ldg
     if out is None:
@@ -194,7 +204,8 @@ def segment_sum_rows(index: RowIndex, row_grads, dim=None, ldg=None, out=None, h
     if head_flag is None:
         head_flag = torch.empty(index.n, dtype=torch.int32, device=row_grads.device)
     check(_lib.load().brSegmentSumRows(index.sorted_ids.data_ptr(), index.id_type, index.sorted_pos.data_ptr(), index.n,
-                                       row_grads.data_ptr(), ldg, dim, out.data_ptr(), head_flag.data_ptr(), _stream()),
+                                       row_grads.data_ptr(), ldg, dim, out.data_ptr(), head_flag.data_ptr(),
+                                       index.seg_ws(dim).data_ptr() if two_level else None, _stream()),
           "brSegmentSumRows")
     return out, head_flag
 
@@ -213,7 +224,7 @@ def adam_rows_sorted(table, m, v, index: RowIndex, row_grads, ldg, alpha_t, beta
                                        table.shape[0], table.shape[1], index.sorted_ids.data_ptr(), index.id_type,
                                        index.sorted_pos.data_ptr(), index.n, row_grads.data_ptr(), int(ldg), _p(row_grads_hi),
                                        int(ldg_hi), int(split), float(alpha_t), float(beta1), float(beta2), float(eps),
-                                       _p(mark), _stream()), "brAdamRowsSorted")
+                                       _p(mark), index.seg_ws(table.shape[1]).data_ptr(), _stream()), "brAdamRowsSorted")
 
 
 def adam_dense_sweep(table, m, v, alpha_t, beta1=0.9, beta2=0.999, eps=1e-7, mark=None):
@@ -232,7 +243,7 @@ def adagrad_rows_sorted(table, acc, index: RowIndex, row_grads, ldg, lr, eps=1e-
     check(_lib.load().brAdagradRowsSorted(_f32(table, "table").data_ptr(), _f32(acc, "acc").data_ptr(), table.shape[0],
                                           table.shape[1], index.sorted_ids.data_ptr(), index.id_type,
                                           index.sorted_pos.data_ptr(), index.n, row_grads.data_ptr(), int(ldg), float(lr),
-                                          float(eps), _stream()), "brAdagradRowsSorted")
+                                          float(eps), index.seg_ws(table.shape[1]).data_ptr(), _stream()), "brAdagradRowsSorted")
 
 
 def adagrad_flat(theta, acc, g, lr, eps=1e-7):

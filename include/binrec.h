@@ -107,11 +107,22 @@ int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t id_upper_bo
 int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
                         const void* ids_b, int64_t upper_b, void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes,
                         int id_type, int64_t n, brStream stream);
+/* The ordered duplicate sum and its scratch.  Every kernel that sums a segment (brSegmentSumRows, brAdamRowsSorted*,
+ * brAdagradRowsSorted) takes an optional `seg_ws` of brSegmentScratchFloats(n, dim) floats (16-byte aligned):
+ *   seg_ws == NULL: the segment head adds its duplicates one by one in ascending batch position = a sequential fp32
+ *     unsorted_segment_sum ([TF-sem] _deduplicate_indexed_slices).  The chain is as long as the segment: fine for
+ *     near-uniform ids, 2.3 ms for ONE launch on a Zipf(1.05) batch of 65 536 (one id holds thousands of positions).
+ *   seg_ws != NULL: two levels, still a fixed order: every 64-aligned block of the SORTED order that continues its
+ *     predecessor's id gets the one-by-one sum of its own run (one extra small launch, all blocks in parallel); the head
+ *     adds its own positions up to the next block boundary one by one, then one partial per later block:
+ *     ((((g_i + g_i+1) + ..) + P_b) + P_b+1) + .., P_b = ((g_64b + g_64b+1) + ..).  Segments that do not cross a
+ *     64-aligned boundary are summed exactly as with NULL.  oracle/binrec_oracle.py::ordered_segment_sum restates it. */
+int64_t brSegmentScratchFloats(int64_t n, int dim);
 /* Materialised dedup: for each segment head h (sorted position), out_rows[h] = ordered sum of
  * row_grads[sorted_pos[j]] over the segment, head_flag[h]=1; non-head rows untouched, flag 0. */
 int brSegmentSumRows(const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                      const float* row_grads, int64_t ldg, int dim, float* out_rows,
-                     int32_t* head_flag, brStream stream);
+                     int32_t* head_flag, float* seg_ws, brStream stream);
 /* Fast form (order-nondeterministic float atomics): g_table[ids[b],:] += rows[b,:]. */
 int brScatterAddRows(float* g_table, int64_t table_rows, const void* ids, int id_type,
                      int64_t n, const float* rows, int dim, int* err_flag, brStream stream);
@@ -132,7 +143,7 @@ int brAdamRowsSorted(float* table, float* m, float* v, int64_t table_rows, int d
                      const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                      const float* row_grads, int64_t ldg, const float* row_grads_hi,
                      int64_t ldg_hi, int split, double alpha_t, double beta1, double beta2,
-                     double eps, uint8_t* mark, brStream stream);
+                     double eps, uint8_t* mark, float* seg_ws, brStream stream);
 int brAdamDenseSweep(float* table, float* m, float* v, int64_t table_rows, int dim,
                      double alpha_t, double beta1, double beta2, double eps, uint8_t* mark,
                      brStream stream);
@@ -145,7 +156,7 @@ int brAdamFlat(float* theta, float* m, float* v, const float* g, int64_t n, doub
 int brAdagradRowsSorted(float* table, float* acc, int64_t table_rows, int dim,
                         const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                         const float* row_grads, int64_t ldg, double lr, double eps,
-                        brStream stream);
+                        float* seg_ws, brStream stream);
 int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n, double lr, double eps,
                   brStream stream);
 
@@ -329,6 +340,7 @@ typedef struct brNeumfStep {
   float* slabs; float* hslabs;
   float* dz_ws;                            /* brDenseBackwardWorkspaceFloats(max layer) floats */
   int* err_flag;
+  float* u_seg_ws; float* i_seg_ws;        /* brSegmentScratchFloats(max batch, 2*dim) each, or NULL (one-by-one duplicate sums) */
   void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;
   void* i_sorted_ids; int32_t* i_sorted_pos; void* i_ws; int64_t i_ws_bytes;
   double lr;          /* learning rate (only used with step_state) */
@@ -380,7 +392,7 @@ int brMfGradInplace(float* stash_user, float* stash_item, int64_t ld, const floa
 int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,
                              const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                              const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
-                             const void* step_state, double beta1, double beta2, double eps, brStream stream);
+                             const void* step_state, double beta1, double beta2, double eps, float* seg_ws, brStream stream);
 /* The user and the item table of one NeuMF step in ONE launch (same dim, n, split; each alone leaves HBM half idle).
  * last_* non-NULL (both): deferred mode (step_state required, alpha_t ignored); else brAdamRowsSorted semantics with marks. */
 int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a, const void* sorted_ids_a, const int32_t* sorted_pos_a,
@@ -388,7 +400,7 @@ int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a,
                          float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
                          const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, uint8_t* mark_b, int32_t* last_b,
                          int dim, int id_type, int64_t n, int split, const void* step_state, double alpha_t, double beta1,
-                         double beta2, double eps, brStream stream);
+                         double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream);
 int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,
                 double beta1, double beta2, double eps, brStream stream);
 int64_t brNeumfStepSizeof(void);

@@ -131,6 +131,35 @@ def dedup_rows_sequential(ids, rows, dt=np.float32):
     return uniq, out
 
 
+SEG_BLOCK = 64   # include/binrec.h "The ordered duplicate sum and its scratch"
+
+
+def ordered_segment_sum(ids, rows, dt=np.float32, block=SEG_BLOCK):
+    """The HIP kernels' two-level ordered duplicate sum (seg_ws != NULL), restated: in the stable-sorted order, the head
+    of a segment [s, e) adds positions s+1 .. up to the next multiple of `block` one by one; every later block start b
+    (multiple of `block`, b < e) contributes P_b = the one-by-one sum of positions b .. min(b + block, e) - 1.
+    Segments that do not cross a block boundary equal dedup_rows_sequential bit for bit."""
+    ids = np.asarray(ids).astype(np.int64)
+    rows = np.asarray(rows, dtype=dt)
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    uniq, start = np.unique(sid, return_index=True)
+    out = np.zeros((len(uniq), rows.shape[1]), dtype=dt)
+    ends = list(start[1:]) + [len(sid)]
+    for k, (s, e) in enumerate(zip(start, ends)):
+        own_end = min(e, (s // block + 1) * block)
+        acc = rows[order[s]].astype(dt).copy()
+        for j in range(s + 1, own_end):
+            acc = (acc + rows[order[j]]).astype(dt)
+        for b in range(own_end, e, block):
+            part = rows[order[b]].astype(dt).copy()
+            for j in range(b + 1, min(b + block, e)):
+                part = (part + rows[order[j]]).astype(dt)
+            acc = (acc + part).astype(dt)
+        out[k] = acc
+    return uniq, out
+
+
 def scatter_add_dense(nrows, ids, rows, dt=np.float64):
     """g_table[ids[b],:] += rows[b,:] (np.add.at) — dense view of the same sum."""
     g = np.zeros((nrows, rows.shape[1]), dtype=dt)

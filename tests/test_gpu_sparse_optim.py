@@ -22,19 +22,26 @@ def _dup_ids(rng, n, rows):
 
 @pytest.mark.parametrize("dim", [64, 10, 75])
 @pytest.mark.parametrize("idt", [torch.int32, torch.int64])
-def test_segment_sum_bit_exact(dev, dim, idt):
+@pytest.mark.parametrize("two_level", [False, True])
+def test_segment_sum_bit_exact(dev, dim, idt, two_level):
+    """S1: one-by-one (seg_ws NULL) == a sequential fp32 unsorted_segment_sum; two-level (hot ids: segments of ~150 here
+    cross several 64-position blocks) == the oracle's restatement of that fixed order - both bit for bit."""
     ops = _ops()
     rng = np.random.default_rng(5)
     n, rows = 3001, 400
     ids = _dup_ids(rng, n, rows)
     g = rng.normal(size=(n, dim)).astype(np.float32)
     idx = ops.RowIndex(n, idt, dev).build(torch.from_numpy(ids).to(dev).to(idt), rows)
-    out, head = ops.segment_sum_rows(idx, torch.from_numpy(g).to(dev))
+    out, head = ops.segment_sum_rows(idx, torch.from_numpy(g).to(dev), two_level=two_level)
     torch.cuda.synchronize()
     sid = idx.sorted_ids.cpu().numpy(); spos = idx.sorted_pos.cpu().numpy()
     order = np.argsort(ids, kind="stable")
     assert np.array_equal(sid, ids[order]) and np.array_equal(spos, order)  # stable sort
-    uniq, ref = O.dedup_rows_sequential(ids, g, dt=np.float32)
+    uniq, ref = (O.ordered_segment_sum if two_level else O.dedup_rows_sequential)(ids, g, dt=np.float32)
+    if two_level:      # the two orders differ in the last bits on the long segments, and only there
+        _, seq = O.dedup_rows_sequential(ids, g, dt=np.float32)
+        assert not np.array_equal(seq.view(np.uint32), ref.view(np.uint32))
+        np.testing.assert_allclose(ref, seq, rtol=1e-5, atol=1e-5)
     h = head.cpu().numpy().astype(bool)
     assert np.array_equal(sid[h], uniq)
     assert np.array_equal(out.cpu().numpy()[h].view(np.uint32), ref.view(np.uint32))  # same order => same bits

@@ -149,3 +149,25 @@ def test_golden_fixtures_reproduce():
         fresh = mg.CASES[f[:-4]]()
         for k in z.files:
             np.testing.assert_allclose(fresh[k], z[k], rtol=1e-12, atol=1e-15, err_msg=f"{f}:{k}")
+
+
+def test_two_level_segment_sum_restatement():
+    """ordered_segment_sum (the HIP kernels' order for hot ids) vs the sequential sum: identical on segments that stay
+    inside one 64-position block of the sorted order, equal to fp32 rounding on the long ones, exact in float64 sense."""
+    rng = np.random.default_rng(3)
+    n = 1000
+    ids = rng.integers(0, 400, n)
+    ids[:300] = 7                                     # one hot id: 300+ positions, crosses 4-5 block boundaries
+    g = rng.normal(size=(n, 6)).astype(np.float32)
+    u1, seq = O.dedup_rows_sequential(ids, g, dt=np.float32)
+    u2, two = O.ordered_segment_sum(ids, g, dt=np.float32)
+    assert np.array_equal(u1, u2)
+    np.testing.assert_allclose(two, seq, rtol=1e-5, atol=1e-5)
+    _, ref64 = O.dedup_rows_sequential(ids, g.astype(np.float64), dt=np.float64)
+    np.testing.assert_allclose(two, ref64, rtol=1e-5, atol=1e-5)
+    order = np.argsort(ids, kind="stable"); sid = ids[order]
+    uniq, start = np.unique(sid, return_index=True)
+    ends = np.append(start[1:], n)
+    inside = (start // 64) == ((ends - 1) // 64)       # segments within one block: bit-equal
+    assert inside.sum() > 100
+    assert np.array_equal(two[inside].view(np.uint32), seq[inside].view(np.uint32))
