@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void inbatch_kernel(const float* __restrict__ 
   float* Rs = smem;                 // [64][ld]
   float* Cs = Rs + kT * ld;         // [64][ld]
   float* Ps = Cs + kT * ld;         // [64][68]  P tile (grad modes)
-  float* aux = Ps + kT * 68;        // [64] per-column lse (GRAD_C)
+  float* CsT = Ps + kT * 68;        // [Dp][68]  the column tile transposed (grad modes: B operand of P·C as ds_read_b128)
+  float* aux = CsT + ((MODE == MODE_GRAD_R || MODE == MODE_GRAD_C) ? Dp * 68 : 0);   // [64] per-column lse (GRAD_C)
   int64_t* cid = reinterpret_cast<int64_t*>(aux + kT);   // [64] ids of the column entities
   constexpr int ldp = 68;
 
@@ -75,9 +76,50 @@ __global__ __launch_bounds__(256) void inbatch_kernel(const float* __restrict__ 
 #pragma unroll
   for (int t = 0; t < 8; ++t) gacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // The column tile of step c0 + 64 is requested into registers BEFORE the MFMA work of step c0 and written to LDS after
+  // it (the staging used to sit between two barriers with its global latency exposed on every one of the n_c / 64 steps).
+  constexpr int MAXQ = kT * (128 / 4) / 256;        // float4 per thread at dim 128
+  const int cq = Dp >> 2, n_q4 = kT * cq;
+  const bool cvec = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cm) & 15) == 0);
+  float4 pre[MAXQ];
+  auto fetch_tile = [&](int64_t c0n) {
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int idx = threadIdx.x + 256 * q;
+      const int idc = idx < n_q4 ? idx : 0;
+      const int r = idc / cq, c = (idc - r * cq) << 2;
+      const int64_t gr = c0n + r;
+      const int64_t grc = gr < n_c ? gr : n_c - 1;
+      float4 v;
+      if (cvec) {
+        const float4 t = *reinterpret_cast<const float4*>(Cm + grc * dim + (c < dim ? c : 0));
+        const bool ok = gr < n_c && c < dim;
+        v = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      } else {
+        const float* pr_ = Cm + grc * dim;
+        const float t0 = pr_[c + 0 < dim ? c + 0 : dim - 1], t1 = pr_[c + 1 < dim ? c + 1 : dim - 1];
+        const float t2 = pr_[c + 2 < dim ? c + 2 : dim - 1], t3 = pr_[c + 3 < dim ? c + 3 : dim - 1];
+        const bool rin = gr < n_c;
+        v = make_float4((rin && c + 0 < dim) ? t0 : 0.f, (rin && c + 1 < dim) ? t1 : 0.f, (rin && c + 2 < dim) ? t2 : 0.f, (rin && c + 3 < dim) ? t3 : 0.f);
+      }
+      pre[q] = v;
+    }
+  };
+  fetch_tile(0);
   for (int64_t c0 = 0; c0 < n_c; c0 += kT) {
-    __syncthreads();
-    stage_rows(Cs, ld, Cm, n_c, c0, dim, Dp);
+    __syncthreads();                                 // the previous step's readers of Cs / CsT / cid are done
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int idx = threadIdx.x + 256 * q;
+      if (idx < n_q4) {
+        const int r = idx / cq, c = (idx - r * cq) << 2;
+        *reinterpret_cast<float4*>(Cs + r * ld + c) = pre[q];
+        if (MODE == MODE_GRAD_R || MODE == MODE_GRAD_C) {
+          CsT[(c + 0) * 68 + r] = pre[q].x; CsT[(c + 1) * 68 + r] = pre[q].y;
+          CsT[(c + 2) * 68 + r] = pre[q].z; CsT[(c + 3) * 68 + r] = pre[q].w;
+        }
+      }
+    }
     if (threadIdx.x < kT) {
       const int64_t gc = c0 + threadIdx.x;
       int64_t v = -2;
@@ -86,6 +128,7 @@ __global__ __launch_bounds__(256) void inbatch_kernel(const float* __restrict__ 
       if (MODE == MODE_GRAD_C) aux[threadIdx.x] = gc < n_c ? lse_in[gc] : 0.f;
     }
     __syncthreads();
+    if (c0 + kT < n_c) fetch_tile(c0 + kT);          // in flight during this step's MFMA work
     // ---- S tile: rows of this wave x 64 columns ----
     f32x4 s[4];
 #pragma unroll
@@ -168,12 +211,17 @@ __global__ __launch_bounds__(256) void inbatch_kernel(const float* __restrict__ 
     for (int j = 0; j < 4; ++j) {          // contraction over the 64 columns of the tile
       const float4 a4 = *reinterpret_cast<const float4*>(pr + 16 * j);
       const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      // B operand: 4 consecutive column entities (k = 16j + 4g + e) of feature t*16 + c16 = one ds_read_b128 of the
+      // transposed tile (was one ds_read_b32 per MFMA)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* crow = Cs + (16 * j + 4 * g + e) * ld + c16;
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (t < DT) gacc[t] = mfma16s(a[e], crow[t * 16], gacc[t]);
+      for (int t = 0; t < 8; ++t) {
+        if (t < DT) {
+          const float4 b4 = *reinterpret_cast<const float4*>(CsT + (t * 16 + c16) * 68 + 16 * j + 4 * g);
+          gacc[t] = mfma16s(a[0], b4.x, gacc[t]);
+          gacc[t] = mfma16s(a[1], b4.y, gacc[t]);
+          gacc[t] = mfma16s(a[2], b4.z, gacc[t]);
+          gacc[t] = mfma16s(a[3], b4.w, gacc[t]);
+        }
       }
     }
   }
@@ -264,7 +312,14 @@ static int launch_inbatch(const float* R, const float* Cm, int64_t n_r, int64_t 
                           int id_type, int64_t diag_offset, const float* lse_in, float* out, int64_t ldo, float* lse_out, double* loss_sum,
                           hipStream_t s) {
   const int Dp = (dim + 15) & ~15;
-  const size_t shmem = ((size_t)2 * kT * (Dp + 4) + (size_t)kT * 68 + kT) * sizeof(float) + kT * sizeof(int64_t) + 16;
+  const bool grad = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C;
+  const size_t shmem = ((size_t)2 * kT * (Dp + 4) + (size_t)kT * 68 + (grad ? (size_t)Dp * 68 : 0) + kT) * sizeof(float) + kT * sizeof(int64_t) + 16;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)inbatch_kernel<MODE, int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)inbatch_kernel<MODE, int64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
   const unsigned grid = (unsigned)ceil_div(n_r, kT);
   if (id_type == BR_IDS_I64)
     inbatch_kernel<MODE, int64_t><<<grid, 256, shmem, s>>>(R, Cm, n_r, n_c, dim, (const int64_t*)q_pos_ids, (const int64_t*)cand_ids, diag_offset,
