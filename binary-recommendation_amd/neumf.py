@@ -95,7 +95,11 @@ class NeuMFEngine:
                  id_dtype=torch.int32, init_seed: int = 0, dist=None):
         self.cfg, self.device, self.max_batch, self.id_dtype = cfg, torch.device(device), int(max_batch), id_dtype
         self.num_user_rows, self.num_item_rows = int(num_user_rows), int(num_item_rows)
-        self.dist = dist                      # None or a parallel.DataParallelCtx
+        self.dist = dist                      # None, or the parallel.DistCtx of the row-sharded subclass
+        if dist is not None and not self.sharded:
+            # replicated tables would need every rank's row gradients (an all-gather of B x 2*dim per stream): the
+            # multi-GPU form of this engine is the row-sharded one
+            raise ValueError("a process group is only supported through parallel.make_sharded_engine (row-sharded tables)")
         D, (n1, n2, n3) = cfg.dim, cfg.hidden
         if 2 * D > 256 or max(n1, n2) > 128 or n3 > 32:
             raise ValueError("tower widths: 2*dim <= 256 (first layer, split-K above 128), n1, n2 <= 128 and n3 <= 32 in this build")
