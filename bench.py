@@ -395,7 +395,7 @@ def main():
         del e2
         return {"value": B * world * args.steps / d2, "unit": "pairs/s", "ms_per_step": d2 / args.steps * 1e3}
 
-    if not args.no_lazy and args.optimizer == "adam_dense":
+    if not args.no_lazy and args.optimizer == "adam_dense" and world == 1:     # the extra legs are single-GPU information
         del eng
         if deferred_mode:
             sweep_leg = extra_leg("adam_dense", "sweep")
