@@ -793,3 +793,78 @@ extern "C" int brStageBatch(void* dst_users, void* dst_items, float* dst_labels,
   BR_CHECK_LAUNCH("brStageBatch");
   return BR_OK;
 }
+
+// ---- row-sharded exchange planning (parallel.py ShardExchange.plan): owner(id) = id mod W --------------------------
+// One id stream: dest = id mod W -> stable sort of (dest, position) with the index machinery above -> order[j] = batch
+// position of bucket slot j, inv[b] = bucket slot of position b, send_local[j] = id div W in bucket order, counts[d] =
+// rows for owner d.  4 launches for a PAIR of equally long streams instead of ~10 torch ops per stream.
+template <typename IdT>
+__global__ __launch_bounds__(256) void shard_dest_kernel(const IdT* __restrict__ a, const IdT* __restrict__ b, IdT* __restrict__ da,
+                                                          IdT* __restrict__ db, int64_t n, int world) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const IdT* src = blockIdx.y ? b : a;
+  IdT* dst = blockIdx.y ? db : da;
+  const int64_t id = (int64_t)src[i];
+  const int64_t m = id % world;
+  dst[i] = (IdT)(m < 0 ? m + world : m);
+}
+
+struct ShardFinishJob { const void* ids; const void* sorted_dest; const int32_t* order; int32_t* inv; void* send_local; int64_t* counts; };
+struct ShardFinishJobs { ShardFinishJob j[2]; };
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void shard_finish_kernel(ShardFinishJobs jobs, int64_t n, int world) {
+  const ShardFinishJob& jb = jobs.j[blockIdx.y];
+  const IdT* ids = (const IdT*)jb.ids;
+  const IdT* sd = (const IdT*)jb.sorted_dest;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) {
+    const int32_t b = jb.order[j];
+    jb.inv[b] = (int32_t)j;
+    const int64_t id = (int64_t)ids[b];
+    const int64_t m = id % world;
+    ((IdT*)jb.send_local)[j] = (IdT)((id - (m < 0 ? m + world : m)) / world);      // floor division for every sign
+  }
+  if (j < world) {                                   // rows for owner j: [lower_bound(j), lower_bound(j + 1)) of the sorted dests
+    auto lb = [&](int64_t d) {
+      int64_t lo = 0, hi = n;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)sd[mid] < d) lo = mid + 1; else hi = mid; }
+      return lo;
+    };
+    jb.counts[j] = lb(j + 1) - lb(j);
+  }
+}
+
+extern "C" int brShardPlanPair(const void* ids_a, const void* ids_b, int id_type, int64_t n, int world, void* dest_a, void* dest_b,
+                               void* sorted_dest_a, void* sorted_dest_b, int32_t* order_a, int32_t* order_b, void* ws_a, void* ws_b,
+                               int64_t ws_bytes, int32_t* inv_a, int32_t* inv_b, void* send_local_a, void* send_local_b,
+                               int64_t* counts_a, int64_t* counts_b, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brShardPlanPair: bad id_type");
+  BR_CHECK_ARG(world >= 1 && world <= 256 && n >= 0, "brShardPlanPair: bad world / n");
+  const int n_jobs = ids_b ? 2 : 1;
+  BR_CHECK_ARG(ids_a && dest_a && sorted_dest_a && order_a && ws_a && inv_a && send_local_a && counts_a, "brShardPlanPair: null pointer (stream a)");
+  BR_CHECK_ARG(!ids_b || (dest_b && sorted_dest_b && order_b && ws_b && inv_b && send_local_b && counts_b), "brShardPlanPair: null pointer (stream b)");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    (void)hipMemsetAsync(counts_a, 0, sizeof(int64_t) * world, s);
+    if (ids_b) (void)hipMemsetAsync(counts_b, 0, sizeof(int64_t) * world, s);
+    return BR_OK;
+  }
+  const dim3 g((unsigned)ceil_div(n, 256), (unsigned)n_jobs);
+  if (id_type == BR_IDS_I32) shard_dest_kernel<int32_t><<<g, 256, 0, s>>>((const int32_t*)ids_a, (const int32_t*)ids_b, (int32_t*)dest_a, (int32_t*)dest_b, n, world);
+  else shard_dest_kernel<int64_t><<<g, 256, 0, s>>>((const int64_t*)ids_a, (const int64_t*)ids_b, (int64_t*)dest_a, (int64_t*)dest_b, n, world);
+  BR_CHECK_LAUNCH("brShardPlanPair(dest)");
+  int rc;
+  if (ids_b) rc = brRowIndexBuildPair(dest_a, world, sorted_dest_a, order_a, ws_a, ws_bytes, dest_b, world, sorted_dest_b, order_b, ws_b, ws_bytes, id_type, n, stream);
+  else rc = brRowIndexBuild(dest_a, id_type, n, world, sorted_dest_a, order_a, ws_a, ws_bytes, stream);
+  if (rc != BR_OK) return rc;
+  ShardFinishJobs J;
+  J.j[0] = ShardFinishJob{ids_a, sorted_dest_a, order_a, inv_a, send_local_a, counts_a};
+  J.j[1] = ids_b ? ShardFinishJob{ids_b, sorted_dest_b, order_b, inv_b, send_local_b, counts_b} : J.j[0];
+  const dim3 g2((unsigned)ceil_div(n > world ? n : world, 256), (unsigned)n_jobs);
+  if (id_type == BR_IDS_I32) shard_finish_kernel<int32_t><<<g2, 256, 0, s>>>(J, n, world);
+  else shard_finish_kernel<int64_t><<<g2, 256, 0, s>>>(J, n, world);
+  BR_CHECK_LAUNCH("brShardPlanPair(finish)");
+  return BR_OK;
+}

@@ -19,8 +19,19 @@ LOSS = {"bce": 0, "mse": 1}
 STAT_REPLICAS = 8   # BR_STAT_REPLICAS: every BatchNorm column-sum buffer is double[8][2N]
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_DEV_INDEX = None
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on this process' device (one process per GPU).  The raw getter costs ~1 us;
+    building a torch.cuda.Stream object per launch was 0.1 ms of a 0.75 ms row-sharded step."""
+    global _DEV_INDEX
+    if _RAW_STREAM is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return _RAW_STREAM(_DEV_INDEX)
 
 
 def _p(t):

@@ -107,6 +107,14 @@ int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t id_upper_bo
 int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
                         const void* ids_b, int64_t upper_b, void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes,
                         int id_type, int64_t n, brStream stream);
+/* Row-sharded exchange planning for one or two equally long id streams (ids_b NULL: one): owner(id) = id mod world.
+ * order[j] = batch position of bucket slot j (buckets = positions stably sorted by owner), inv[b] = bucket slot of position b,
+ * send_local[j] = id div world in bucket order, counts[d] = rows for owner d (int64[world]).  dest / sorted_dest: scratch of n
+ * ids each; ws: brRowIndexWorkspaceBytes(n) bytes each. */
+int brShardPlanPair(const void* ids_a, const void* ids_b, int id_type, int64_t n, int world, void* dest_a, void* dest_b,
+                    void* sorted_dest_a, void* sorted_dest_b, int32_t* order_a, int32_t* order_b, void* ws_a, void* ws_b,
+                    int64_t ws_bytes, int32_t* inv_a, int32_t* inv_b, void* send_local_a, void* send_local_b,
+                    int64_t* counts_a, int64_t* counts_b, brStream stream);
 /* The ordered duplicate sum and its scratch.  Every kernel that sums a segment (brSegmentSumRows, brAdamRowsSorted*,
  * brAdagradRowsSorted) takes an optional `seg_ws` of brSegmentScratchFloats(n, dim) floats (16-byte aligned):
  *   seg_ws == NULL: the segment head adds its duplicates one by one in ascending batch position = a sequential fp32
