@@ -357,7 +357,9 @@ struct InBn {                // BN carried by the input (for the producer's back
 // ([batch][Np], zero padded) for the dW kernel.  dx = dz·W^T against the row-major W image in LDS
 // (lane (c16,g) reads W[kt*16+c16][16j+4g..+3] as one ds_read_b128).  Epilogue: dropout transposed
 // (keep-bytes in the per-wave LDS patch), gx stored, BN-backward sums of the producer accumulated.
-template <int NT, int KT>
+// IBN: the layer's input carries a BatchNorm (backward column sums of the producer + xhat operands) - a template
+// parameter because its 32 + 16 extra registers spill the first layer's instantiation, which never needs them
+template <int NT, int KT, bool IBN>
 __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
                                                                 const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
                                                                 int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
@@ -375,8 +377,8 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
   uint8_t* mk = mk_all + wave * 16 * NCH;
 
   for (int k = threadIdx.x; k < Kp; k += kThreads) {
-    Is[k] = (ibn.mean && k < K) ? ibn.mean[k] : 0.f;
-    Is[Kp + k] = (ibn.mean && k < K) ? ibn.rstd[k] : 0.f;
+    Is[k] = (IBN && k < K) ? ibn.mean[k] : 0.f;
+    Is[Kp + k] = (IBN && k < K) ? ibn.rstd[k] : 0.f;
   }
   for (int n = threadIdx.x; n < Np; n += kThreads) {
     float c1 = 1.f, c2 = 0.f, c3 = 0.f, mu = 0.f, rs = 0.f;
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
     // raw x of this tile's outputs (for xhat in the epilogues): ALL k-tiles are requested here, before the
     // Philox and MFMA work of the tile - loaded per pass they cost one exposed HBM round trip per pass
     float xv[4][KT];
-    if (ibn.mean) {
+    if (IBN) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t gr = rbase + 4 * g + r;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
                 const bool keep = tin.drop.thr ? ((mk[lr * NCH + (k >> 3)] >> (k & 7)) & 1) : true;
                 const float dh = keep ? acc[w][r] * tin.drop.inv_keep : 0.f;
                 gx[gr * ldgx + k] = dh;
-                if (ibn.mean && keep) {
+                if (IBN && keep) {
                   const float xhat = (xv[r][kt0 + w] - Is[k]) * Is[Kp + k];
                   isum[kt0 + w] += dh;
                   isq[kt0 + w] += dh * xhat;
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < NT; ++j) dz[j] = dzn[j];
   }
-  if (in_sums && ibn.mean) {
+  if (IBN && in_sums) {
     __shared__ double red[2][kMaxT * 16];
     for (int n = threadIdx.x; n < 2 * kMaxT * 16; n += kThreads) (&red[0][0])[n] = 0.0;
     __syncthreads();
@@ -996,16 +998,23 @@ extern "C" int64_t brDenseBackwardWorkspaceFloats(int64_t batch, int K, int N) {
   return batch * (int64_t)(tiles16(N) * 16);
 }
 
+template <int NT, int KT, bool IBN>
+static void launch_dx_v(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
+                        int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn, int64_t row0,
+                        float* gx, int64_t ldgx, float* dzbuf, double* in_sums) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dense_dx_kernel<NT, KT, IBN>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  dense_dx_kernel<NT, KT, IBN><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
+}
 template <int NT, int KT>
 static void launch_dx(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
                       int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn, int64_t row0,
                       float* gx, int64_t ldgx, float* dzbuf, double* in_sums) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_dx_kernel<NT, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-    attr_set = true;
-  }
-  dense_dx_kernel<NT, KT><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
+  if (ibn.mean) launch_dx_v<NT, KT, true>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
+  else launch_dx_v<NT, KT, false>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
 }
 
 template <int NT, int KTP>
