@@ -160,6 +160,16 @@ def ordered_segment_sum(ids, rows, dt=np.float32, block=SEG_BLOCK):
     return uniq, out
 
 
+def dedup_rows_unordered(ids, rows, dt=np.float64):
+    """Same unique-id sums as dedup_rows_sequential, accumulated by np.add.at (no Python loop): the add order is
+    numpy's, so this is a float64 TOLERANCE anchor for full-size batches, never the fp32 bit anchor."""
+    ids = np.asarray(ids).astype(np.int64)
+    uniq, inv = np.unique(ids, return_inverse=True)
+    out = np.zeros((len(uniq), rows.shape[1]), dtype=dt)
+    np.add.at(out, inv, np.asarray(rows, dtype=dt))
+    return uniq, out
+
+
 def scatter_add_dense(nrows, ids, rows, dt=np.float64):
     """g_table[ids[b],:] += rows[b,:] (np.add.at) — dense view of the same sum."""
     g = np.zeros((nrows, rows.shape[1]), dtype=dt)
@@ -428,13 +438,13 @@ def adam_dense(theta, m, v, g, lr, t, b1=0.9, b2=0.999, eps=1e-7, dt=np.float64)
     return theta, m, v
 
 
-def adam_sparse_tf(theta, m, v, ids, row_grads, lr, t, lazy=False, b1=0.9, b2=0.999, eps=1e-7, dt=np.float64):
+def adam_sparse_tf(theta, m, v, ids, row_grads, lr, t, lazy=False, b1=0.9, b2=0.999, eps=1e-7, dt=np.float64, dedup=None):
     """[TF-sem] Keras Adam `_resource_apply_sparse` after `_deduplicate_indexed_slices`:
     duplicates summed FIRST (so v gets (sum g)^2), then m,v decayed over the WHOLE table and
     the WHOLE table updated (non-lazy).  lazy=True touches only the gathered rows
     (documented throughput deviation, not the reference's semantics)."""
     theta, m, v = theta.astype(dt).copy(), m.astype(dt).copy(), v.astype(dt).copy()
-    uniq, gs = dedup_rows_sequential(ids, row_grads, dt=dt)
+    uniq, gs = (dedup or dedup_rows_sequential)(ids, row_grads, dt=dt)
     if lazy:
         theta[uniq], m[uniq], v[uniq] = adam_dense(theta[uniq], m[uniq], v[uniq], gs, lr, t, b1, b2, eps, dt)
         return theta, m, v
@@ -515,6 +525,42 @@ def inbatch_softmax_loss(q, c, cand_ids):
     P = ex / den
     dS = P - np.eye(len(ids), dtype=dt)
     return loss, dS @ c, dS.T @ q
+
+
+def inbatch_softmax_stripe(q, c, q_ids, c_ids, diag_offset, chunk=8192):
+    """The data-parallel form of inbatch_softmax_loss: a stripe of Bq queries against Bc (all-gathered)
+    candidates; query i's positive is candidate i + diag_offset (columns outside [0, Bc) have no positive in this stripe),
+    accidental hits = same id, not the positive.  Column chunks, so Bq x Bc is never held.  Returns (loss over the
+    stripe's rows, row lse, dq (Bq, d), dc contribution of these queries to every candidate (Bc, d))."""
+    dt = q.dtype
+    Bq, Bc = q.shape[0], c.shape[0]
+    qi, ci = np.asarray(q_ids), np.asarray(c_ids)
+    pos = np.arange(Bq) + diag_offset
+
+    def tile(c0, c1):
+        S = q @ c[c0:c1].T
+        hit = (qi[:, None] == ci[None, c0:c1]) & (pos[:, None] != np.arange(c0, c1)[None, :])
+        return (S + hit.astype(dt) * MIN_FLOAT).astype(dt)
+
+    mx = np.full(Bq, -np.inf, dt)
+    for c0 in range(0, Bc, chunk):
+        mx = np.maximum(mx, tile(c0, min(Bc, c0 + chunk)).max(axis=1))
+    den = np.zeros(Bq, dt)
+    for c0 in range(0, Bc, chunk):
+        den += np.exp(tile(c0, min(Bc, c0 + chunk)) - mx[:, None]).sum(axis=1)
+    lse = mx + np.log(den)
+    has = (pos >= 0) & (pos < Bc)
+    sdiag = np.einsum("ij,ij->i", q[has], c[pos[has]])
+    loss = lse[has].sum() - sdiag.sum()
+    dq, dc = np.zeros_like(q), np.zeros_like(c)
+    for c0 in range(0, Bc, chunk):
+        c1 = min(Bc, c0 + chunk)
+        P = np.exp(tile(c0, c1) - lse[:, None])
+        inr = has & (pos >= c0) & (pos < c1)
+        P[np.nonzero(inr)[0], pos[inr] - c0] -= 1.0
+        dq += P @ c[c0:c1]
+        dc[c0:c1] = P.T @ q
+    return loss, lse, dq, dc
 
 
 def twotower_step_grads(p, users, items, labels=None, rd_zero=False, dt=np.float64):

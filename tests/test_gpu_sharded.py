@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, variant, dim, optimizer, impl, q):
+def _worker(rank, world, port, variant, dim, optimizer, impl, q, idt=torch.int32):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -41,7 +41,7 @@ def _worker(rank, world, port, variant, dim, optimizer, impl, q):
         cfg = neumf.NeuMFConfig(variant=variant, dim=dim, optimizer=optimizer, seed=777, dense_impl=impl)
         Sharded = par.make_sharded_engine(neumf.NeuMFEngine)
         full = {k: torch.from_numpy(p[k]) for k in neumf.TABLES}
-        eng = Sharded(cfg, U, I, dev, Bl, ctx, full_tables=full)
+        eng = Sharded(cfg, U, I, dev, Bl, ctx, full_tables=full, id_dtype=idt)
         for k in neumf.DENSE_ORDER:
             eng.theta.view(k).copy_(torch.from_numpy(p[k]).reshape(eng.theta.view(k).shape))
         rng = np.random.default_rng(9)
@@ -55,7 +55,7 @@ def _worker(rank, world, port, variant, dim, optimizer, impl, q):
             u = rng.integers(0, U, B); i = rng.integers(0, I, B); u[:30] = 4
             y = (rng.random(B) < 0.25).astype(np.float32)
             sl = slice(rank * Bl, (rank + 1) * Bl)
-            eng.train_step(td(u[sl], torch.int32), td(i[sl], torch.int32), td(y[sl], torch.float32), row0=rank * Bl, batch_total=B)
+            eng.train_step(td(u[sl], idt), td(i[sl], idt), td(y[sl], torch.float32), row0=rank * Bl, batch_total=B)
             masks = [O.dropout_mask(cfg.seed, t, s, B, w, cfg.dropout) for s, w in enumerate((2 * dim, spec.hidden[0], spec.hidden[1]))]
             loss, c, g, rg, ns = O.neumf_step_grads(spec, P, u, i, y, masks, dt=np.float64)
             if t == 1:
@@ -91,12 +91,14 @@ def _worker(rank, world, port, variant, dim, optimizer, impl, q):
             pass
 
 
-@pytest.mark.parametrize("variant,dim,optimizer,impl", [("A", 64, "adam_dense", "deferred"), ("A", 64, "adam_dense", "sweep"), ("B", 32, "adam_lazy", "sweep")])
-def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer, impl):
+@pytest.mark.parametrize("variant,dim,optimizer,impl,idt", [("A", 64, "adam_dense", "deferred", torch.int32), ("A", 64, "adam_dense", "sweep", torch.int32),
+                                                            ("B", 32, "adam_lazy", "sweep", torch.int32),
+                                                            ("A", 128, "adam_dense", "deferred", torch.int64)])     # config 5: dim 128 (K = 256 first layer), int64 ids
+def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer, impl, idt):
     world, port = 2, _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, variant, dim, optimizer, impl, q)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, variant, dim, optimizer, impl, q, idt)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
