@@ -1,0 +1,490 @@
+// T1-T4 forward of one tower layer on fp32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 fma chains, the only MFMA
+// form inside the 1e-5 logit/loss tolerance; 157 TFLOP/s peak on MI355X) + the dropout keep-bit planes.
+//
+// dense_fwd_kernel: ONE 1024-thread workgroup per CU = 16 waves = 4 per SIMD, <= 128 VGPRs.
+//   * The layer's W is staged once per workgroup into LDS, pre-swizzled [j][g][n][s] so that a lane's four k-steps of
+//     one n-tile are one conflict-free ds_read_b128.
+//   * Every wave is then independent: it owns 16-row tiles, loads the A fragments straight from global memory in the
+//     MFMA lane layout (lane (c16,g) <- 16 B of row c16 at k = 16j+4g; K is contracted in that lane-permuted order),
+//     applies BatchNorm-affine and the dropout keep bits in registers (v_bfe_i32 + v_and per element; the 1/(1-p)
+//     scale is folded into the epilogue's fma with the bias), and runs the n-tiles in passes of 4 independent
+//     accumulator chains.  Each finished 16x16 output tile is transposed through a 1.3-KB per-wave LDS patch so that it
+//     leaves as ONE 16-B store per lane (7 stores per 16 x 100 tile instead of 28 dword stores: the store tail is
+//     issue-bound, MI355X guide T21).
+//   * STATIC PRIORITIES: the 4 waves that share a SIMD (w, w+4, w+8, w+12) run at s_setprio 3, 2, 1, 0.  At equal priority
+//     they take turns on the matrix pipe, reach the end of a pass together and then execute the (cold, VALU-paced)
+//     epilogue code together with the pipe idle: in-kernel stamps showed 7.7 K MFMA cycles inside 50 K wave cycles.  With
+//     distinct priorities the leader runs its MFMA passes at full rate and the next wave takes the pipe over whenever the
+//     leader is in loads / VALU / stores; the followers also find the leader's code in the instruction cache.
+//   * Column statistics (BatchNorm sums of y, y^2): per-wave partials in LDS, summed over the waves in double, then one
+//     double atomic per column and workgroup into BR_STAT_REPLICAS replicas.
+// keep_bits_kernel: the Philox4x32-10 masks of csrc/philox.h materialised ONCE per (step, site) as bit planes
+//   (uint32 [rows][ceil(K/32)]: 2.3 MB for the three sites of the NeuMF tower at batch 65 536) instead of being
+//   regenerated inside the forward, the dx and the dW kernel of each layer (~120 VALU per 8 elements, three times).
+#include "common.h"
+#include "philox.h"
+
+namespace br {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kFwdThreads = 1024;
+constexpr int kFwdWaves = kFwdThreads / 64;
+constexpr int kRep = BR_STAT_REPLICAS;
+
+// In-kernel stamps of the diagnostic build (tools/diag/: this file compiled with -DBR_STAMPS into a test binary of its
+// own; MI355X guide "In-kernel stamps").  No stamp exists in the product build.
+#ifdef BR_STAMPS
+constexpr int kStampSlots = 12;
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define BR_STAMP_DECL unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define BR_STAMP(i)                                                                             \
+  do {                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    unsigned long long t_;                                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+    if (stamps_[i] == 0) stamps_[i] = t_;                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+#define BR_STAMP_RT(i)                                                                          \
+  do {                                                                                          \
+    unsigned long long t_;                                                                      \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    stamps_[i] = t_;                                                                            \
+  } while (0)
+#define BR_STAMP_FLUSH(widx)                                                                    \
+  do {                                                                                          \
+    if ((threadIdx.x & 63) == 0 && g_stamp_buf)                                                 \
+      for (int i_ = 0; i_ < kStampSlots; ++i_) g_stamp_buf[(size_t)(widx) * kStampSlots + i_] = stamps_[i_]; \
+  } while (0)
+#else
+#define BR_STAMP_DECL
+#define BR_STAMP(i)
+#define BR_STAMP_RT(i)
+#define BR_STAMP_FLUSH(widx)
+#endif
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------ keep-bit planes
+struct KeepSite { uint32_t* out; int K, kw; uint32_t site; };
+struct KeepArgs {
+  KeepSite s[3];
+  int n_sites;
+  DropoutCfg drop;      // key, step (or step_ptr), threshold
+  int64_t row0, batch;
+};
+
+// one thread per (row, 32-column word): its 4 Philox calls (one per 8-column chunk) run INTERLEAVED, round by round - a
+// Philox round is two dependent 32x32->64 multiplies (v_mad_u64_u32, quarter rate), so four independent chains per lane
+// are what keeps the multiplier busy (one chain at a time behind per-chunk branches measured 9.6 us for the 128-column
+// plane of 65 536 rows) - then one coalesced store.  Chunks past K produce bits that nobody reads.
+__global__ __launch_bounds__(256) void keep_bits_kernel(KeepArgs a) {
+  dropout_resolve(a.drop);
+  const KeepSite s = blockIdx.y == 0 ? a.s[0] : (blockIdx.y == 1 ? a.s[1] : a.s[2]);    // (a runtime index would copy the struct to scratch)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.batch * s.kw) return;
+  const int64_t r = idx / s.kw;
+  const uint32_t w = (uint32_t)(idx - r * s.kw);
+  uint32_t c0[4], c1[4], c2[4], c3[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { c0[c] = (uint32_t)(a.row0 + r); c1[c] = 4 * w + c; c2[c] = s.site; c3[c] = a.drop.step; }
+  uint32_t k0 = a.drop.k0, k1 = a.drop.k1;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint64_t p0 = (uint64_t)0xD2511F53u * c0[c], p1 = (uint64_t)0xCD9E8D57u * c2[c];
+      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1[c] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3[c] ^ k1;
+      c0[c] = n0; c1[c] = (uint32_t)p1; c2[c] = n2; c3[c] = (uint32_t)p0;
+    }
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const uint32_t thr = a.drop.thr;
+  uint32_t word = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t d[4] = {c0[c], c1[c], c2[c], c3[c]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      word |= ((d[e] & 0xFFFFu) >= thr ? 1u : 0u) << (8 * c + 2 * e);
+      word |= ((d[e] >> 16) >= thr ? 1u : 0u) << (8 * c + 2 * e + 1);
+    }
+  }
+  s.out[idx] = word;
+}
+
+// ------------------------------------------------------------------------------------ forward
+struct FwdArgs {
+  const float* x; int64_t ldx;
+  const float* W; const float* bias;
+  float* y; int64_t ldy;
+  int64_t batch;
+  int K, N, act;
+  const float* scale; const float* shift;   // (K) BatchNorm affine of the producer, or null
+  const uint32_t* keep; int kw;             // keep-bit plane [batch][kw] of this layer's input dropout, or null
+  float inv_keep;                           // 1/(1-p) (1 without dropout)
+  double* stats;                            // [kRep][2N] or null
+  const float* yin;                         // split-K: the other K-half's partial sums (same element of y), or null
+};
+
+// x & (bit `pos` of w ? ~0 : 0): v_bfe_i32 + v_and_b32
+__device__ __forceinline__ float keep_if(float x, uint32_t w, uint32_t pos) {
+  const int m = __builtin_amdgcn_sbfe((int)w, pos, 1u);
+  return __int_as_float(__float_as_int(x) & m);
+}
+
+// Activation, branch-free and without copies of the epilogue (the instruction footprint matters: every wave runs this code
+// once, cold): both candidates are formed and blended with a bit mask (v_bfi_b32) -
+//   sigmoid: 1/(1+2^(-z log2 e)) = v_mul, v_exp_f32, v_add, v_rcp_f32 (z -> -inf gives rcp(inf) = 0, z -> +inf gives 1;
+//            |rel err| < 4e-7: hardware exp2 / rcp are ~1 ulp each, inside the 1e-5 budget, tests/test_gpu_neumf.py);
+//   relu / linear: max(z, floor) with floor = 0 / -inf.
+// (`cond ? act(z) : 0` in C makes hipcc build an exec-masked branch around every element's exp/rcp.)
+__device__ __forceinline__ float act_fwd(float z, int sigmask, float floor_) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f));
+  const float m = fmaxf(z, floor_);
+  return __int_as_float((__float_as_int(s) & sigmask) | (__float_as_int(m) & ~sigmask));
+}
+
+// A fragments + keep words of one tile.  ONE base pointer per lane (row clamped into the batch) and compile-time byte
+// offsets; only the last 16-column block can reach past K (KJ = ceil(K/16)) and is loaded from a clamped column.
+// Nothing is zeroed here: columns >= K meet zero rows of the W image (and a zero BN affine), rows >= batch are
+// never stored or counted by the epilogue.  VEC: 16-B loads and stores (launch_fwd).
+template <int KJ, bool VEC>
+__device__ __forceinline__ void fwd_load_tile(float4 (&av)[KJ], uint32_t (&kb)[(KJ + 1) / 2], const FwdArgs& a, int64_t tile, int c16, int g) {
+  int64_t arow = (tile << 4) + c16;
+  arow = arow < a.batch ? arow : a.batch - 1;
+  const float* p = a.x + arow * a.ldx + 4 * g;
+  const int klast = 16 * (KJ - 1) + 4 * g;
+  if (VEC) {
+#pragma unroll
+    for (int j = 0; j < KJ - 1; ++j) av[j] = *reinterpret_cast<const float4*>(p + 16 * j);
+    av[KJ - 1] = *reinterpret_cast<const float4*>(klast < a.K ? p + 16 * (KJ - 1) : p - 4 * g);
+    if (a.K & 3) {         // wave-uniform: the last 16-B group may straddle K (padded rows): what it read past K must not be NaN
+      if (klast + 1 >= a.K) av[KJ - 1].y = 0.f;
+      if (klast + 2 >= a.K) av[KJ - 1].z = 0.f;
+      if (klast + 3 >= a.K) av[KJ - 1].w = 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KJ - 1; ++j) av[j] = make_float4(p[16 * j], p[16 * j + 1], p[16 * j + 2], p[16 * j + 3]);
+    const float* q = p - 4 * g;     // row start
+    const int K1 = a.K - 1;
+    av[KJ - 1] = make_float4(q[klast < K1 ? klast : K1], q[klast + 1 < K1 ? klast + 1 : K1], q[klast + 2 < K1 ? klast + 2 : K1], q[klast + 3 < K1 ? klast + 3 : K1]);
+  }
+  if (a.keep) {
+    const uint32_t* kr = a.keep + arow * a.kw;      // kw == (KJ + 1) / 2 words per row
+#pragma unroll
+    for (int w = 0; w < (KJ + 1) / 2; ++w) kb[w] = kr[w];
+  }
+}
+
+constexpr int kPatchLd = 20;      // floats per row of the per-wave 16x16 transposition patch: 16-B aligned rows, conflict-free dword writes
+
+// epilogue of one n-tile.  In: lane (c16, g) holds rows 4g..4g+3 of column nt*16+c16 (MFMA C layout).  bias + 1/(1-p) +
+// activation + column sums in that layout (elements outside the batch / past N are ANDed to 0), then through the wave's LDS
+// patch into row layout: lane (c16, g) <- columns nt*16+4g..+3 of row c16, one 16-B store.  vmask[r]: ~0 where row 4g+r is
+// inside the batch.
+template <bool VEC>
+__device__ __forceinline__ void fwd_epilogue(const f32x4& acc, const FwdArgs& a, float* patch, float* yrow, int64_t rbase, int nt, int c16, int g,
+                                             const int (&vmask)[4], bool row_ok, float bv, int sigmask, float floor_, float& ssum, float& ssq) {
+  const int n = nt * 16 + c16;
+  const bool last = nt * 16 + 16 > a.N;                    // only the last n-tile can be ragged (wave-uniform)
+  const int cmask = (!last || n < a.N) ? -1 : 0;
+  float yv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.yin) {                                             // wave-uniform: split-K second half (K > 128)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yv[r] = a.yin[(rbase + (vmask[r] ? 4 * g + r : 0)) * a.ldy + (cmask ? n : 0)];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float z = fmaf(acc[r], a.inv_keep, bv) + yv[r];
+    const float v = __int_as_float(__float_as_int(act_fwd(z, sigmask, floor_)) & vmask[r] & cmask);
+    ssum += v;
+    ssq = fmaf(v, v, ssq);
+    patch[(4 * g + r) * kPatchLd + c16] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float4 o = *reinterpret_cast<const float4*>(patch + c16 * kPatchLd + 4 * g);
+  __builtin_amdgcn_wave_barrier();
+  float* dst = yrow + nt * 16;                              // &y[rbase + c16][nt*16 + 4g]
+  const int n0 = nt * 16 + 4 * g;
+  if (VEC) {                                                // rows are padded to 4 floats: a group that starts inside N is stored whole
+    if (row_ok && (!last || n0 < a.N)) *reinterpret_cast<float4*>(dst) = o;
+  } else if (row_ok) {
+    if (n0 + 0 < a.N) dst[0] = o.x;
+    if (n0 + 1 < a.N) dst[1] = o.y;
+    if (n0 + 2 < a.N) dst[2] = o.z;
+    if (n0 + 3 < a.N) dst[3] = o.w;
+  }
+}
+
+template <int NT, int KJ, bool VEC>
+__global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int Np = NT * 16, Kp = KJ * 16, KWJ = (KJ + 1) / 2;
+  float* Ws = smem;                                     // [KJ][4][Np][4]
+  float* ssb = Ws + Kp * Np;                            // [scale Kp | shift Kp]
+  float* bs = ssb + 2 * Kp;                             // [bias Np]
+  float* patches = bs + Np;                             // [waves][16][kPatchLd]
+  float* redw = patches + kFwdWaves * 16 * kPatchLd;    // [waves][2][Np] per-wave column sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int K = a.K, N = a.N;
+  const int64_t batch = a.batch;
+  const int64_t n_tiles = (batch + 15) >> 4;
+  const int64_t tstride = (int64_t)gridDim.x * kFwdWaves;
+  {   // static priority per SIMD slot (waves w, w+4, w+8, w+12 share a SIMD): see the file header
+    const int slot = __builtin_amdgcn_readfirstlane(wave >> 2);
+    if (slot == 0) __builtin_amdgcn_s_setprio(3);
+    else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+    else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+  }
+
+  BR_STAMP_DECL;
+  BR_STAMP_RT(10);
+  BR_STAMP(0);
+  float4 av[KJ];
+  uint32_t kb[KWJ];
+  int64_t tile = (int64_t)blockIdx.x * kFwdWaves + wave;
+  fwd_load_tile<KJ, VEC>(av, kb, a, tile, c16, g);      // the first tile's loads fly while W is staged (row clamped)
+  BR_STAMP(1);
+
+  // W image: thread -> (j, g, n): 4 coalesced loads (k = 16j+4g+s) -> one conflict-free ds_write_b128.  All loads of the
+  // image are issued before the first LDS write (compile-time trip count, clamped addresses).
+  {
+    constexpr int TOT = KJ * 4 * Np, TR = (TOT + kFwdThreads - 1) / kFwdThreads;
+    float wv[TR][4];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kFwdThreads;
+      const int idc = idx < TOT ? idx : 0;
+      const int jg = idc / Np, n = idc - jg * Np;
+      const int k0 = 4 * jg;
+      const int nc = n < N ? n : N - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[i][q] = a.W[(k0 + q < K ? k0 + q : K - 1) * N + nc];
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kFwdThreads;
+      const int jg = idx / Np, n = idx - jg * Np;
+      const int k0 = 4 * jg;
+      const bool nin = n < N;
+      if (idx < TOT)
+        *reinterpret_cast<float4*>(Ws + idx * 4) = make_float4((nin && k0 + 0 < K) ? wv[i][0] : 0.f, (nin && k0 + 1 < K) ? wv[i][1] : 0.f,
+                                                                (nin && k0 + 2 < K) ? wv[i][2] : 0.f, (nin && k0 + 3 < K) ? wv[i][3] : 0.f);
+    }
+  }
+  for (int k = threadIdx.x; k < Kp; k += kFwdThreads) {     // identity where there is no BatchNorm, zero past K
+    ssb[k] = k < K ? (a.scale ? a.scale[k] : 1.f) : 0.f;
+    ssb[Kp + k] = (a.scale && k < K) ? a.shift[k] : 0.f;
+  }
+  for (int n = threadIdx.x; n < Np; n += kFwdThreads) bs[n] = (a.bias && n < N) ? a.bias[n] : 0.f;
+  BR_STAMP(2);
+  __syncthreads();
+  BR_STAMP(3);
+
+  float* patch = patches + wave * 16 * kPatchLd;
+  float ssum[NT], ssq[NT];             // this lane's column sums of y, y^2 (column nt*16+c16, its 4 rows of every tile)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
+  const int sigmask = a.act == BR_ACT_SIGMOID ? -1 : 0;
+  const float floor_ = a.act == BR_ACT_RELU ? 0.f : -__builtin_inff();
+
+  while (tile < n_tiles) {
+    const int64_t rbase = tile << 4;
+    // ---- T(): BN affine + dropout keep bits, in registers (fenced per 16-column block: left alone the compiler hoists every
+    //      block's scale / shift reads and spills) ----
+    const bool affine = a.scale || 16 * KJ != K;      // the affine also zeroes the columns >= K of the last block
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      if (affine) {
+        const int k = 16 * j + 4 * g;
+        const float4 sc = *reinterpret_cast<const float4*>(ssb + k), sh = *reinterpret_cast<const float4*>(ssb + Kp + k);
+        av[j].x = av[j].x * sc.x + sh.x; av[j].y = av[j].y * sc.y + sh.y; av[j].z = av[j].z * sc.z + sh.z; av[j].w = av[j].w * sc.w + sh.w;
+      }
+      if (a.keep) {
+        const uint32_t w = kb[j >> 1], p0 = 16u * (j & 1) + 4u * g;
+        av[j].x = keep_if(av[j].x, w, p0); av[j].y = keep_if(av[j].y, w, p0 + 1);
+        av[j].z = keep_if(av[j].z, w, p0 + 2); av[j].w = keep_if(av[j].w, w, p0 + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    BR_STAMP(4);       // first tile: operands transformed (includes the wait for the A loads)
+    const int64_t left = batch - rbase;
+    const int rows_left16 = left > 16 ? 16 : (int)left;               // rows of this tile inside the batch
+    int vmask[4];                                                     // ~0 where C-layout row 4g+r is inside the batch
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vmask[r] = (4 * g + r < rows_left16) ? -1 : 0;
+    const bool row_ok = c16 < rows_left16;
+    float* yrow = a.y + (rbase + (row_ok ? c16 : 0)) * a.ldy + 4 * g;      // row layout: &y[rbase + c16][4g]
+    // ---- MFMA in passes of <= 4 n-tiles: 4 independent accumulator chains, each revisited every 4th MFMA ----
+#pragma unroll
+    for (int nt0 = 0; nt0 < NT; nt0 += 4) {
+      constexpr int WMAX = 4;
+      const int Wn = (NT - nt0) < WMAX ? (NT - nt0) : WMAX;     // compile-time after unrolling
+      f32x4 acc[WMAX];
+#pragma unroll
+      for (int w = 0; w < WMAX; ++w) acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // One k-block at a time: 4 B fragments (ds_read_b128), then their 16 MFMAs.  No double buffer: while this wave waits for
+      // its fragments the lower-priority waves of the SIMD own the matrix pipe, and 16 more VGPRs of fragments do not fit the
+      // 128-VGPR budget.  The fence keeps hipcc from hoisting every block's reads to the top of the pass (~200 spills).
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        float4 bc[WMAX];
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w)
+          if (w < Wn) bc[w] = *reinterpret_cast<const float4*>(Ws + ((j * 4 + g) * Np + c16) * 4 + (nt0 + w) * 64);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].x, bc[w].x, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].y, bc[w].y, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].z, bc[w].z, acc[w]);
+#pragma unroll
+        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].w, bc[w].w, acc[w]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      BR_STAMP(5 + 2 * (nt0 / 4));       // pass MFMAs issued
+#pragma unroll
+      for (int w = 0; w < WMAX; ++w) {
+        if (w < Wn) {
+          const float bv = bs[(nt0 + w) * 16 + c16];
+          fwd_epilogue<VEC>(acc[w], a, patch, yrow, rbase, nt0 + w, c16, g, vmask, row_ok, bv, sigmask, floor_, ssum[nt0 + w], ssq[nt0 + w]);
+          __builtin_amdgcn_sched_barrier(0);      // one n-tile at a time: interleaved, the four epilogues' temporaries spill
+        }
+      }
+      BR_STAMP(6 + 2 * (nt0 / 4));       // pass epilogue issued
+    }
+    tile += tstride;
+    if (tile < n_tiles) fwd_load_tile<KJ, VEC>(av, kb, a, tile, c16, g);
+  }
+
+  if (a.stats) {      // lane -> wave (the 4 row groups) -> per-wave LDS partials -> workgroup sum in double -> one global atomic per column
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float sv = ssum[nt], q = ssq[nt];
+      sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (g == 0) { redw[wave * 2 * Np + nt * 16 + c16] = sv; redw[wave * 2 * Np + Np + nt * 16 + c16] = q; }
+    }
+    __syncthreads();
+    double* rep = a.stats + (size_t)(blockIdx.x % kRep) * 2 * N;
+    for (int t = threadIdx.x; t < 2 * Np; t += kFwdThreads) {
+      const int half = t >= Np, n = t - half * Np;
+      if (n < N) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < kFwdWaves; ++w) acc += (double)redw[w * 2 * Np + t];
+        atomicAdd(rep + half * N + n, acc);
+      }
+    }
+  }
+  BR_STAMP(9);
+  BR_STAMP_RT(11);
+  BR_STAMP_FLUSH(blockIdx.x * kFwdWaves + wave);
+}
+
+}  // namespace br
+
+using namespace br;
+
+static inline int tiles16(int v) { return (v + 15) / 16; }
+constexpr int kMaxT = 8;         // max 16-wide tiles along K or N (=> K,N <= 128 per launch)
+
+extern "C" int64_t brDropoutKeepWords(int64_t batch, int K) { return (batch > 0 ? batch : 0) * (int64_t)((K + 31) / 32); }
+
+extern "C" int brDropoutKeepBits(float drop_p, uint64_t seed, uint32_t step, int64_t row0, int64_t batch, int n_sites, const uint32_t* sites,
+                                 const int* widths, uint32_t* const* out, brStream stream) {
+  BR_CHECK_ARG(n_sites >= 1 && n_sites <= 3 && sites && widths && out && batch >= 0, "brDropoutKeepBits: bad args (1..3 sites)");
+  BR_CHECK_ARG(drop_p > 0.f && drop_p < 1.f, "brDropoutKeepBits: drop_p must be in (0,1)");
+  if (batch == 0) return BR_OK;
+  KeepArgs a;
+  a.n_sites = n_sites;
+  int kwmax = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int j = i < n_sites ? i : 0;
+    BR_CHECK_ARG(widths[j] >= 1 && out[j], "brDropoutKeepBits: bad site %d", j);
+    a.s[i].out = out[j]; a.s[i].K = widths[j]; a.s[i].kw = (widths[j] + 31) / 32; a.s[i].site = sites[j];
+    if (a.s[i].kw > kwmax) kwmax = a.s[i].kw;
+  }
+  a.drop = make_dropout(drop_p, seed, step, 0);
+  if (const StepStateDev* ss = current_step_state()) a.drop.step_ptr = &ss->step;
+  a.row0 = row0; a.batch = batch;
+  const dim3 grid((unsigned)ceil_div(batch * kwmax, 256), (unsigned)n_sites);
+  keep_bits_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  BR_CHECK_LAUNCH("brDropoutKeepBits");
+  return BR_OK;
+}
+
+template <int NT, int KJ, bool VEC>
+static void launch_fwd_v(unsigned grid, size_t shmem, hipStream_t s, const FwdArgs& a) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    attr_set = true;
+  }
+  dense_fwd_kernel<NT, KJ, VEC><<<grid, kFwdThreads, shmem, s>>>(a);
+}
+template <int NT, int KJ>
+static void launch_fwd(unsigned grid, size_t shmem, hipStream_t s, const FwdArgs& a) {
+  // VEC: 16-B accesses on both sides: x rows / y rows 16-B aligned with row strides that are multiples of 4 floats (rows of K
+  // or N floats are then padded to 4, and a 16-B access that starts inside a row stays inside its allocation)
+  const bool vec = (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
+                   (a.yin == nullptr || a.K % 4 == 0);
+  if (vec) launch_fwd_v<NT, KJ, true>(grid, shmem, s, a);
+  else launch_fwd_v<NT, KJ, false>(grid, shmem, s, a);
+}
+
+static int dense_forward_one(FwdArgs a, hipStream_t s) {
+  const int NT = tiles16(a.N), KJ = tiles16(a.K), Kp = KJ * 16, Np = NT * 16;
+  const size_t shmem = ((size_t)Kp * Np + 2 * (size_t)Kp + (size_t)Np + (size_t)kFwdWaves * 16 * kPatchLd + (size_t)kFwdWaves * 2 * Np) * sizeof(float);
+  int64_t wgs = ceil_div(ceil_div(a.batch, 16), kFwdWaves);
+  const unsigned grid = (unsigned)(wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs));      // one workgroup per CU
+#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(grid, shmem, s, a); break;
+#define BR_FWD(NTv)                                                                                        \
+  case NTv:                                                                                                \
+    switch (KJ) { BR_FWD_KJ(NTv, 1) BR_FWD_KJ(NTv, 2) BR_FWD_KJ(NTv, 3) BR_FWD_KJ(NTv, 4) BR_FWD_KJ(NTv, 5) \
+                  BR_FWD_KJ(NTv, 6) BR_FWD_KJ(NTv, 7) BR_FWD_KJ(NTv, 8) default: break; }                  \
+    break;
+  switch (NT) {
+    BR_FWD(1) BR_FWD(2) BR_FWD(3) BR_FWD(4) BR_FWD(5) BR_FWD(6) BR_FWD(7) BR_FWD(8)
+    default: br::set_error("brDenseForward: unsupported N"); return BR_ERR_UNSUPPORTED;
+  }
+  BR_CHECK_LAUNCH("brDenseForward");
+  return BR_OK;
+}
+
+// K > 128 (config 5: 2 x embed_dim 128 = 256 inputs) runs as two K-halves: the first launch leaves the raw partial
+// sums in y, the second adds them in its epilogue (bias, activation, BatchNorm column sums only there).  The split
+// point is a multiple of 32 so that each half starts on a word of the keep-bit plane.
+static inline int split_k(int K) { return ((K / 2 + 31) / 32) * 32; }
+
+extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
+                              int64_t batch, int K, int N, int act, const float* in_scale, const float* in_shift,
+                              float drop_p, const uint32_t* keep, double* stats, brStream stream) {
+  BR_CHECK_ARG(x && W && y && batch >= 0 && K >= 1 && N >= 1, "brDenseForward: bad args");
+  BR_CHECK_ARG(K <= 2 * kMaxT * 16 && N <= kMaxT * 16, "brDenseForward: K=%d N=%d exceed %d / %d", K, N, 2 * kMaxT * 16, kMaxT * 16);
+  BR_CHECK_ARG(ldx >= K && ldy >= N, "brDenseForward: bad leading dims");
+  BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
+  BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
+  BR_CHECK_ARG((drop_p > 0.f) == (keep != nullptr), "brDenseForward: keep bits (brDropoutKeepBits) are required exactly when drop_p > 0");
+  if (batch == 0) return BR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int kw = (K + 31) / 32;
+  FwdArgs a{x, ldx, W, bias, y, ldy, batch, K, N, act, in_scale, in_shift, keep, kw, drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, stats, nullptr};
+  if (K <= kMaxT * 16) return dense_forward_one(a, s);
+  const int Ka = split_k(K);
+  FwdArgs h = a;
+  h.K = Ka; h.bias = nullptr; h.act = BR_ACT_LINEAR; h.stats = nullptr;
+  int rc = dense_forward_one(h, s);
+  if (rc != BR_OK) return rc;
+  h = a;
+  h.x = x + Ka; h.W = W + (int64_t)Ka * N; h.K = K - Ka; h.yin = y;
+  if (in_scale) { h.scale = in_scale + Ka; h.shift = in_shift + Ka; }
+  if (keep) h.keep = keep + Ka / 32;        // same row stride kw, first word of the second half
+  return dense_forward_one(h, s);
+}

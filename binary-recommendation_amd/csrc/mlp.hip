@@ -24,7 +24,7 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "philox.h"
+#include "dense.h"
 
 namespace br {
 
@@ -42,9 +42,15 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 struct InXform {       // T(x): BatchNorm affine of the producer + dropout, applied on load
   const float* scale;  // (K) or null (global; the kernels stage scale|shift into LDS once)
   const float* shift;  // (K) or null
-  DropoutCfg drop;
-  uint32_t c8off;      // first 8-column dropout chunk of this launch (split-K: the second half of a K > 128 layer)
+  const uint8_t* keep; // keep-bit plane of the input dropout (brDropoutKeepBits) viewed as bytes: byte c8 of a row = its 8-column
+                       // chunk c8 (already offset to this launch's first column for the second half of a K > 128 layer), or null
+  int64_t keep_ld;     // bytes per row of the plane
+  float inv_keep;      // 1/(1-p)
 };
+// keep bits of the 8-column chunk c8 of row r (0xFF without dropout)
+__device__ __forceinline__ uint32_t keep8(const InXform& t, int64_t r, int c8) {
+  return t.keep ? (uint32_t)t.keep[r * t.keep_ld + c8] : 0xFFu;
+}
 
 // Branch-free guarded loads.  Every load below is issued UNCONDITIONALLY from an address clamped
 // into the buffer and the out-of-range lanes are zeroed with selects: an `if (in range) load` makes
@@ -90,10 +96,10 @@ __device__ __forceinline__ uint32_t xform8(float (&v)[8], const InXform& t, cons
     v[4] = v[4] * s1.x + h1.x; v[5] = v[5] * s1.y + h1.y; v[6] = v[6] * s1.z + h1.z; v[7] = v[7] * s1.w + h1.w;
   }
   uint32_t bits = 0xFFu;
-  if (t.drop.thr) {
-    bits = dropout_keep8(t.drop, grow, (uint32_t)(c >> 3) + t.c8off);
+  if (t.keep) {
+    bits = keep8(t, grow, c >> 3);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = ((bits >> i) & 1u) ? v[i] * t.drop.inv_keep : 0.f;
+    for (int i = 0; i < 8; ++i) v[i] = ((bits >> i) & 1u) ? v[i] * t.inv_keep : 0.f;
   }
   return bits;
 }
@@ -101,195 +107,6 @@ __device__ __forceinline__ uint32_t xform8(float (&v)[8], const InXform& t, cons
 __device__ __forceinline__ void store8_lds(float* dst, const float (&v)[8]) {
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-
-// ------------------------------------------------------------------------------------ forward
-// Every wave is independent (no barrier after the W image is staged): it walks its own 16-row tiles,
-// loads the A fragments STRAIGHT from global memory in the MFMA lane layout (lane (c16,g) <- 16 B of
-// row c16 at k = 16j+4g), applies BN-affine + dropout in registers, and contracts against the W image
-// in LDS, stored pre-swizzled [j][g][n][s] so one conflict-free ds_read_b128 yields the four k-steps
-// of a lane.  One wave owns all n-tiles of its rows, so a row's outputs leave as back-to-back 64-B
-// pieces of the same 128-B lines (no partial-line write amplification between waves).
-// Per-wave scratch in LDS: dropout keep-bytes [16 rows][2*KJ] (4 Philox calls per lane per tile).
-template <int NT, int KJ>
-__global__ __launch_bounds__(kThreads, 2) void dense_fwd_kernel(const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
-                                                                 const float* __restrict__ bias, float* y, int64_t ldy,
-                                                                 int64_t batch, int K, int N, int act, InXform tin, int64_t row0,
-                                                                 double* __restrict__ stats, const float* yin) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  dropout_resolve(tin.drop);
-  constexpr int Np = NT * 16, Kp = KJ * 16, NCH = 2 * KJ;
-  float* Ws = smem;                                   // [KJ][4][Np][4]
-  float* ssb = Ws + Kp * Np;                          // [scale Kp | shift Kp]
-  uint8_t* mk_all = reinterpret_cast<uint8_t*>(ssb + 2 * Kp);   // [8 waves][16][NCH]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c16 = lane & 15, g = lane >> 4;
-  uint8_t* mk = mk_all + wave * 16 * NCH;
-  const bool vec_ok = (ldx_g % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  const int64_t n_tiles = (batch + 15) >> 4;
-  const int64_t tstride = (int64_t)gridDim.x * 8;
-
-  // A fragments of one 16-row tile straight from global: lane (c16,g) <- 16 B of row c16 at k = 16j+4g
-  // (tiles past the end read row batch-1 and are zeroed: no branch around the loads)
-  auto load_a = [&](float4 (&a)[KJ], int64_t tile) {
-    const int64_t arow = tile < n_tiles ? (tile << 4) + c16 : batch;
-    if (vec_ok) {
-#pragma unroll
-      for (int j = 0; j < KJ; ++j) a[j] = ld4_guard<true>(x, ldx_g, arow, batch, 16 * j + 4 * g, K);
-    } else {
-#pragma unroll
-      for (int j = 0; j < KJ; ++j) a[j] = ld4_guard<false>(x, ldx_g, arow, batch, 16 * j + 4 * g, K);
-    }
-  };
-
-  int64_t tile = (int64_t)blockIdx.x * 8 + wave;
-  float4 a[KJ], an[KJ];
-  load_a(a, tile);                                    // first tile's loads fly while W is staged
-
-  // W image: thread -> (j, g, n): 4 coalesced loads (k = 16j+4g+s) -> one conflict-free ds_write_b128.
-  // ALL loads of the image are issued before the first LDS write (compile-time trip count, clamped
-  // addresses): a rolled load->write loop costs one L2 round trip per trip (measured: ~6 us of a 32 us launch).
-  {
-    constexpr int TOT = KJ * 4 * Np, TR = (TOT + kThreads - 1) / kThreads;
-    float wv[TR][4];
-#pragma unroll
-    for (int i = 0; i < TR; ++i) {
-      const int idx = threadIdx.x + i * kThreads;
-      const int idc = idx < TOT ? idx : 0;
-      const int jg = idc / Np, n = idc - jg * Np;
-      const int k0 = 4 * jg;
-      const int nc = n < N ? n : N - 1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) wv[i][q] = W[(k0 + q < K ? k0 + q : K - 1) * N + nc];
-    }
-#pragma unroll
-    for (int i = 0; i < TR; ++i) {
-      const int idx = threadIdx.x + i * kThreads;
-      const int jg = idx / Np, n = idx - jg * Np;
-      const int k0 = 4 * jg;
-      const bool nin = n < N;
-      if (idx < TOT)
-        *reinterpret_cast<float4*>(Ws + idx * 4) = make_float4((nin && k0 + 0 < K) ? wv[i][0] : 0.f, (nin && k0 + 1 < K) ? wv[i][1] : 0.f,
-                                                                (nin && k0 + 2 < K) ? wv[i][2] : 0.f, (nin && k0 + 3 < K) ? wv[i][3] : 0.f);
-    }
-  }
-  if (tin.scale)
-    for (int k = threadIdx.x; k < Kp; k += kThreads) {
-      ssb[k] = k < K ? tin.scale[k] : 0.f;
-      ssb[Kp + k] = k < K ? tin.shift[k] : 0.f;
-    }
-  __syncthreads();
-
-  float bcol[NT], ssum[NT], ssq[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + c16;
-    bcol[nt] = (bias && n < N) ? bias[n] : 0.f;
-    ssum[nt] = 0.f; ssq[nt] = 0.f;
-  }
-  for (; tile < n_tiles; tile += tstride) {
-    const int64_t rbase = tile << 4;
-    const int64_t arow = rbase + c16;                  // the row this lane feeds as the A operand
-    load_a(an, tile + tstride);                        // next tile's A in flight during this tile's MFMAs
-    // ---- dropout keep-bytes of the tile: 16 rows x NCH chunks, <= 4 Philox calls per lane ----
-    if (tin.drop.thr) {
-#pragma unroll
-      for (int i = 0; i < (16 * NCH + 63) / 64; ++i) {
-        const int q = lane + 64 * i;
-        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH) + tin.c8off);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    // ---- T(): BN affine + dropout, in registers ----
-#pragma unroll
-    for (int j = 0; j < KJ; ++j) {
-      const int k = 16 * j + 4 * g;
-      if (tin.scale) {
-        const float4 sc = *reinterpret_cast<const float4*>(ssb + k), sh = *reinterpret_cast<const float4*>(ssb + Kp + k);
-        a[j].x = a[j].x * sc.x + sh.x; a[j].y = a[j].y * sc.y + sh.y; a[j].z = a[j].z * sc.z + sh.z; a[j].w = a[j].w * sc.w + sh.w;
-      }
-      if (tin.drop.thr) {
-        const uint32_t bits = (uint32_t)mk[c16 * NCH + (k >> 3)] >> (k & 4);
-        const float ik = tin.drop.inv_keep;
-        a[j].x = (bits & 1u) ? a[j].x * ik : 0.f; a[j].y = (bits & 2u) ? a[j].y * ik : 0.f;
-        a[j].z = (bits & 4u) ? a[j].z * ik : 0.f; a[j].w = (bits & 8u) ? a[j].w * ik : 0.f;
-      }
-      if (arow >= batch) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // ---- MFMA in passes of <= 4 n-tiles: the pass's accumulators are independent chains (s outer,
-    //      n-tile inner => a chain is revisited every >= 3 MFMAs), and the B fragments of k-step j+1
-    //      are read from LDS while step j is in the matrix pipe (explicit double buffer: with the
-    //      128-VGPR budget hipcc otherwise issues read -> wait -> 4 dependent MFMAs) ----
-#pragma unroll
-    for (int nt0 = 0; nt0 < NT; nt0 += 4) {
-      constexpr int WMAX = 4;
-      const int Wn = (NT - nt0) < WMAX ? (NT - nt0) : WMAX;     // compile-time after unrolling
-      f32x4 acc[WMAX];
-      float4 bc[WMAX], bn[WMAX];
-#pragma unroll
-      for (int w = 0; w < WMAX; ++w) {
-        acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (w < Wn) bc[w] = *reinterpret_cast<const float4*>(Ws + ((0 * 4 + g) * Np + c16) * 4 + (nt0 + w) * 64);
-      }
-#pragma unroll
-      for (int j = 0; j < KJ; ++j) {
-        if (j + 1 < KJ) {
-#pragma unroll
-          for (int w = 0; w < WMAX; ++w)
-            if (w < Wn) bn[w] = *reinterpret_cast<const float4*>(Ws + (((j + 1) * 4 + g) * Np + c16) * 4 + (nt0 + w) * 64);
-        }
-#pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].x, bc[w].x, acc[w]);
-#pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].y, bc[w].y, acc[w]);
-#pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].z, bc[w].z, acc[w]);
-#pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(a[j].w, bc[w].w, acc[w]);
-#pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) bc[w] = bn[w];
-      }
-      // epilogue of the pass: lane holds rows 4g..4g+3, column (nt0+w)*16+c16
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gr = rbase + 4 * g + r;
-#pragma unroll
-        for (int w = 0; w < WMAX; ++w) {
-          if (w < Wn) {
-            const int n = (nt0 + w) * 16 + c16;
-            if (gr < batch && n < N) {
-              // yin: the other K-half's partial sums (split-K for K > 128; same element, read before it is written)
-              const float v = act_apply(acc[w][r] + bcol[nt0 + w] + (yin ? yin[gr * ldy + n] : 0.f), act);
-              y[gr * ldy + n] = v;
-              ssum[nt0 + w] += v;
-              ssq[nt0 + w] += v * v;
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < KJ; ++j) a[j] = an[j];
-  }
-  if (stats) {
-    // wave -> workgroup (LDS double atomics) -> one global atomic per column and workgroup
-    __shared__ double red[2][kMaxT * 16];
-    for (int n = threadIdx.x; n < 2 * kMaxT * 16; n += kThreads) (&red[0][0])[n] = 0.0;
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      double sv = (double)ssum[nt], q = (double)ssq[nt];
-      sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (g == 0) { atomicAdd(&red[0][nt * 16 + c16], sv); atomicAdd(&red[1][nt * 16 + c16], q); }
-    }
-    __syncthreads();
-    double* rep = stats + (size_t)(blockIdx.x % kRep) * 2 * N;
-    for (int n = threadIdx.x; n < N; n += kThreads) {
-      atomicAdd(rep + n, red[0][n]);
-      atomicAdd(rep + N + n, red[1][n]);
-    }
-  }
 }
 
 // --------------------------------------------------------------------------------- BN helpers
@@ -363,10 +180,9 @@ template <int NT, int KT, bool IBN>
 __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
                                                                 const float* __restrict__ x, int64_t ldx_g, const float* __restrict__ W,
                                                                 int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
-                                                                int64_t row0, float* __restrict__ gx, int64_t ldgx, float* __restrict__ dzbuf,
+                                                                float* __restrict__ gx, int64_t ldgx, float* __restrict__ dzbuf,
                                                                 double* __restrict__ in_sums) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  dropout_resolve(tin.drop);
   constexpr int Np = NT * 16, Kp = KT * 16, ldw = Np + 4, NCH = 2 * KT;
   float* Ws = smem;                                   // [Kp][ldw] row-major W
   float* Cs = Ws + Kp * ldw;                          // [4][Np] out-BN constants
@@ -472,11 +288,12 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
       for (int j = 0; j < NT; ++j) dz[j] = dzn[j];
       continue;
     }
-    if (tin.drop.thr) {
+    if (tin.keep) {
 #pragma unroll
       for (int i = 0; i < (16 * NCH + 63) / 64; ++i) {
         const int q = lane + 64 * i;
-        if (q < 16 * NCH) mk[q] = (uint8_t)dropout_keep8(tin.drop, row0 + rbase + q / NCH, (uint32_t)(q % NCH) + tin.c8off);
+        const int64_t kr = rbase + q / NCH;
+        if (q < 16 * NCH) mk[q] = (8 * (q % NCH) < K && kr < batch) ? (uint8_t)keep8(tin, kr, q % NCH) : (uint8_t)0;
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -539,8 +356,8 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
               const int k = (kt0 + w) * 16 + c16;
               if (k < K) {
                 // gx = gradient w.r.t. the producer's BN output h (dropout transposed here)
-                const bool keep = tin.drop.thr ? ((mk[lr * NCH + (k >> 3)] >> (k & 7)) & 1) : true;
-                const float dh = keep ? acc[w][r] * tin.drop.inv_keep : 0.f;
+                const bool keep = tin.keep ? ((mk[lr * NCH + (k >> 3)] >> (k & 7)) & 1) : true;
+                const float dh = keep ? acc[w][r] * tin.inv_keep : 0.f;
                 gx[gr * ldgx + k] = dh;
                 if (IBN && keep) {
                   const float xhat = (xv[r][kt0 + w] - Is[k]) * Is[Kp + k];
@@ -584,10 +401,9 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dx_kernel(const float* __re
 // KTP = pow2 >= number of k-tiles: wave -> (k-tile = wave % KTP, row group = wave / KTP)
 template <int NT, int KTP>
 __global__ __launch_bounds__(kThreads, 2) void dense_dw_kernel(const float* __restrict__ dzbuf, const float* __restrict__ x, int64_t ldx_g,
-                                                                int64_t batch, int K, int N, InXform tin, int64_t row0,
+                                                                int64_t batch, int K, int N, InXform tin,
                                                                 float* __restrict__ slabs, int64_t slab_elems, int64_t db_off) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  dropout_resolve(tin.drop);
   constexpr int Np = NT * 16, ldz = Np + 4;
   constexpr int RGN = 8 / KTP;                      // row groups
   constexpr int TM = 16 * (RGN > 4 ? RGN : 4);      // 64 rows per tile (128 when K <= 16)
@@ -664,7 +480,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_dw_kernel(const float* __re
       const int idx = threadIdx.x + kThreads * i;
       if (idx < n_xc) {
         const int r = idx / xc_row, c = (idx - r * xc_row) << 3;
-        xform8(px[i], tin, ss, Kp, row0 + row_base + r, c, K, (row_base + r) < batch && c < K);
+        xform8(px[i], tin, ss, Kp, row_base + r, c, K, (row_base + r) < batch && c < K);
         store8_lds(Xs + r * ldx + c, px[i]);
       }
     }
@@ -889,63 +705,8 @@ static inline unsigned grid_for(int64_t batch, int tm) {
   return (unsigned)(t < kMaxGrid ? (t < 1 ? 1 : t) : kMaxGrid);
 }
 constexpr int kMaxDynLds = 150 * 1024;
-template <int NT, int KJ>
-static void launch_fwd(unsigned grid, size_t shmem, hipStream_t s, const float* x, int64_t ldx, const float* W, const float* bias, float* y,
-                       int64_t ldy, int64_t batch, int K, int N, int act, InXform t, int64_t row0, double* stats, const float* yin) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-    attr_set = true;
-  }
-  dense_fwd_kernel<NT, KJ><<<grid, kThreads, shmem, s>>>(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats, yin);
-}
-
-static int dense_forward_one(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy, int64_t batch, int K, int N,
-                             int act, InXform t, int64_t row0, double* stats, const float* yin, hipStream_t s) {
-  const int NT = tiles16(N), KJ = tiles16(K), Kp = KJ * 16, Np = NT * 16;
-  const size_t shmem = ((size_t)Kp * Np + 2 * (size_t)Kp) * sizeof(float) + (size_t)8 * 16 * 2 * KJ + 16;
-  const unsigned grid = grid_for(batch, 16 * 8);
-#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(grid, shmem, s, x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats, yin); break;
-#define BR_FWD(NTv)                                                                                        \
-  case NTv:                                                                                                \
-    switch (KJ) { BR_FWD_KJ(NTv, 1) BR_FWD_KJ(NTv, 2) BR_FWD_KJ(NTv, 3) BR_FWD_KJ(NTv, 4) BR_FWD_KJ(NTv, 5) \
-                  BR_FWD_KJ(NTv, 6) BR_FWD_KJ(NTv, 7) BR_FWD_KJ(NTv, 8) default: break; }                  \
-    break;
-  switch (NT) {
-    BR_FWD(1) BR_FWD(2) BR_FWD(3) BR_FWD(4) BR_FWD(5) BR_FWD(6) BR_FWD(7) BR_FWD(8)
-    default: br::set_error("brDenseForward: unsupported N"); return BR_ERR_UNSUPPORTED;
-  }
-  BR_CHECK_LAUNCH("brDenseForward");
-  return BR_OK;
-}
-
-// K > 128 (config 5: 2 x embed_dim 128 = 256 inputs) runs as two K-halves: the first launch leaves the raw partial
-// sums in y, the second adds them in its epilogue (bias, activation, BatchNorm column sums only there).  The split
-// point is a multiple of 8 so that the dropout chunks (8 columns per Philox call) keep their global numbering.
-static inline int split_k(int K) { return ((K / 2 + 7) / 8) * 8; }
-
-extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
-                              int64_t batch, int K, int N, int act, const float* in_scale, const float* in_shift,
-                              float drop_p, uint64_t seed, uint32_t step, uint32_t site, int64_t row0, double* stats,
-                              brStream stream) {
-  BR_CHECK_ARG(x && W && y && batch >= 0 && K >= 1 && N >= 1, "brDenseForward: bad args");
-  BR_CHECK_ARG(K <= 2 * kMaxT * 16 && N <= kMaxT * 16, "brDenseForward: K=%d N=%d exceed %d / %d", K, N, 2 * kMaxT * 16, kMaxT * 16);
-  BR_CHECK_ARG(ldx >= K && ldy >= N, "brDenseForward: bad leading dims");
-  BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
-  BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
-  if (batch == 0) return BR_OK;
-  InXform t{in_scale, in_shift, make_dropout(drop_p, seed, step, site), 0u};
-  if (const StepStateDev* ss = current_step_state()) t.drop.step_ptr = &ss->step;
-  hipStream_t s = (hipStream_t)stream;
-  if (K <= kMaxT * 16) return dense_forward_one(x, ldx, W, bias, y, ldy, batch, K, N, act, t, row0, stats, nullptr, s);
-  const int Ka = split_k(K);
-  int rc = dense_forward_one(x, ldx, W, nullptr, y, ldy, batch, Ka, N, BR_ACT_LINEAR, t, row0, nullptr, nullptr, s);
-  if (rc != BR_OK) return rc;
-  InXform tb = t;
-  if (in_scale) { tb.scale = in_scale + Ka; tb.shift = in_shift + Ka; }
-  tb.c8off = (uint32_t)(Ka >> 3);
-  return dense_forward_one(x + Ka, ldx, W + (int64_t)Ka * N, bias, y, ldy, batch, K - Ka, N, act, tb, row0, stats, y, s);
-}
+// K > 128 layers run as two K-halves (see dense_fwd.hip); any split that is a multiple of 8 keeps the dropout chunks' numbering
+static inline int split_k(int K) { return ((K / 2 + 31) / 32) * 32; }
 
 extern "C" int brBnFinalize(const double* stats, double batch_total, const float* gamma, const float* beta, float eps,
                             float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, float* mean,
@@ -1000,37 +761,38 @@ extern "C" int64_t brDenseBackwardWorkspaceFloats(int64_t batch, int K, int N) {
 
 template <int NT, int KT, bool IBN>
 static void launch_dx_v(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
-                        int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn, int64_t row0,
+                        int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
                         float* gx, int64_t ldgx, float* dzbuf, double* in_sums) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dense_dx_kernel<NT, KT, IBN>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     attr_set = true;
   }
-  dense_dx_kernel<NT, KT, IBN><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
+  dense_dx_kernel<NT, KT, IBN><<<grid, kThreads, shmem, s>>>(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, gx, ldgx, dzbuf, in_sums);
 }
 template <int NT, int KT>
 static void launch_dx(unsigned grid, size_t shmem, hipStream_t s, const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
-                      int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn, int64_t row0,
+                      int64_t ldx, const float* W, int64_t batch, int K, int N, int act, OutXform to, InXform tin, InBn ibn,
                       float* gx, int64_t ldgx, float* dzbuf, double* in_sums) {
-  if (ibn.mean) launch_dx_v<NT, KT, true>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
-  else launch_dx_v<NT, KT, false>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dzbuf, in_sums);
+  if (ibn.mean) launch_dx_v<NT, KT, true>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, gx, ldgx, dzbuf, in_sums);
+  else launch_dx_v<NT, KT, false>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, gx, ldgx, dzbuf, in_sums);
 }
 
 template <int NT, int KTP>
 static void launch_dw(unsigned grid, size_t shmem, hipStream_t s, int64_t slab_elems, int64_t db_off, const float* dzbuf, const float* x, int64_t ldx, int64_t batch, int K, int N,
-                      InXform tin, int64_t row0, float* slabs) {
+                      InXform tin, float* slabs) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dense_dw_kernel<NT, KTP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     attr_set = true;
   }
-  dense_dw_kernel<NT, KTP><<<grid, kThreads, shmem, s>>>(dzbuf, x, ldx, batch, K, N, tin, row0, slabs, slab_elems, db_off);
+  dense_dw_kernel<NT, KTP><<<grid, kThreads, shmem, s>>>(dzbuf, x, ldx, batch, K, N, tin, slabs, slab_elems, db_off);
 }
 
-// one K-range of a layer's backward: dx for columns [k0, k0+Kc) of gx, dW rows [k0, k0+Kc)
+// one K-range of a layer's backward on the two-kernel path (any K, N <= 128, any alignment): dx for columns [k0, k0+Kc) of gx,
+// dW rows [k0, k0+Kc)
 static int dense_backward_part(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* W,
-                               int64_t batch, int Kc, int N, int act, const OutXform& to, InXform tin, InBn ibn, int64_t row0, float* gx,
+                               int64_t batch, int Kc, int N, int act, const OutXform& to, InXform tin, InBn ibn, float* gx,
                                int64_t ldgx, float* dz_ws, float* slabs, int64_t slab_elems, int64_t db_off, int KTP, double* in_bn_sums,
                                bool run_dx, bool run_dw, hipStream_t s) {
   const int KT = tiles16(Kc), NT = tiles16(N);
@@ -1039,7 +801,7 @@ static int dense_backward_part(const float* gy, int64_t ldgy, const float* y, in
   if (run_dx) {
     const unsigned grid = grid_for(batch, 16 * 8);
     const size_t shmem = ((size_t)Kp * (Np + 4) + 4 * (size_t)Np + 2 * (size_t)Kp) * sizeof(float) + (size_t)8 * 16 * 2 * KT + 16;
-#define BR_DX_K(NTv, KTv) case KTv: launch_dx<NTv, KTv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W_, batch, Kc, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, in_bn_sums); break;
+#define BR_DX_K(NTv, KTv) case KTv: launch_dx<NTv, KTv>(grid, shmem, s, gy, ldgy, y, ldy, x, ldx, W_, batch, Kc, N, act, to, tin, ibn, gx, ldgx, dz_ws, in_bn_sums); break;
 #define BR_DX(NTv) \
   case NTv:        \
     switch (KT) { BR_DX_K(NTv, 1) BR_DX_K(NTv, 2) BR_DX_K(NTv, 3) BR_DX_K(NTv, 4) BR_DX_K(NTv, 5) BR_DX_K(NTv, 6) BR_DX_K(NTv, 7) BR_DX_K(NTv, 8) default: break; } \
@@ -1054,7 +816,7 @@ static int dense_backward_part(const float* gy, int64_t ldgy, const float* y, in
     const unsigned grid = dw_grid(batch, KTP);
     const int tm = dw_tm(KTP);
     const size_t shmem = ((size_t)tm * (Kp + 4) + (size_t)tm * (Np + 4) + 2 * (size_t)Kp) * sizeof(float);
-#define BR_DW_K(NTv, KTPv) case KTPv: launch_dw<NTv, KTPv>(grid, shmem, s, slab_elems, db_off, dz_ws, x, ldx, batch, Kc, N, tin, row0, slabs); break;
+#define BR_DW_K(NTv, KTPv) case KTPv: launch_dw<NTv, KTPv>(grid, shmem, s, slab_elems, db_off, dz_ws, x, ldx, batch, Kc, N, tin, slabs); break;
 #define BR_DW(NTv) \
   case NTv:        \
     switch (KTP) { BR_DW_K(NTv, 1) BR_DW_K(NTv, 2) BR_DW_K(NTv, 4) BR_DW_K(NTv, 8) default: break; } \
@@ -1068,12 +830,14 @@ static int dense_backward_part(const float* gy, int64_t ldgy, const float* y, in
   return BR_OK;
 }
 
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
                                const float* W, int64_t batch, int K, int N, int act, const float* out_mean,
                                const float* out_rstd, const float* out_gamma, const double* bn_sums, double batch_total,
                                const float* in_scale, const float* in_shift, const float* in_mean, const float* in_rstd,
-                               float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0, float* gx,
-                               int64_t ldgx, float* dz_ws, float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream) {
+                               float in_drop_p, const uint32_t* keep, float* gx, int64_t ldgx, float* dz_ws, float* dW_slabs,
+                               int n_slabs, double* in_bn_sums, brStream stream) {
   BR_CHECK_ARG(gy && y && x && W && dW_slabs && dz_ws && batch >= 0 && K >= 1 && N >= 1, "brDenseBackward: bad args");
   BR_CHECK_ARG(K <= 2 * kMaxT * 16 && N <= kMaxT * 16, "brDenseBackward: K=%d N=%d exceed %d / %d", K, N, 2 * kMaxT * 16, kMaxT * 16);
   BR_CHECK_ARG(ldgy >= N && ldy >= N && ldx >= K && (!gx || ldgx >= K), "brDenseBackward: bad leading dims");
@@ -1085,37 +849,65 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
   BR_CHECK_ARG(!in_mean || gx, "brDenseBackward: in BN sums need gx");
   BR_CHECK_ARG(K <= kMaxT * 16 || !in_mean, "brDenseBackward: K > %d is supported for inputs without a BatchNorm (first layer of a tower)", kMaxT * 16);
   BR_CHECK_ARG((reinterpret_cast<uintptr_t>(dz_ws) & 15) == 0, "brDenseBackward: dz_ws must be 16-byte aligned");
+  BR_CHECK_ARG(in_drop_p >= 0.f && in_drop_p < 1.f, "brDenseBackward: in_drop_p out of [0,1)");
+  BR_CHECK_ARG((in_drop_p > 0.f) == (keep != nullptr), "brDenseBackward: keep bits (brDropoutKeepBits) are required exactly when in_drop_p > 0");
   if (batch == 0) return BR_OK;
   const int want = brDenseBackwardSlabs(batch, K, N);
   BR_CHECK_ARG(n_slabs == want, "brDenseBackward: n_slabs %d != brDenseBackwardSlabs() %d", n_slabs, want);
-  OutXform to{out_mean, out_rstd, out_gamma, bn_sums, (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch))};
-  InXform tin{in_scale, in_shift, make_dropout(in_drop_p, seed, step, in_site), 0u};
-  if (const StepStateDev* ss = current_step_state()) tin.drop.step_ptr = &ss->step;
-  InBn ibn{in_mean, in_rstd};
   hipStream_t s = (hipStream_t)stream;
   const int64_t slab_elems = (int64_t)K * N + N;
-  if (K <= kMaxT * 16)
-    return dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, dW_slabs, slab_elems,
+  const float inv_batch = (float)(1.0 / (batch_total > 0 ? batch_total : (double)batch));
+  const float inv_keep = in_drop_p > 0.f ? 1.0f / (1.0f - in_drop_p) : 1.0f;
+  const int kw = (K + 31) / 32;
+  const int Ka = K <= kMaxT * 16 ? K : split_k(K), Kb = K - Ka;
+
+  // ---- fused one-launch path: 16-B aligned rows everywhere (row strides multiples of 4 floats) and an LDS image that fits ----
+  const bool vec = ldgy % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && (!gx || ldgx % 4 == 0) && al16(gy) && al16(y) && al16(x) && (!gx || al16(gx)) &&
+                   (N % 4 != 0 || al16(W)) && (Kb == 0 || Ka % 4 == 0);
+  if (vec && br::dense_bwd_fused_lds(tiles16(N), tiles16(Ka)) <= 160 * 1024) {
+    br::BwdArgs a{gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, out_mean, out_rstd, out_gamma, bn_sums, inv_batch, in_scale, in_shift,
+                  keep, kw, inv_keep, in_mean, in_rstd, in_bn_sums, gx, ldgx, dW_slabs, slab_elems, (int64_t)K * N};
+    const int fg = br::dense_bwd_fused_grid(batch);
+    if (fg < n_slabs) {     // the slab count is sized for the two-kernel path: unused slabs must read as zeros
+      hipError_t e = hipMemsetAsync(dW_slabs + (int64_t)fg * slab_elems, 0, sizeof(float) * (size_t)(n_slabs - fg) * (size_t)slab_elems, s);
+      if (e != hipSuccess) { br::set_error("brDenseBackward: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
+    }
+    int rc = br::dense_backward_fused(a, s);
+    if (rc != BR_OK || Kb == 0) return rc;
+    // second K-half of a K > 128 layer: dz is formed again (identically); dW rows / gx columns / keep words of that half; db done
+    a.x = x + Ka; a.W = W + (int64_t)Ka * N; a.K = Kb;
+    if (in_scale) { a.scale = in_scale + Ka; a.shift = in_shift + Ka; }
+    if (keep) a.keep = keep + Ka / 32;
+    if (gx) a.gx = gx + Ka;
+    a.slabs = dW_slabs + (int64_t)Ka * N; a.db_off = -1;
+    return br::dense_backward_fused(a, s);
+  }
+
+  // ---- general two-kernel path ----
+  OutXform to{out_mean, out_rstd, out_gamma, bn_sums, inv_batch};
+  InXform tin{in_scale, in_shift, reinterpret_cast<const uint8_t*>(keep), (int64_t)kw * 4, inv_keep};
+  InBn ibn{in_mean, in_rstd};
+  if (Kb == 0)
+    return dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, K, N, act, to, tin, ibn, gx, ldgx, dz_ws, dW_slabs, slab_elems,
                                (int64_t)K * N, pow2_ge(tiles16(K)), in_bn_sums, true, true, s);
   // two K-halves (see brDenseForward): dx A, dx B (dz is formed - identically - by both), then dW A, dW B
-  const int Ka = split_k(K), Kb = K - Ka;
   InXform tb = tin;
   if (in_scale) { tb.scale = in_scale + Ka; tb.shift = in_shift + Ka; }
-  tb.c8off = (uint32_t)(Ka >> 3);
+  if (keep) tb.keep = tin.keep + Ka / 8;
   int rc = BR_OK;
   if (gx) {
-    rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, row0, gx, ldgx, dz_ws, nullptr, 0, 0, 8, nullptr, true, false, s);
+    rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, gx, ldgx, dz_ws, nullptr, 0, 0, 8, nullptr, true, false, s);
     if (rc != BR_OK) return rc;
-    rc = dense_backward_part(gy, ldgy, y, ldy, x + Ka, ldx, W + (int64_t)Ka * N, batch, Kb, N, act, to, tb, ibn, row0, gx + Ka, ldgx, dz_ws, nullptr, 0, 0,
+    rc = dense_backward_part(gy, ldgy, y, ldy, x + Ka, ldx, W + (int64_t)Ka * N, batch, Kb, N, act, to, tb, ibn, gx + Ka, ldgx, dz_ws, nullptr, 0, 0,
                              8, nullptr, true, false, s);
   } else {   // no input gradient wanted: one dx launch still forms dz for the dW kernels
-    rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, row0, nullptr, ldgx, dz_ws, nullptr, 0, 0, 8, nullptr, true, false, s);
+    rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, nullptr, ldgx, dz_ws, nullptr, 0, 0, 8, nullptr, true, false, s);
   }
   if (rc != BR_OK) return rc;
-  rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, row0, nullptr, ldgx, dz_ws, dW_slabs, slab_elems, (int64_t)K * N, 8,
+  rc = dense_backward_part(gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, to, tin, ibn, nullptr, ldgx, dz_ws, dW_slabs, slab_elems, (int64_t)K * N, 8,
                            nullptr, false, true, s);
   if (rc != BR_OK) return rc;
-  return dense_backward_part(gy, ldgy, y, ldy, x + Ka, ldx, W, batch, Kb, N, act, to, tb, ibn, row0, nullptr, ldgx, dz_ws, dW_slabs + (int64_t)Ka * N, slab_elems,
+  return dense_backward_part(gy, ldgy, y, ldy, x + Ka, ldx, W, batch, Kb, N, act, to, tb, ibn, nullptr, ldgx, dz_ws, dW_slabs + (int64_t)Ka * N, slab_elems,
                              -1, 8, nullptr, false, true, s);
 }
 

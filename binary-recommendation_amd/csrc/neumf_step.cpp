@@ -117,6 +117,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const SlabPlan sp = slab_plan(B, D, n1, n2, n3);
   float *slabs_t = s->slabs + sp.off_t, *slabs2 = s->slabs + sp.off2, *slabs1 = s->slabs + sp.off1;
   BR_CHECK_ARG(!deferred || (s->step_state && s->user_last && s->item_last), "brNeumfStepRun: deferred Adam needs step_state and the last[] arrays");
+  const int l1 = (n1 + 3) & ~3, l2 = (n2 + 3) & ~3;      // row strides of a1 / gh1 and a2 / gh2 (padded to 16 B: include/binrec.h)
   const float p = train ? s->dropout : 0.f;
   const double bt = (double)(s->batch_total > 0 ? s->batch_total : B);
   const float inv_b = (float)(1.0 / bt);
@@ -156,6 +157,18 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   // (a host that runs the embedding exchange itself - no EMBED bit - advanced the state before its lookup)
   if ((ph & BR_PH_FWD1) && (ph & BR_PH_EMBED) && train && s->step_state)
     RUN(BR_TAG_SMALL, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, s->dstat, n_dstat, stream));
+  // dropout keep-bit planes of the three sites [2D | n1 | n2], filled once per step (after the step counter advanced)
+  uint32_t *keep0 = nullptr, *keep1 = nullptr, *keep2 = nullptr;
+  if (p > 0.f) {
+    BR_CHECK_ARG(s->keep_bits != nullptr, "brNeumfStepRun: dropout needs brNeumfStep.keep_bits");
+    keep0 = s->keep_bits; keep1 = keep0 + brDropoutKeepWords(B, 2 * D); keep2 = keep1 + brDropoutKeepWords(B, n1);
+  }
+  if ((ph & BR_PH_FWD1) && p > 0.f) {
+    const uint32_t sites[3] = {0, 1, 2};
+    const int widths[3] = {2 * D, n1, n2};
+    uint32_t* const outs[3] = {keep0, keep1, keep2};
+    RUN(BR_TAG_SMALL, brDropoutKeepBits(p, s->seed, (uint32_t)s->step, s->row0, B, 3, sites, widths, outs, stream));
+  }
   if (ph & BR_PH_FWD1) {
     if (train && !s->step_state) {
       hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(BR_STAT_REPLICAS * (4 * n1 + 4 * n2)), hs);
@@ -178,16 +191,16 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       if (rc != BR_OK) return rc;
       (void)hipEventRecord(g_join, as);
     }
-    RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, n1, B, 2 * D, n1, s->act, nullptr, nullptr, p, s->seed,
-                       (uint32_t)s->step, 0, s->row0, train ? stats1 : nullptr, stream));
+    RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, l1, B, 2 * D, n1, s->act, nullptr, nullptr, p, keep0,
+                       train ? stats1 : nullptr, stream));
   }
   if (ph & BR_PH_FWD2) {
     if (train)
       RUN(BR_TAG_SMALL, brBnFinalize(stats1, bt_bn, th + og1, th + obe1, s->bn_eps, s->bn_momentum, mm1, mv1, scale1, shift1, mean1, rstd1, n1, stream));
     else
       RUN(BR_TAG_SMALL, brBnInference(th + og1, th + obe1, mm1, mv1, s->bn_eps, scale1, shift1, n1, stream));
-    RUN(BR_TAG_FWD_L2, brDenseForward(s->a1, n1, th + oW2, th + ob2, s->a2, n2, B, n1, n2, s->act, scale1, shift1, p, s->seed, (uint32_t)s->step, 1,
-                       s->row0, train ? stats2 : nullptr, stream));
+    RUN(BR_TAG_FWD_L2, brDenseForward(s->a1, l1, th + oW2, th + ob2, s->a2, l2, B, n1, n2, s->act, scale1, shift1, p, keep1,
+                       train ? stats2 : nullptr, stream));
   }
   if (ph & BR_PH_FWD3) {
     if (train)
@@ -195,14 +208,13 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     else
       RUN(BR_TAG_SMALL, brBnInference(th + og2, th + obe2, mm2, mv2, s->bn_eps, scale2, shift2, n2, stream));
     if (!train)
-      RUN(BR_TAG_FWD_L3, brDenseForward(s->a2, n2, th + oW3, th + ob3, s->a3, n3, B, n2, n3, s->act, scale2, shift2, 0.f, s->seed, (uint32_t)s->step, 2,
-                         s->row0, nullptr, stream));
+      RUN(BR_TAG_FWD_L3, brDenseForward(s->a2, l2, th + oW3, th + ob3, s->a3, n3, B, n2, n3, s->act, scale2, shift2, 0.f, nullptr, nullptr, stream));
     if (train) {
       // L3 forward, head, loss and their backward in one launch; W3|b3|W4|b4 are adjacent in theta / grad
       const int nst = sp.ns_t;
-      RUN(BR_TAG_HEAD, brNeumfTailFused(s->a2, n2, th + oW3, th + ob3, th + oW4, th + ob4, s->dot, s->labels, scale2, shift2, mean2, rstd2, p, s->seed,
-                      (uint32_t)s->step, 2, s->row0, B, n2, n3, s->act, s->mf_first, s->loss, inv_b, s->a3, s->logit, s->prob, s->msums, s->ddot,
-                      s->gh2, n2, bsum2, slabs_t, nst, stream));
+      RUN(BR_TAG_HEAD, brNeumfTailFused(s->a2, l2, th + oW3, th + ob3, th + oW4, th + ob4, s->dot, s->labels, scale2, shift2, mean2, rstd2, p, keep2,
+                      B, n2, n3, s->act, s->mf_first, s->loss, inv_b, s->a3, s->logit, s->prob, s->msums, s->ddot,
+                      s->gh2, l2, bsum2, slabs_t, nst, stream));
       if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs_t, nst, sp.el_t, gr + oW3, stream));
     } else {
       RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob,
@@ -212,14 +224,14 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   if (!train) return BR_OK;
   if (ph & BR_PH_BWD2) {
     const int ns2 = sp.ns2;
-    RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, n2, s->a2, n2, s->a1, n1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt_bn, scale1, shift1,
-                        mean1, rstd1, p, 1, s->seed, (uint32_t)s->step, s->row0, s->gh1, n1, s->dz_ws, slabs2, ns2, bsum1, stream));
+    RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, l2, s->a2, l2, s->a1, l1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt_bn, scale1, shift1,
+                        mean1, rstd1, p, keep1, s->gh1, l1, s->dz_ws, slabs2, ns2, bsum1, stream));
     if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs2, ns2, sp.el2, gr + oW2, stream));
   }
   if (ph & BR_PH_BWD1) {
     const int ns1 = sp.ns1;
-    RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, n1, s->a1, n1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt_bn, nullptr,
-                        nullptr, nullptr, nullptr, p, 0, s->seed, (uint32_t)s->step, s->row0, s->dx0, 2 * D, s->dz_ws, slabs1, ns1, nullptr, stream));
+    RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, l1, s->a1, l1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt_bn, nullptr,
+                        nullptr, nullptr, nullptr, p, keep0, s->dx0, 2 * D, s->dz_ws, slabs1, ns1, nullptr, stream));
     if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs1, ns1, sp.el1, gr + oW1, stream));
   }
   if ((ph & BR_PH_BNG) && !fused_final) {

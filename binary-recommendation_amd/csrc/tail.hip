@@ -15,7 +15,6 @@
 // access staged through LDS tiles (coalesced in, coalesced out).  128 rows per workgroup, 4 lanes per row
 // (one thread per row left a single wave per SIMD with every LDS latency exposed: 57 us), 2 tiles of LDS.
 #include "common.h"
-#include "philox.h"
 
 namespace br {
 
@@ -29,8 +28,8 @@ struct TailArgs {
   const float* a2; int64_t lda2;
   const float *W3, *b3, *w4, *b4, *dot, *labels;
   const float *scale2, *shift2, *mean2, *rstd2;
-  DropoutCfg drop;
-  int64_t row0, batch;
+  const uint8_t* keep; int64_t keep_ld; float inv_keep;     // keep-bit plane of dropout site 2 as bytes (byte c8 of a row = its chunk c8), or null
+  int64_t batch;
   int n2, n3, act, mf_first, loss;
   float inv_batch;
   float *a3, *logit, *prob, *ddot, *gh2;
@@ -43,7 +42,6 @@ struct TailArgs {
 template <int N3P>
 __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  dropout_resolve(a.drop);
   const int n2 = a.n2, n3 = a.n3, ld = n2 | 1;             // odd row stride
   float* A = smem;                                          // [128][ld]  raw a2, later gh2
   float* X = A + kTailRows * ld;                            // [128][ld]  T(a2), later gh2 * xhat
@@ -102,7 +100,7 @@ __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
   for (int k = t; k < 256; k += kTailThreads) (&colred[0][0])[k] = 0.0;
   __syncthreads();
 
-  const float ik = a.drop.inv_keep;
+  const float ik = a.inv_keep;
   // ---- forward of the row: T(a2) -> X, z3 (this lane's chunks, then summed over the 4 lanes of the row) ----
   float z[N3P];
 #pragma unroll
@@ -113,7 +111,7 @@ __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
     const int k0 = 8 * (q + 4 * i);
     bits[i] = 0u;
     if (k0 < n2) {
-      bits[i] = live ? dropout_keep8(a.drop, a.row0 + gr, (uint32_t)(k0 >> 3)) : 0u;
+      bits[i] = live ? (a.keep ? (uint32_t)a.keep[gr * a.keep_ld + (k0 >> 3)] : 0xFFu) : 0u;
       const int kend = (n2 - k0) < 8 ? (n2 - k0) : 8;
       for (int j = 0; j < kend; ++j) {
         const int k = k0 + j;
@@ -271,7 +269,7 @@ extern "C" int64_t brNeumfTailSlabElems(int n2, int n3) { return (int64_t)n2 * n
 
 extern "C" int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, const float* b3, const float* w4, const float* b4,
                                 const float* dot, const float* labels, const float* scale2, const float* shift2, const float* mean2,
-                                const float* rstd2, float drop_p, uint64_t seed, uint32_t step, uint32_t site, int64_t row0,
+                                const float* rstd2, float drop_p, const uint32_t* keep,
                                 int64_t batch, int n2, int n3, int act, int mf_first, int loss, float inv_batch, float* a3,
                                 float* logit, float* prob, double* sums, float* ddot, float* gh2, int64_t ldgh2, double* bn_sums,
                                 float* slabs, int n_slabs, brStream stream) {
@@ -279,15 +277,15 @@ extern "C" int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, 
                "brNeumfTailFused: null pointer");
   BR_CHECK_ARG(batch >= 0 && n2 >= 1 && n2 <= 128 && n3 >= 1 && n3 <= 32 && lda2 >= n2 && ldgh2 >= n2, "brNeumfTailFused: bad sizes");
   BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brNeumfTailFused: drop_p out of [0,1)");
+  BR_CHECK_ARG((drop_p > 0.f) == (keep != nullptr), "brNeumfTailFused: keep bits (brDropoutKeepBits) are required exactly when drop_p > 0");
   BR_CHECK_ARG(loss == BR_LOSS_BCE || loss == BR_LOSS_MSE, "brNeumfTailFused: bad loss");
   if (batch == 0) return BR_OK;
   BR_CHECK_ARG(n_slabs == brNeumfTailSlabs(batch), "brNeumfTailFused: n_slabs must be brNeumfTailSlabs(batch)");
   TailArgs a;
   a.a2 = a2; a.lda2 = lda2; a.W3 = W3; a.b3 = b3; a.w4 = w4; a.b4 = b4; a.dot = dot; a.labels = labels;
   a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rstd2 = rstd2;
-  a.drop = make_dropout(drop_p, seed, step, site);
-  if (const StepStateDev* ss = current_step_state()) a.drop.step_ptr = &ss->step;
-  a.row0 = row0; a.batch = batch; a.n2 = n2; a.n3 = n3; a.act = act; a.mf_first = mf_first; a.loss = loss; a.inv_batch = inv_batch;
+  a.keep = reinterpret_cast<const uint8_t*>(keep); a.keep_ld = 4 * (int64_t)((n2 + 31) / 32); a.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  a.batch = batch; a.n2 = n2; a.n3 = n3; a.act = act; a.mf_first = mf_first; a.loss = loss; a.inv_batch = inv_batch;
   a.a3 = a3; a.logit = logit; a.prob = prob; a.ddot = ddot; a.gh2 = gh2; a.ldgh2 = ldgh2; a.msums = sums; a.bn_sums = bn_sums;
   a.slabs = slabs;
   const int n3p = (n3 + 3) & ~3;

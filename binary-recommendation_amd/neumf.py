@@ -195,10 +195,11 @@ class NeuMFEngine:
         D, (n1, n2, n3) = cfg.dim, cfg.hidden
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.x0, self.dot = f(B, 2 * D), f(B)
-        self.a1, self.a2, self.a3 = f(B, n1), f(B, n2), f(B, n3)
+        pad4 = lambda n: (n + 3) & ~3      # rows of the hidden activations / their gradients are padded to 16 B (brNeumfStep)
+        self.a1, self.a2, self.a3 = f(B, pad4(n1))[:, :n1], f(B, pad4(n2))[:, :n2], f(B, n3)
         self.logit, self.prob = f(B), f(B)
         self.da3, self.ddot = f(B, n3), f(B)
-        self.gh2, self.gh1, self.dx0 = f(B, n2), f(B, n1), f(B, 2 * D)
+        self.gh2, self.gh1, self.dx0 = f(B, pad4(n2))[:, :n2], f(B, pad4(n1))[:, :n1], f(B, 2 * D)
         self.g_user, self.g_item = f(B, 2 * D), f(B, 2 * D)      # fused [mlp | mf] row gradients per stream
         # per-step double scratch: [stats1 | stats2 | bsum1 | bsum2], each [BR_STAT_REPLICAS][2n] (the kernels
         # spread their column-sum atomics over 8 replicas; consumers add them)
@@ -220,6 +221,7 @@ class NeuMFEngine:
         self.dz_ws = f(max(ops.dense_backward_ws_floats(B, k, n) for k, n in layers))
         self.nsh = ops.head_slabs(B)
         self.hslabs = f(self.nsh * (n3 + 2))
+        self.keep_bits = torch.empty(sum(ops.dropout_keep_words(B, k) for k in (2 * D, n1, n2)), dtype=torch.int32, device=dev)
         self.err = ops.new_err_flag(dev)
         self._alloc_sparse(B)
         self._build_step_struct()
@@ -262,6 +264,7 @@ class NeuMFEngine:
             setattr(st, k, P(getattr(self, k)))
         st.bn, st.dstat, st.msums = P(self.bn_buf), P(self.dstat), P(self.msums)
         st.slabs, st.hslabs, st.err_flag, st.dz_ws = P(self.slabs), P(self.hslabs), P(self.err), P(self.dz_ws)
+        st.keep_bits = P(self.keep_bits)
         self._bind_indexes(st)
         if not self.sharded and os.environ.get("BR_AUX_STREAM", "1") != "0":
             self.aux_stream = torch.cuda.Stream(device=self.device)     # the dedup sorts run beside fwd/bwd

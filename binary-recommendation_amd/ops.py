@@ -268,13 +268,33 @@ def adam_alpha(lr: float, t: int, beta1=0.9, beta2=0.999) -> float:
 
 
 # ------------------------------------------------------------------------------ T1-T4 MLP tower
+def dropout_keep_words(batch, K) -> int:
+    return int(_lib.load().brDropoutKeepWords(batch, K))
+
+
+def dropout_keep_bits(drop_p, seed, step, row0, batch, sites, widths, outs=None):
+    """T4: the Philox keep-bit planes of up to three dropout sites in one launch (uint32 [batch][ceil(K/32)] each)."""
+    n = len(sites)
+    if outs is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        outs = [torch.empty(dropout_keep_words(batch, k), dtype=torch.int32, device=dev) for k in widths]
+    S = (ctypes.c_uint32 * n)(*[int(s) for s in sites])
+    Wd = (ctypes.c_int * n)(*[int(k) for k in widths])
+    OP = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    check(_lib.load().brDropoutKeepBits(float(drop_p), int(seed), int(step), int(row0), int(batch), n, S, Wd, OP, _stream()), "brDropoutKeepBits")
+    return outs
+
+
 def dense_forward(x, W, bias, y, act, in_scale=None, in_shift=None, drop_p=0.0, seed=0, step=0, site=0, row0=0,
-                  stats=None, batch=None):
+                  stats=None, batch=None, keep=None):
+    """keep: the site's bit plane (dropout_keep_bits); built here from (seed, step, site, row0) when drop_p > 0 and it is None."""
     B = x.shape[0] if batch is None else batch
     K, N = W.shape
+    if drop_p > 0 and keep is None and B > 0:
+        keep = dropout_keep_bits(drop_p, seed, step, row0, B, [site], [K])[0]
     check(_lib.load().brDenseForward(x.data_ptr(), x.stride(0), _f32(W, "W").data_ptr(), _p(bias), y.data_ptr(), y.stride(0),
-                                     B, K, N, ACT[act], _p(in_scale), _p(in_shift), float(drop_p), int(seed), int(step),
-                                     int(site), int(row0), _p(stats), _stream()), "brDenseForward")
+                                     B, K, N, ACT[act], _p(in_scale), _p(in_shift), float(drop_p), _p(keep) if drop_p > 0 else 0,
+                                     _p(stats), _stream()), "brDenseForward")
 
 
 def bn_finalize(stats, batch_total, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd):
@@ -298,18 +318,21 @@ def dense_backward_ws_floats(batch, K, N) -> int:
 
 def dense_backward(gy, y, x, W, act, slabs, n_slabs, gx=None, out_bn=None, bn_sums=None, batch_total=None,
                    in_scale=None, in_shift=None, in_bn=None, in_drop_p=0.0, in_site=0, seed=0, step=0, row0=0,
-                   in_bn_sums=None, batch=None, dz_ws=None):
-    """out_bn = (mean, rstd, gamma) of the BN after this layer; in_bn = (mean, rstd) of the BN before it."""
+                   in_bn_sums=None, batch=None, dz_ws=None, keep=None):
+    """out_bn = (mean, rstd, gamma) of the BN after this layer; in_bn = (mean, rstd) of the BN before it.
+    keep: bit plane of the input dropout; built from (seed, step, in_site, row0) when in_drop_p > 0 and it is None."""
     B = gy.shape[0] if batch is None else batch
     K, N = W.shape
     om, ors, og = out_bn if out_bn is not None else (None, None, None)
     im, irs = in_bn if in_bn is not None else (None, None)
     if dz_ws is None:
         dz_ws = torch.empty(dense_backward_ws_floats(B, K, N), dtype=torch.float32, device=gy.device)
+    if in_drop_p > 0 and keep is None and B > 0:
+        keep = dropout_keep_bits(in_drop_p, seed, step, row0, B, [in_site], [K])[0]
     check(_lib.load().brDenseBackward(gy.data_ptr(), gy.stride(0), y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0),
                                       W.data_ptr(), B, K, N, ACT[act], _p(om), _p(ors), _p(og), _p(bn_sums),
                                       float(batch_total if batch_total is not None else B), _p(in_scale), _p(in_shift),
-                                      _p(im), _p(irs), float(in_drop_p), int(in_site), int(seed), int(step), int(row0),
+                                      _p(im), _p(irs), float(in_drop_p), _p(keep) if in_drop_p > 0 else 0,
                                       _p(gx), gx.stride(0) if gx is not None else 0, dz_ws.data_ptr(), slabs.data_ptr(), int(n_slabs),
                                       _p(in_bn_sums), _stream()), "brDenseBackward")
 

@@ -168,11 +168,21 @@ int brAdagradRowsSorted(float* table, float* acc, int64_t table_rows, int dim,
 int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n, double lr, double eps,
                   brStream stream);
 
+/* ---- T4: Dropout keep-bit planes — NFC_plain.py:138,141,144; NeuMFModel.py:67,71,75 ----------
+ * The masks are a pure function (Philox4x32-10, csrc/philox.h) of (seed, step, site, global row, col).  They are
+ * materialised once per (step, site) as bit planes and read by the forward and the backward of the layer behind the
+ * site: keep[r][w] (uint32, row stride ceil(K/32) words), bit b of word w = element (row0 + r, 32w + b) is KEPT.
+ * brDropoutKeepWords(batch, K) = words of one plane.  Up to three sites (widths[i] columns, dropout site id sites[i],
+ * plane out[i]) in one launch.  Inside brNeumfStepRun `step` comes from the device step state when there is one. */
+int64_t brDropoutKeepWords(int64_t batch, int K);
+int brDropoutKeepBits(float drop_p, uint64_t seed, uint32_t step, int64_t row0, int64_t batch, int n_sites,
+                      const uint32_t* sites, const int* widths, uint32_t* const* out, brStream stream);
+
 /* ---- T1-T4: MLP tower layer, fp32 MFMA (v_mfma_f32_16x16x4_f32) ----------------------------
  * Dense/BatchNormalization/Dropout: NFC_plain.py:138-147, NeuMFModel.py:67-78, twoTower.py:40-41.
  * y = act( T(x)·W + bias ),  T(x)[r,k] = (x[r,k]*in_scale[k] + in_shift[k]) * keep(r,k)/(1-p)
  *   in_scale/in_shift (K) NULL => identity (they carry the previous layer's BatchNorm);
- *   drop_p == 0 => no dropout; keep(r,k) from Philox(seed, step, site, row0+r, k).
+ *   drop_p == 0 (keep NULL) => no dropout; else keep = the site's bit plane (brDropoutKeepBits).
  * stats (double[BR_STAT_REPLICAS][2N], may be NULL): += column sums of y and y^2 (BatchNorm batch
  *   statistics), spread over 8 replicas (workgroup % 8) so same-address atomics do not serialise;
  *   consumers (brBnFinalize, brDenseBackward, brBnParamGrads) add the replicas.  The same layout
@@ -180,8 +190,8 @@ int brAdagradFlat(float* theta, float* acc, const float* g, int64_t n, double lr
  * x: (B x K) row stride ldx; W: (K x N) row-major; y: (B x N) row stride ldy. */
 int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
                    int64_t ldy, int64_t batch, int K, int N, int act, const float* in_scale,
-                   const float* in_shift, float drop_p, uint64_t seed, uint32_t step,
-                   uint32_t site, int64_t row0, double* stats, brStream stream);
+                   const float* in_shift, float drop_p, const uint32_t* keep, double* stats,
+                   brStream stream);
 /* BatchNorm bookkeeping from the column sums (tiny): mean, biased var, scale = gamma*rstd,
  * shift = beta - mean*scale, moving stats <- momentum*moving + (1-momentum)*batch [TF-sem].
  * bstats (mean[N], rstd[N]) kept for the backward. */
@@ -206,17 +216,18 @@ int brBnInference(const float* gamma, const float* beta, const float* moving_mea
  *      of [dW | db], reduced by brReduceSlabs in a fixed order (bitwise reproducible; no float
  *      atomics).  n_slabs = brDenseBackwardSlabs(). */
 int brDenseBackwardSlabs(int64_t batch, int K, int N);
-/* dz_ws: caller scratch of brDenseBackwardWorkspaceFloats() floats (16-B aligned): dz = dL/dz of the
- * layer, written by the dx kernel and re-read by the dW kernel (two launches inside the call). */
+/* One launch (dz, dx and dW together, dz never leaves the CU: csrc/dense_bwd.hip) when K % 4 == N % 4 == 0 and every row is
+ * 16-B aligned; other shapes run a dx and a dW kernel with dz handed over through dz_ws: caller scratch of
+ * brDenseBackwardWorkspaceFloats() floats (16-B aligned).  keep: the bit plane of the layer's input dropout (brDropoutKeepBits),
+ * required exactly when in_drop_p > 0. */
 int64_t brDenseBackwardWorkspaceFloats(int64_t batch, int K, int N);
 int brDenseBackward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x,
                     int64_t ldx, const float* W, int64_t batch, int K, int N, int act,
                     const float* out_mean, const float* out_rstd, const float* out_gamma,
                     const double* bn_sums, double batch_total, const float* in_scale,
                     const float* in_shift, const float* in_mean, const float* in_rstd,
-                    float in_drop_p, uint32_t in_site, uint64_t seed, uint32_t step, int64_t row0,
-                    float* gx, int64_t ldgx, float* dz_ws, float* dW_slabs, int n_slabs,
-                    double* in_bn_sums, brStream stream);
+                    float in_drop_p, const uint32_t* keep, float* gx, int64_t ldgx, float* dz_ws,
+                    float* dW_slabs, int n_slabs, double* in_bn_sums, brStream stream);
 /* dgamma = sum gy*xhat, dbeta = sum gy: the BN-backward column sums as fp32 parameter grads. */
 int brBnParamGrads(const double* bn_sums, float* dgamma, float* dbeta, int N, brStream stream);
 int brBnParamGradsPair(const double* sums_a, float* dgamma_a, float* dbeta_a, int Na, const double* sums_b, float* dgamma_b,
@@ -235,7 +246,8 @@ int brDenseFinalize(const float* const* slabs, const int* n_slabs, const int64_t
 /* ---- fused tail of the training step: T(a2) -> Dense(n3) -> concat [dot | a3] -> Dense(1) -> sigmoid -> loss and the
  * backward of all of it, one launch (trainers/NFC_plain.py:143-155, src/models/NeuMFModel.py:75-93) ----
  * Same results as brDenseForward(layer 3) + brNeumfHead + brDenseBackward(layer 3) (fp32 sums in a different
- * order).  a2: (B x n2) raw output of layer 2; scale2/shift2/mean2/rstd2 from brBnFinalize; dropout site `site`.
+ * order).  a2: (B x n2) raw output of layer 2; scale2/shift2/mean2/rstd2 from brBnFinalize; keep: the bit plane of
+ * the dropout in front of layer 3 (brDropoutKeepBits; NULL with drop_p == 0).
  * Outputs: a3 (B x n3, may be NULL), logit/prob/ddot (B), gh2 (B x n2) = gradient w.r.t. BN2's output,
  * bn_sums (double[BR_STAT_REPLICAS][2*n2]) += (sum gh2, sum gh2*xhat2), sums as brNeumfHead, and one slab per
  * workgroup [dW3 (n2*n3) | db3 (n3) | dW4 (n3+1, concat order) | db4]: n_slabs = brNeumfTailSlabs(batch),
@@ -244,7 +256,7 @@ int brNeumfTailSlabs(int64_t batch);
 int64_t brNeumfTailSlabElems(int n2, int n3);
 int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, const float* b3, const float* w4, const float* b4,
                      const float* dot, const float* labels, const float* scale2, const float* shift2, const float* mean2,
-                     const float* rstd2, float drop_p, uint64_t seed, uint32_t step, uint32_t site, int64_t row0,
+                     const float* rstd2, float drop_p, const uint32_t* keep,
                      int64_t batch, int n2, int n3, int act, int mf_first, int loss, float inv_batch, float* a3,
                      float* logit, float* prob, double* sums, float* ddot, float* gh2, int64_t ldgh2, double* bn_sums,
                      float* slabs, int n_slabs, brStream stream);
@@ -340,13 +352,15 @@ typedef struct brNeumfStep {
   uint8_t* user_mark; uint8_t* item_mark;          /* [rows], adam_dense only */
   float* theta; float* grad; float* adam_m; float* adam_v;
   float* moving;                           /* [mm1 n1 | mv1 n1 | mm2 n2 | mv2 n2] */
-  float* x0; float* dot; float* a1; float* a2; float* a3; float* logit; float* prob;
+  float* x0; float* dot; float* a1; float* a2; float* a3; float* logit; float* prob;    /* a1 / gh1 and a2 / gh2: row stride n rounded up to 4 floats */
   float* da3; float* ddot; float* gh2; float* gh1; float* dx0; float* g_user; float* g_item;
   float* bn;                               /* [scale1|shift1|mean1|rstd1] n1 each, then the same for layer 2 */
   double* dstat;                           /* [stats1 | stats2 | bsum1 | bsum2], each [BR_STAT_REPLICAS][2n]; zeroed in FWD1 */
   double* msums;                           /* [BR_SUM_SLOTS][loss, sum sq err, sum abs err, #correct] accumulated */
   float* slabs; float* hslabs;
   float* dz_ws;                            /* brDenseBackwardWorkspaceFloats(max layer) floats */
+  uint32_t* keep_bits;                     /* the three dropout planes of a step back to back: brDropoutKeepWords(batch, 2*dim) +
+                                              (batch, n1) + (batch, n2) words (training with dropout > 0) */
   int* err_flag;
   float* u_seg_ws; float* i_seg_ws;        /* brSegmentScratchFloats(max batch, 2*dim) each, or NULL (one-by-one duplicate sums) */
   void* u_sorted_ids; int32_t* u_sorted_pos; void* u_ws; int64_t u_ws_bytes;

@@ -39,7 +39,9 @@ def test_neumf_step_vs_golden(dev, name, variant, dim):
         ref = z["rg_" + k]
         np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=k)
     for k in ("user_mf", "item_mlp"):
-        np.testing.assert_allclose(eng.tables[k].cpu().numpy(), z["adam1_" + k], rtol=1e-5, atol=5e-3 * cfg.lr, err_msg=k)
+        # the first Adam step is lr * g / (|g| + eps): sign-like, so an element whose gradient sits at the fp32 noise floor can move
+        # by a visible fraction of lr; same small-batch factor as the gradient checks above
+        np.testing.assert_allclose(eng.tables[k].cpu().numpy(), z["adam1_" + k], rtol=1e-5, atol=f * 5e-3 * cfg.lr, err_msg=k)
         assert np.median(np.abs(eng.tables[k].cpu().numpy() - z["adam1_" + k])) <= 1e-7
 
 
