@@ -1,4 +1,5 @@
-// Argument block and host entry of the fused one-launch backward (dense_bwd.hip), called from brDenseBackward (mlp.hip).
+// Argument blocks and host entries shared between translation units: the fused one-launch backward (dense_bwd.hip, called from
+// brDenseBackward in mlp.hip) and the MFMA tail (tail_mfma.hip, called from brNeumfTailFused in tail.hip).
 #pragma once
 #include "common.h"
 
@@ -22,5 +23,25 @@ struct BwdArgs {
 int dense_backward_fused(const BwdArgs& a, hipStream_t s);    // BR_ERR_UNSUPPORTED when the LDS image does not fit
 int dense_bwd_fused_grid(int64_t batch);                      // workgroups = slabs written
 size_t dense_bwd_fused_lds(int NT, int KT);
+
+// tail_mfma.hip
+struct TailMArgs {
+  const float* a2; int64_t lda2;
+  const float *W3, *b3, *w4, *b4, *dot, *labels;
+  // BatchNorm 2: either ready-made constants (scale2 != null) or the forward column sums to finalize in the launch (stats2 != null)
+  const float *scale2, *shift2, *mean2, *rstd2;
+  const double* stats2; double batch_total; const float *gamma2, *beta2; float bn_eps, bn_momentum;
+  float *moving_mean, *moving_var, *out_scale, *out_shift, *out_mean, *out_rstd;     // written by workgroup 0 when finalizing
+  const uint32_t* keep; int kw; float inv_keep;
+  int64_t batch;
+  int n2, n3, act, mf_first, loss;
+  float inv_batch;
+  float *a3, *logit, *prob, *ddot, *gh2;
+  int64_t ldgh2;
+  double *msums, *bn_sums;
+  float* slabs;
+};
+int tail_mfma_grid(int64_t batch);
+void launch_tail_mfma(const TailMArgs& a, int grid, hipStream_t s);
 
 }  // namespace br

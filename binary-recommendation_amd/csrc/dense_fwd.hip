@@ -124,6 +124,7 @@ struct FwdArgs {
   int64_t batch;
   int K, N, act;
   const float* scale; const float* shift;   // (K) BatchNorm affine of the producer, or null
+  brBnFold bn;                              // bn.stats != null: the affine is finalized here from the producer's column sums
   const uint32_t* keep; int kw;             // keep-bit plane [batch][kw] of this layer's input dropout, or null
   float inv_keep;                           // 1/(1-p) (1 without dropout)
   double* stats;                            // [kRep][2N] or null
@@ -279,8 +280,27 @@ __global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs
     }
   }
   for (int k = threadIdx.x; k < Kp; k += kFwdThreads) {     // identity where there is no BatchNorm, zero past K
-    ssb[k] = k < K ? (a.scale ? a.scale[k] : 1.f) : 0.f;
-    ssb[Kp + k] = (a.scale && k < K) ? a.shift[k] : 0.f;
+    float sc = k < K ? 1.f : 0.f, sh = 0.f;
+    if (k < K && a.bn.stats) {      // BatchNorm finalize (as bn_finalize_kernel): biased batch variance [TF-sem]; workgroup 0 publishes
+      double s1 = 0.0, s2 = 0.0;
+      for (int r = 0; r < kRep; ++r) { s1 += a.bn.stats[(size_t)r * 2 * K + k]; s2 += a.bn.stats[(size_t)r * 2 * K + K + k]; }
+      const double mu = s1 / a.bn.batch_total;
+      double var = s2 / a.bn.batch_total - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const float muf = (float)mu, varf = (float)var;
+      const float rs = 1.0f / sqrtf(varf + a.bn.eps);
+      sc = a.bn.gamma[k] * rs;
+      sh = a.bn.beta[k] - muf * sc;
+      if (blockIdx.x == 0) {
+        a.bn.scale[k] = sc; a.bn.shift[k] = sh; a.bn.mean[k] = muf; a.bn.rstd[k] = rs;
+        if (a.bn.moving_mean) {
+          a.bn.moving_mean[k] = a.bn.moving_mean[k] * a.bn.momentum + muf * (1.0f - a.bn.momentum);
+          a.bn.moving_var[k] = a.bn.moving_var[k] * a.bn.momentum + varf * (1.0f - a.bn.momentum);
+        }
+      }
+    } else if (k < K && a.scale) { sc = a.scale[k]; sh = a.shift[k]; }
+    ssb[k] = sc;
+    ssb[Kp + k] = sh;
   }
   for (int n = threadIdx.x; n < Np; n += kFwdThreads) bs[n] = (a.bias && n < N) ? a.bias[n] : 0.f;
   BR_STAMP(2);
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs
     const int64_t rbase = tile << 4;
     // ---- T(): BN affine + dropout keep bits, in registers (fenced per 16-column block: left alone the compiler hoists every
     //      block's scale / shift reads and spills) ----
-    const bool affine = a.scale || 16 * KJ != K;      // the affine also zeroes the columns >= K of the last block
+    const bool affine = a.scale || a.bn.stats || 16 * KJ != K;      // the affine also zeroes the columns >= K of the last block
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
       if (affine) {
@@ -465,17 +485,21 @@ static inline int split_k(int K) { return ((K / 2 + 31) / 32) * 32; }
 
 extern "C" int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
                               int64_t batch, int K, int N, int act, const float* in_scale, const float* in_shift,
-                              float drop_p, const uint32_t* keep, double* stats, brStream stream) {
+                              const brBnFold* in_bn, float drop_p, const uint32_t* keep, double* stats, brStream stream) {
   BR_CHECK_ARG(x && W && y && batch >= 0 && K >= 1 && N >= 1, "brDenseForward: bad args");
   BR_CHECK_ARG(K <= 2 * kMaxT * 16 && N <= kMaxT * 16, "brDenseForward: K=%d N=%d exceed %d / %d", K, N, 2 * kMaxT * 16, kMaxT * 16);
   BR_CHECK_ARG(ldx >= K && ldy >= N, "brDenseForward: bad leading dims");
   BR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "brDenseForward: in_scale/in_shift both or neither");
+  BR_CHECK_ARG(!in_bn || (!in_scale && in_bn->stats && in_bn->gamma && in_bn->beta && in_bn->scale && in_bn->shift && in_bn->mean && in_bn->rstd &&
+                          in_bn->batch_total > 0 && (in_bn->moving_mean == nullptr) == (in_bn->moving_var == nullptr) && K <= kMaxT * 16),
+               "brDenseForward: in_bn needs stats, gamma, beta and the four outputs, no in_scale/in_shift, K <= %d", kMaxT * 16);
   BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brDenseForward: drop_p out of [0,1)");
   BR_CHECK_ARG((drop_p > 0.f) == (keep != nullptr), "brDenseForward: keep bits (brDropoutKeepBits) are required exactly when drop_p > 0");
   if (batch == 0) return BR_OK;
   hipStream_t s = (hipStream_t)stream;
   const int kw = (K + 31) / 32;
-  FwdArgs a{x, ldx, W, bias, y, ldy, batch, K, N, act, in_scale, in_shift, keep, kw, drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, stats, nullptr};
+  brBnFold nofold{};
+  FwdArgs a{x, ldx, W, bias, y, ldy, batch, K, N, act, in_scale, in_shift, in_bn ? *in_bn : nofold, keep, kw, drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, stats, nullptr};
   if (K <= kMaxT * 16) return dense_forward_one(a, s);
   const int Ka = split_k(K);
   FwdArgs h = a;

@@ -191,28 +191,27 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       if (rc != BR_OK) return rc;
       (void)hipEventRecord(g_join, as);
     }
-    RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, l1, B, 2 * D, n1, s->act, nullptr, nullptr, p, keep0,
+    RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, l1, B, 2 * D, n1, s->act, nullptr, nullptr, nullptr, p, keep0,
                        train ? stats1 : nullptr, stream));
   }
   if (ph & BR_PH_FWD2) {
-    if (train)
-      RUN(BR_TAG_SMALL, brBnFinalize(stats1, bt_bn, th + og1, th + obe1, s->bn_eps, s->bn_momentum, mm1, mv1, scale1, shift1, mean1, rstd1, n1, stream));
-    else
+    // training: BatchNorm 1 is finalized inside the layer-2 launch (brBnFold), BatchNorm 2 inside the tail launch
+    brBnFold f1{stats1, bt_bn, th + og1, th + obe1, s->bn_eps, s->bn_momentum, mm1, mv1, scale1, shift1, mean1, rstd1};
+    if (!train)
       RUN(BR_TAG_SMALL, brBnInference(th + og1, th + obe1, mm1, mv1, s->bn_eps, scale1, shift1, n1, stream));
-    RUN(BR_TAG_FWD_L2, brDenseForward(s->a1, l1, th + oW2, th + ob2, s->a2, l2, B, n1, n2, s->act, scale1, shift1, p, keep1,
-                       train ? stats2 : nullptr, stream));
+    RUN(BR_TAG_FWD_L2, brDenseForward(s->a1, l1, th + oW2, th + ob2, s->a2, l2, B, n1, n2, s->act, train ? nullptr : scale1, train ? nullptr : shift1,
+                       train ? &f1 : nullptr, p, keep1, train ? stats2 : nullptr, stream));
   }
   if (ph & BR_PH_FWD3) {
-    if (train)
-      RUN(BR_TAG_SMALL, brBnFinalize(stats2, bt_bn, th + og2, th + obe2, s->bn_eps, s->bn_momentum, mm2, mv2, scale2, shift2, mean2, rstd2, n2, stream));
-    else
+    brBnFold f2{stats2, bt_bn, th + og2, th + obe2, s->bn_eps, s->bn_momentum, mm2, mv2, scale2, shift2, mean2, rstd2};
+    if (!train)
       RUN(BR_TAG_SMALL, brBnInference(th + og2, th + obe2, mm2, mv2, s->bn_eps, scale2, shift2, n2, stream));
     if (!train)
-      RUN(BR_TAG_FWD_L3, brDenseForward(s->a2, l2, th + oW3, th + ob3, s->a3, n3, B, n2, n3, s->act, scale2, shift2, 0.f, nullptr, nullptr, stream));
+      RUN(BR_TAG_FWD_L3, brDenseForward(s->a2, l2, th + oW3, th + ob3, s->a3, n3, B, n2, n3, s->act, scale2, shift2, nullptr, 0.f, nullptr, nullptr, stream));
     if (train) {
       // L3 forward, head, loss and their backward in one launch; W3|b3|W4|b4 are adjacent in theta / grad
       const int nst = sp.ns_t;
-      RUN(BR_TAG_HEAD, brNeumfTailFused(s->a2, l2, th + oW3, th + ob3, th + oW4, th + ob4, s->dot, s->labels, scale2, shift2, mean2, rstd2, p, keep2,
+      RUN(BR_TAG_HEAD, brNeumfTailFused(s->a2, l2, th + oW3, th + ob3, th + oW4, th + ob4, s->dot, s->labels, nullptr, nullptr, nullptr, nullptr, &f2, p, keep2,
                       B, n2, n3, s->act, s->mf_first, s->loss, inv_b, s->a3, s->logit, s->prob, s->msums, s->ddot,
                       s->gh2, l2, bsum2, slabs_t, nst, stream));
       if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs_t, nst, sp.el_t, gr + oW3, stream));

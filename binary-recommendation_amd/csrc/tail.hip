@@ -15,6 +15,7 @@
 // access staged through LDS tiles (coalesced in, coalesced out).  128 rows per workgroup, 4 lanes per row
 // (one thread per row left a single wave per SIMD with every LDS latency exposed: 57 us), 2 tiles of LDS.
 #include "common.h"
+#include "dense.h"
 
 namespace br {
 
@@ -269,18 +270,51 @@ extern "C" int64_t brNeumfTailSlabElems(int n2, int n3) { return (int64_t)n2 * n
 
 extern "C" int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, const float* b3, const float* w4, const float* b4,
                                 const float* dot, const float* labels, const float* scale2, const float* shift2, const float* mean2,
-                                const float* rstd2, float drop_p, const uint32_t* keep,
+                                const float* rstd2, const brBnFold* bn2, float drop_p, const uint32_t* keep,
                                 int64_t batch, int n2, int n3, int act, int mf_first, int loss, float inv_batch, float* a3,
                                 float* logit, float* prob, double* sums, float* ddot, float* gh2, int64_t ldgh2, double* bn_sums,
                                 float* slabs, int n_slabs, brStream stream) {
-  BR_CHECK_ARG(a2 && W3 && b3 && w4 && b4 && dot && labels && scale2 && shift2 && mean2 && rstd2 && logit && prob && ddot && gh2 && slabs,
-               "brNeumfTailFused: null pointer");
+  BR_CHECK_ARG(a2 && W3 && b3 && w4 && b4 && dot && labels && logit && prob && ddot && gh2 && slabs, "brNeumfTailFused: null pointer");
+  BR_CHECK_ARG(bn2 ? (!scale2 && !shift2 && !mean2 && !rstd2 && bn2->stats && bn2->gamma && bn2->beta && bn2->scale && bn2->shift && bn2->mean && bn2->rstd &&
+                      bn2->batch_total > 0 && (bn2->moving_mean == nullptr) == (bn2->moving_var == nullptr))
+                   : (scale2 && shift2 && mean2 && rstd2),
+               "brNeumfTailFused: BatchNorm 2 either as scale2/shift2/mean2/rstd2 or as bn2 (stats, gamma, beta and the four outputs)");
   BR_CHECK_ARG(batch >= 0 && n2 >= 1 && n2 <= 128 && n3 >= 1 && n3 <= 32 && lda2 >= n2 && ldgh2 >= n2, "brNeumfTailFused: bad sizes");
   BR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "brNeumfTailFused: drop_p out of [0,1)");
   BR_CHECK_ARG((drop_p > 0.f) == (keep != nullptr), "brNeumfTailFused: keep bits (brDropoutKeepBits) are required exactly when drop_p > 0");
   BR_CHECK_ARG(loss == BR_LOSS_BCE || loss == BR_LOSS_MSE, "brNeumfTailFused: bad loss");
   if (batch == 0) return BR_OK;
   BR_CHECK_ARG(n_slabs == brNeumfTailSlabs(batch), "brNeumfTailFused: n_slabs must be brNeumfTailSlabs(batch)");
+  hipStream_t s = (hipStream_t)stream;
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (n2 <= 64 && n3 <= 16 && lda2 % 4 == 0 && ldgh2 % 4 == 0 && al16(a2) && al16(gh2)) {
+    TailMArgs m{};
+    m.a2 = a2; m.lda2 = lda2; m.W3 = W3; m.b3 = b3; m.w4 = w4; m.b4 = b4; m.dot = dot; m.labels = labels;
+    m.scale2 = scale2; m.shift2 = shift2; m.mean2 = mean2; m.rstd2 = rstd2;
+    if (bn2) {
+      m.stats2 = bn2->stats; m.batch_total = bn2->batch_total; m.gamma2 = bn2->gamma; m.beta2 = bn2->beta; m.bn_eps = bn2->eps; m.bn_momentum = bn2->momentum;
+      m.moving_mean = bn2->moving_mean; m.moving_var = bn2->moving_var; m.out_scale = bn2->scale; m.out_shift = bn2->shift; m.out_mean = bn2->mean; m.out_rstd = bn2->rstd;
+    }
+    m.keep = keep; m.kw = (n2 + 31) / 32; m.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    m.batch = batch; m.n2 = n2; m.n3 = n3; m.act = act; m.mf_first = mf_first; m.loss = loss; m.inv_batch = inv_batch;
+    m.a3 = a3; m.logit = logit; m.prob = prob; m.ddot = ddot; m.gh2 = gh2; m.ldgh2 = ldgh2; m.msums = sums; m.bn_sums = bn_sums; m.slabs = slabs;
+    int grid = tail_mfma_grid(batch);
+    if (grid > n_slabs) grid = n_slabs;
+    if (grid < n_slabs) {     // the slab count is sized for the 128-row workgroups of the VALU form: unused slabs must read as zeros
+      const int64_t el = brNeumfTailSlabElems(n2, n3);
+      hipError_t e = hipMemsetAsync(slabs + (int64_t)grid * el, 0, sizeof(float) * (size_t)(n_slabs - grid) * (size_t)el, s);
+      if (e != hipSuccess) { set_error("brNeumfTailFused: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
+    }
+    launch_tail_mfma(m, grid, s);
+    BR_CHECK_LAUNCH("brNeumfTailFused(mfma)");
+    return BR_OK;
+  }
+  if (bn2) {   // VALU form: finalize first
+    int rc = brBnFinalize(bn2->stats, bn2->batch_total, bn2->gamma, bn2->beta, bn2->eps, bn2->momentum, bn2->moving_mean, bn2->moving_var, bn2->scale,
+                          bn2->shift, bn2->mean, bn2->rstd, n2, stream);
+    if (rc != BR_OK) return rc;
+    scale2 = bn2->scale; shift2 = bn2->shift; mean2 = bn2->mean; rstd2 = bn2->rstd;
+  }
   TailArgs a;
   a.a2 = a2; a.lda2 = lda2; a.W3 = W3; a.b3 = b3; a.w4 = w4; a.b4 = b4; a.dot = dot; a.labels = labels;
   a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rstd2 = rstd2;
@@ -291,7 +325,6 @@ extern "C" int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, 
   const int n3p = (n3 + 3) & ~3;
   const size_t lds = tail_lds_bytes(n2, n3p);
   const unsigned grid = (unsigned)n_slabs;
-  hipStream_t s = (hipStream_t)stream;
 #define BR_TAIL(NP)                                                                                                       \
   case NP: {                                                                                                              \
     static bool attr = false;                                                                                             \

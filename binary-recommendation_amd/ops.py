@@ -293,7 +293,7 @@ def dense_forward(x, W, bias, y, act, in_scale=None, in_shift=None, drop_p=0.0, 
     if drop_p > 0 and keep is None and B > 0:
         keep = dropout_keep_bits(drop_p, seed, step, row0, B, [site], [K])[0]
     check(_lib.load().brDenseForward(x.data_ptr(), x.stride(0), _f32(W, "W").data_ptr(), _p(bias), y.data_ptr(), y.stride(0),
-                                     B, K, N, ACT[act], _p(in_scale), _p(in_shift), float(drop_p), _p(keep) if drop_p > 0 else 0,
+                                     B, K, N, ACT[act], _p(in_scale), _p(in_shift), None, float(drop_p), _p(keep) if drop_p > 0 else 0,
                                      _p(stats), _stream()), "brDenseForward")
 
 

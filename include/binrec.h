@@ -178,10 +178,24 @@ int64_t brDropoutKeepWords(int64_t batch, int K);
 int brDropoutKeepBits(float drop_p, uint64_t seed, uint32_t step, int64_t row0, int64_t batch, int n_sites,
                       const uint32_t* sites, const int* widths, uint32_t* const* out, brStream stream);
 
+/* BatchNorm finalize folded into the consumer of the normalised activations (brDenseForward / brNeumfTailFused): the
+ * consumer's workgroups each turn the producer's column sums into scale / shift in their prologue (a few hundred flops),
+ * workgroup 0 also writes scale / shift / mean / rstd (N each, kept for the backward) and updates the moving statistics -
+ * the same arithmetic as brBnFinalize without its launch. */
+typedef struct brBnFold {
+  const double* stats;        /* [BR_STAT_REPLICAS][2N] column sums of y, y^2 */
+  double batch_total;         /* rows behind the sums */
+  const float* gamma; const float* beta;
+  float eps; float momentum;
+  float* moving_mean; float* moving_var;            /* may be NULL (both) */
+  float* scale; float* shift; float* mean; float* rstd;   /* outputs */
+} brBnFold;
+
 /* ---- T1-T4: MLP tower layer, fp32 MFMA (v_mfma_f32_16x16x4_f32) ----------------------------
  * Dense/BatchNormalization/Dropout: NFC_plain.py:138-147, NeuMFModel.py:67-78, twoTower.py:40-41.
  * y = act( T(x)·W + bias ),  T(x)[r,k] = (x[r,k]*in_scale[k] + in_shift[k]) * keep(r,k)/(1-p)
- *   in_scale/in_shift (K) NULL => identity (they carry the previous layer's BatchNorm);
+ *   in_scale/in_shift (K) NULL => identity (they carry the previous layer's BatchNorm); in_bn != NULL (then in_scale and
+ *   in_shift must be NULL): the BatchNorm is finalized from its column sums in this launch (brBnFold);
  *   drop_p == 0 (keep NULL) => no dropout; else keep = the site's bit plane (brDropoutKeepBits).
  * stats (double[BR_STAT_REPLICAS][2N], may be NULL): += column sums of y and y^2 (BatchNorm batch
  *   statistics), spread over 8 replicas (workgroup % 8) so same-address atomics do not serialise;
@@ -190,8 +204,8 @@ int brDropoutKeepBits(float drop_p, uint64_t seed, uint32_t step, int64_t row0, 
  * x: (B x K) row stride ldx; W: (K x N) row-major; y: (B x N) row stride ldy. */
 int brDenseForward(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
                    int64_t ldy, int64_t batch, int K, int N, int act, const float* in_scale,
-                   const float* in_shift, float drop_p, const uint32_t* keep, double* stats,
-                   brStream stream);
+                   const float* in_shift, const brBnFold* in_bn, float drop_p, const uint32_t* keep,
+                   double* stats, brStream stream);
 /* BatchNorm bookkeeping from the column sums (tiny): mean, biased var, scale = gamma*rstd,
  * shift = beta - mean*scale, moving stats <- momentum*moving + (1-momentum)*batch [TF-sem].
  * bstats (mean[N], rstd[N]) kept for the backward. */
@@ -246,7 +260,8 @@ int brDenseFinalize(const float* const* slabs, const int* n_slabs, const int64_t
 /* ---- fused tail of the training step: T(a2) -> Dense(n3) -> concat [dot | a3] -> Dense(1) -> sigmoid -> loss and the
  * backward of all of it, one launch (trainers/NFC_plain.py:143-155, src/models/NeuMFModel.py:75-93) ----
  * Same results as brDenseForward(layer 3) + brNeumfHead + brDenseBackward(layer 3) (fp32 sums in a different
- * order).  a2: (B x n2) raw output of layer 2; scale2/shift2/mean2/rstd2 from brBnFinalize; keep: the bit plane of
+ * order).  a2: (B x n2) raw output of layer 2; scale2/shift2/mean2/rstd2 from brBnFinalize, or all NULL with bn2 given
+ * (BatchNorm 2 finalized inside this launch, brBnFold); n2 <= 64, n3 <= 16 and 16-B aligned rows run on MFMA (csrc/tail_mfma.hip); keep: the bit plane of
  * the dropout in front of layer 3 (brDropoutKeepBits; NULL with drop_p == 0).
  * Outputs: a3 (B x n3, may be NULL), logit/prob/ddot (B), gh2 (B x n2) = gradient w.r.t. BN2's output,
  * bn_sums (double[BR_STAT_REPLICAS][2*n2]) += (sum gh2, sum gh2*xhat2), sums as brNeumfHead, and one slab per
@@ -256,7 +271,7 @@ int brNeumfTailSlabs(int64_t batch);
 int64_t brNeumfTailSlabElems(int n2, int n3);
 int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, const float* b3, const float* w4, const float* b4,
                      const float* dot, const float* labels, const float* scale2, const float* shift2, const float* mean2,
-                     const float* rstd2, float drop_p, const uint32_t* keep,
+                     const float* rstd2, const brBnFold* bn2, float drop_p, const uint32_t* keep,
                      int64_t batch, int n2, int n3, int act, int mf_first, int loss, float inv_batch, float* a3,
                      float* logit, float* prob, double* sums, float* ddot, float* gh2, int64_t ldgh2, double* bn_sums,
                      float* slabs, int n_slabs, brStream stream);

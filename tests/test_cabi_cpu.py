@@ -47,7 +47,7 @@ def test_argument_errors_are_reported_not_crashed(built):
     h = lib.load()
     rc = h.brRowDot(None, None, None, 64, 10, None)          # null pointers -> BR_ERR_ARG before any launch
     assert rc == -1 and b"brRowDot" in h.brGetLastError()
-    rc = h.brDenseForward(None, 0, None, None, None, 0, 0, 1, 1, 0, None, None, 0.0, 0, 0, 0, 0, None, None)
+    rc = h.brDenseForward(None, 0, None, None, None, 0, 0, 1, 1, 0, None, None, None, 0.0, None, None, None)
     assert rc == -1
     with pytest.raises(lib.BinrecError):
         lib.check(rc, "brDenseForward")
