@@ -96,9 +96,12 @@ __global__ __launch_bounds__(256) void keep_bits_kernel(KeepArgs a) {
   for (int i = 0; i < 10; ++i) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const uint64_t p0 = (uint64_t)0xD2511F53u * c0[c], p1 = (uint64_t)0xCD9E8D57u * c2[c];
-      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1[c] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3[c] ^ k1;
-      c0[c] = n0; c1[c] = (uint32_t)p1; c2[c] = n2; c3[c] = (uint32_t)p0;
+      // 32x32 -> hi / lo as v_mul_hi_u32 + v_mul_lo_u32: the 64-bit product form compiles to v_mad_u64_u32, which measured
+      // ~78 cycles per wave instruction on gfx950 (27 us for the three planes of a step)
+      const uint32_t h0 = __umulhi(0xD2511F53u, c0[c]), l0 = 0xD2511F53u * c0[c];
+      const uint32_t h1 = __umulhi(0xCD9E8D57u, c2[c]), l1 = 0xCD9E8D57u * c2[c];
+      const uint32_t n0 = h1 ^ c1[c] ^ k0, n2 = h0 ^ c3[c] ^ k1;
+      c0[c] = n0; c1[c] = l1; c2[c] = n2; c3[c] = l0;
     }
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

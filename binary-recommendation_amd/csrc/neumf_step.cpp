@@ -237,9 +237,12 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     RUN(BR_TAG_SMALL, brBnParamGradsPair(bsum2, gr + og2, gr + obe2, n2, bsum1, gr + og1, gr + obe1, n1, stream));
   }
   if (ph & BR_PH_OPT_TABLES) {
-    if ((ph & BR_PH_EMBED) && deferred)
+    // deferred: the forward stashed the MF rows; their gradients ddot[b] * partner row are formed by the optimizer launch as it
+    // reads them (brAdamRowsSortedPair hi_scale) - unless the two tables are updated by separate calls
+    const bool both = (ph & BR_PH_ROWS_USER) && (ph & BR_PH_ROWS_ITEM);
+    if ((ph & BR_PH_EMBED) && deferred && !both)
       RUN(BR_TAG_EMBED_BWD, brMfGradInplace(s->g_user + D, s->g_item + D, 2 * D, s->ddot, B, D, stream));
-    else if (ph & BR_PH_EMBED)
+    else if ((ph & BR_PH_EMBED) && !deferred)
       RUN(BR_TAG_EMBED_BWD, brNeumfEmbedBackward(s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows, s->users, s->items, s->id_type, D,
                                B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, stream));
   }
@@ -256,13 +259,15 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     uint8_t* im = s->adam_dense == 1 ? s->item_mark : nullptr;
     const bool both_rows = (ph & BR_PH_ROWS_USER) && (ph & BR_PH_ROWS_ITEM);
     if (both_rows) {
-      // the two fused tables in one launch (they share dim, batch, split): the sweeps of adam_dense == 1 follow
+      // the two fused tables in one launch (they share dim, batch, split): the sweeps of adam_dense == 1 follow.
+      // deferred + EMBED: g_user / g_item still hold the stashed MF rows, so each table reads the PARTNER's stash times ddot
+      const bool fuse_mf = deferred && (ph & BR_PH_EMBED) && (ph & BR_PH_OPT_TABLES);
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedPair(
-              s->user_tab, s->user_m, s->user_v, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, um,
+              s->user_tab, s->user_m, s->user_v, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->dx0 + uoff, 2 * D, (fuse_mf ? s->g_item : s->g_user) + D, 2 * D, um,
               deferred ? s->user_last : nullptr,
-              s->item_tab, s->item_m, s->item_v, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->dx0 + ioff, 2 * D, s->g_item + D, 2 * D, im,
-              deferred ? s->item_last : nullptr, 2 * D, s->id_type, B, D, s->step_state, s->alpha_t, s->beta1, s->beta2, s->adam_eps, s->u_seg_ws,
-              s->i_seg_ws, stream));
+              s->item_tab, s->item_m, s->item_v, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->dx0 + ioff, 2 * D, (fuse_mf ? s->g_user : s->g_item) + D, 2 * D, im,
+              deferred ? s->item_last : nullptr, 2 * D, s->id_type, B, D, fuse_mf ? s->ddot : nullptr, s->step_state, s->alpha_t, s->beta1, s->beta2, s->adam_eps,
+              s->u_seg_ws, s->i_seg_ws, stream));
     } else if ((ph & BR_PH_ROWS_USER) && deferred) {
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type,
                            s->u_sorted_pos, B, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, s->u_seg_ws, stream));

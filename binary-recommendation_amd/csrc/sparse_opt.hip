@@ -52,15 +52,23 @@ __device__ __forceinline__ bool segment_head(const IdT* sid, int64_t i) {
 // with P_b = ((g_64b + g_64b+1) + ..) - restated by the oracle (ordered_segment_sum); without a buffer: one by one.
 constexpr int kSegBlock = 64;
 
+// a row of per-pair gradients: g[pos], times sc[pos] when the source carries a per-position factor (the MF halves of a NeuMF
+// step: the stashed partner row times ddot[pos] - the product the embed backward used to write out as its own launch)
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type grow(const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc, int32_t pos) {
+  const typename VecT<VEC>::type v = vload<VEC>(g + (int64_t)pos * ldg);
+  return sc ? vmul(v, sc[pos]) : v;
+}
+
 template <typename IdT, int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type seg_acc(const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n, int64_t i,
-                                                            IdT row, const float* __restrict__ g, int64_t ldg,
+                                                            IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc,
                                                             const float* __restrict__ part, int pdim) {
   using V = typename VecT<VEC>::type;
-  V acc = vload<VEC>(g + (int64_t)spos[i] * ldg);
+  V acc = grow<VEC>(g, ldg, sc, spos[i]);
   const int64_t own_end = part ? ((i / kSegBlock + 1) * kSegBlock < n ? (i / kSegBlock + 1) * kSegBlock : n) : n;
   int64_t j = i + 1;
-  for (; j < own_end && sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg));
+  for (; j < own_end && sid[j] == row; ++j) acc = vadd(acc, grow<VEC>(g, ldg, sc, spos[j]));
   if (part && j == own_end)
     for (; j < n && sid[j] == row; j += kSegBlock) acc = vadd(acc, vload<VEC>(part + (j / kSegBlock) * pdim));
   return acc;
@@ -71,6 +79,7 @@ struct SegJob {                // one table's gradient source for the partials
   const float* g0; int64_t ldg0;
   const float* g1; int64_t ldg1;
   float* part;                 // [ceil(n / kSegBlock)][dim]
+  const float* sc1 = nullptr;  // per-position factor of g1 rows, or null (last: positional initialisers of the other users stay valid)
 };
 struct SegJobs { SegJob j[2]; };
 
@@ -93,8 +102,9 @@ __global__ __launch_bounds__(256) void segment_partials_kernel(SegJobs jobs, int
     const int col = c * VEC;
     const float* g = col < split ? jb.g0 + col : jb.g1 + (col - split);
     const int64_t ldg = col < split ? jb.ldg0 : jb.ldg1;
-    V acc = vload<VEC>(g + (int64_t)spos[i] * ldg);
-    for (int64_t j = i + 1; j < end && sid[j] == row; ++j) acc = vadd(acc, vload<VEC>(g + (int64_t)spos[j] * ldg));
+    const float* sc = col < split ? nullptr : jb.sc1;
+    V acc = grow<VEC>(g, ldg, sc, spos[i]);
+    for (int64_t j = i + 1; j < end && sid[j] == row; ++j) acc = vadd(acc, grow<VEC>(g, ldg, sc, spos[j]));
     vstore<VEC>(jb.part + b * dim + col, acc);
   }
 }
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const IdT* __restrict_
   if (!head) return;
   const IdT row = sid[i];
   for (int c = lir; c < chunks; c += lpr) {
-    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, row, g + c * VEC, ldg, part ? part + c * VEC : nullptr, dim);
+    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, row, g + c * VEC, ldg, nullptr, part ? part + c * VEC : nullptr, dim);
     vstore<VEC>(out + i * dim + c * VEC, acc);
   }
 }
@@ -130,6 +140,7 @@ struct AdamRowsJob {
   const void* sid; const int32_t* spos;
   const float* g0; int64_t ldg0;
   const float* g1; int64_t ldg1;
+  const float* sc1;           // per-position factor of g1 rows, or null
   const float* part;          // segment partials of this table's gradient source (NULL: one-by-one walk)
   uint8_t* mark; int32_t* last;
 };
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs
     const int col = c * VEC;
     const float* g = col < split ? g0 + col : g1 + (col - split);
     const int64_t ldg = col < split ? ldg0 : ldg1;
-    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, sid[i], g, ldg, jb.part ? jb.part + col : nullptr, dim);
+    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, sid[i], g, ldg, col < split ? nullptr : jb.sc1, jb.part ? jb.part + col : nullptr, dim);
     const int64_t off = row * dim + col;
     V th = vload<VEC>(table + off), m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
     if (last && seen + 1 < t) adam_replay(th, m, v, seen, t - 1, ring, h);
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void adagrad_rows_sorted_kernel(float* __restr
   const int64_t row = (int64_t)sid[i];
   if ((uint64_t)row >= (uint64_t)table_rows) return;
   for (int c = lir; c < chunks; c += lpr) {
-    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, sid[i], g + c * VEC, ldg, part ? part + c * VEC : nullptr, dim);
+    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, sid[i], g + c * VEC, ldg, nullptr, part ? part + c * VEC : nullptr, dim);
     const int64_t off = row * dim + c * VEC;
     V th = vload<VEC>(table + off), a = vload<VEC>(A + off);
     adagrad_update(th, a, acc, lr, eps);
@@ -349,14 +360,18 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 // ---- dedup index for small batches: 2 launches instead of hipcub's ~10 per id stream ------------------------
 // hipcub::DeviceRadixSort on 65 536 pairs is a block sort + 6 merge passes (+ iota): ~10 launches of ~5 us each,
 // and a hipGraph replay runs them on the critical path (rocprofv3 timeline, ROCm 7.2).  For n <= kRankMaxN:
-//   K1 chunk_sort_kernel : every workgroup radix-sorts one chunk of 2048 (id, position) pairs in LDS (stable);
+//   K1 chunk_sort_kernel : every workgroup radix-sorts one chunk of (id, position) pairs in LDS (stable);
 //   K2 chunk_rank_kernel : the final rank of an element = its index in its chunk + for every other chunk the
 //                          number of keys that sort before it (binary search: "<=" in earlier chunks, "<" in
-//                          later ones = stable), then one scatter.  32 chunks x 12 probes per element at n = 65 536, all in L2.
+//                          later ones = stable), then one scatter.
+// Chunk size: 2048 pairs (256 threads) up to 16 384 keys, 8192 pairs (1024 threads) above.  Round 1 used 2048 throughout:
+// at n = 65 536 that is 31 other chunks x 11 probes = 341 dependent L2 probes per key, 25 us alone and 90 us beside the
+// MLP kernels it overlaps (15 % of all GPU time in the rocprofv3 trace).  8 chunks of 8192 need 7 x 13 = 91 probes.
 // Both id streams of a step share the two launches (blockIdx.y).  Out-of-range ids get the key `upper`
 // (>= table rows: the optimizer kernels skip them), so only bits_for(upper + 2) key bits are sorted.
-constexpr int kChunk = 2048, kSortThreads = 256, kRankMaxChunks = 64;
-constexpr int64_t kRankMaxN = (int64_t)kChunk * kRankMaxChunks;
+constexpr int kChunkS = 2048, kThreadsS = 256, kChunkL = 8192, kThreadsL = 1024, kRankMaxChunks = 64;
+constexpr int64_t kChunkSwitchN = 16384;
+constexpr int64_t kRankMaxN = (int64_t)kChunkL * kRankMaxChunks;
 struct IdxJob {
   const void* ids;
   void* sorted_ids;
@@ -368,7 +383,7 @@ struct IdxJob {
 };
 struct IdxJobs { IdxJob j[2]; };
 
-template <typename IdT>
+template <typename IdT, int kChunk, int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, int64_t n) {
   constexpr int IPT = kChunk / kSortThreads;
   using Sort = hipcub::BlockRadixSort<uint32_t, kSortThreads, IPT, uint32_t>;
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, 
     if (base + q < n) { job.ck[base + q] = k[q]; job.cp[base + q] = p[q]; }
 }
 
-template <typename IdT>
+template <typename IdT, int kChunk>
 __global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n, int n_chunks) {
   const IdxJob& job = jobs.j[blockIdx.y];
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -436,14 +451,15 @@ __global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n
 static bool rank_path_ok(int64_t n, int64_t upper) { return n <= kRankMaxN && upper > 0 && upper < ((int64_t)1 << 31) - 2; }
 
 static int index_build_rank(IdxJobs& jobs, int n_jobs, int id_type, int64_t n, hipStream_t s) {
-  const int n_chunks = (int)ceil_div(n, kChunk);
+  const bool large = n > kChunkSwitchN;
+  const int n_chunks = (int)ceil_div(n, large ? kChunkL : kChunkS);
   const dim3 g1((unsigned)n_chunks, (unsigned)n_jobs), g2((unsigned)ceil_div(n, 256), (unsigned)n_jobs);
   if (id_type == BR_IDS_I32) {
-    chunk_sort_kernel<int32_t><<<g1, kSortThreads, 0, s>>>(jobs, n);
-    chunk_rank_kernel<int32_t><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
+    if (large) { chunk_sort_kernel<int32_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    else { chunk_sort_kernel<int32_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); chunk_rank_kernel<int32_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
   } else {
-    chunk_sort_kernel<int64_t><<<g1, kSortThreads, 0, s>>>(jobs, n);
-    chunk_rank_kernel<int64_t><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
+    if (large) { chunk_sort_kernel<int64_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    else { chunk_sort_kernel<int64_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); chunk_rank_kernel<int64_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
   }
   BR_CHECK_LAUNCH("brRowIndexBuild");
   return BR_OK;
@@ -594,6 +610,7 @@ struct AdamRowsArgs {      // one table's host-side arguments
   const float* row_grads_hi; int64_t ldg_hi;
   uint8_t* mark; int32_t* last;
   float* seg_ws;
+  const float* hi_scale = nullptr;     // per-position factor of the row_grads_hi rows
 };
 
 static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_type, int64_t n, int split, double alpha_t, double beta1,
@@ -614,9 +631,9 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     const int64_t lm = (t.ldg % 4 == 0 && t.ldg_hi % 4 == 0 && split % 4 == 0 && (al & 15) == 0) ? 4
                        : (t.ldg % 2 == 0 && t.ldg_hi % 2 == 0 && split % 2 == 0 && (al & 7) == 0) ? 2 : 1;
     ldmin = lm < ldmin ? lm : ldmin;
-    jobs.j[q] = AdamRowsJob{t.table, t.m, t.v, t.table_rows, t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws,
-                            t.mark, t.last};
-    segs[q] = SegJob{t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws};
+    jobs.j[q] = AdamRowsJob{t.table, t.m, t.v, t.table_rows, t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.hi_scale,
+                            t.seg_ws, t.mark, t.last};
+    segs[q] = SegJob{t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws, t.hi_scale};
     with_partials = with_partials && t.seg_ws != nullptr;
   }
   if (n_jobs == 1) jobs.j[1] = jobs.j[0];
@@ -661,12 +678,12 @@ extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int6
                                     const float* grads_a, int64_t ldg_a, const float* grads_hi_a, int64_t ldg_hi_a, uint8_t* mark_a, int32_t* last_a,
                                     float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
                                     const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, uint8_t* mark_b, int32_t* last_b,
-                                    int dim, int id_type, int64_t n, int split, const void* step_state, double alpha_t, double beta1,
-                                    double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream) {
+                                    int dim, int id_type, int64_t n, int split, const float* hi_scale, const void* step_state, double alpha_t,
+                                    double beta1, double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream) {
   BR_CHECK_ARG((last_a == nullptr) == (last_b == nullptr) && (last_a == nullptr || step_state), "brAdamRowsSortedPair: last arrays for both tables (with step_state) or neither");
   BR_CHECK_ARG(grads_hi_a && grads_hi_b, "brAdamRowsSortedPair: both gradient halves required");
-  const AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, mark_a, last_a, seg_ws_a},
-                             {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, mark_b, last_b, seg_ws_b}};
+  const AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, mark_a, last_a, seg_ws_a, hi_scale},
+                             {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, mark_b, last_b, seg_ws_b, hi_scale}};
   return adam_rows_launch(a, 2, dim, id_type, n, split, alpha_t, beta1, beta2, eps, last_a ? (const StepStateDev*)step_state : nullptr, stream);
 }
 

@@ -465,12 +465,19 @@ class NeuMFEngine:
                 g.replay()
 
     def row_grad_views(self, B):
-        """name -> (tensor, row stride): the MLP halves are views of dx0, the MF halves of g_user / g_item."""
+        """name -> (tensor, row stride): the MLP halves are views of dx0, the MF halves of g_user / g_item.
+        (Inspection helper for tests.  Single-GPU deferred mode: the step never writes the MF gradients out - the optimizer
+        launch forms ddot[b] * partner row as it reads the stashed rows (brAdamRowsSortedPair hi_scale) - so they are
+        formed here, with the same single fp32 multiply.)"""
         D = self.cfg.dim
         uo, io = (D, 0) if self.cfg.item_first else (0, D)
         dx0 = self.dx0[:B]
+        gu, gi = self.g_user[:B, D:], self.g_item[:B, D:]
+        if self.deferred and not self.sharded:
+            dd = self.ddot[:B, None]
+            gu, gi = dd * gi, dd * gu
         return {"user_mlp": (dx0[:, uo:uo + D], 2 * D), "item_mlp": (dx0[:, io:io + D], 2 * D),
-                "user_mf": (self.g_user[:B, D:], 2 * D), "item_mf": (self.g_item[:B, D:], 2 * D)}
+                "user_mf": (gu, 2 * D), "item_mf": (gi, 2 * D)}
 
     def _embed_backward_apply(self, users, items, B):
         """B1 row gradients of the 4 tables, S1 dedup index, O1 Adam on the (fused) tables."""

@@ -101,7 +101,7 @@ int64_t brRowIndexWorkspaceBytes(int64_t n, int id_type);
 int brRowIndexBuild(const void* ids, int id_type, int64_t n, int64_t id_upper_bound,
                     void* sorted_ids, int32_t* sorted_pos, void* workspace,
                     int64_t workspace_bytes, brStream stream);
-/* Both id streams of a step (same n) in shared launches: for n <= 131 072 (64 chunks of 2048) and id bounds < 2^31 the index is
+/* Both id streams of a step (same n) in shared launches: for n <= 524 288 (64 chunks of 8192) and id bounds < 2^31 the index is
  * built in TWO launches for the pair (chunk sort in LDS + rank-by-binary-search scatter) instead of one device
  * radix sort (~10 launches) per stream.  Same outputs as two brRowIndexBuild calls. */
 int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
@@ -431,13 +431,16 @@ int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, in
                              const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
                              const void* step_state, double beta1, double beta2, double eps, float* seg_ws, brStream stream);
 /* The user and the item table of one NeuMF step in ONE launch (same dim, n, split; each alone leaves HBM half idle).
- * last_* non-NULL (both): deferred mode (step_state required, alpha_t ignored); else brAdamRowsSorted semantics with marks. */
+ * last_* non-NULL (both): deferred mode (step_state required, alpha_t ignored); else brAdamRowsSorted semantics with marks.
+ * hi_scale (n floats, may be NULL): the grads_hi rows of BOTH tables are multiplied by hi_scale[position] as they are read.  The
+ * deferred step passes the stashed partner MF rows as grads_hi (user table: the item rows, item table: the user rows) and
+ * ddot here: g_user_mf[b] = ddot[b]*item_mf[i_b] (brNeumfEmbedBackward) without the launch that used to write it out. */
 int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a, const void* sorted_ids_a, const int32_t* sorted_pos_a,
                          const float* grads_a, int64_t ldg_a, const float* grads_hi_a, int64_t ldg_hi_a, uint8_t* mark_a, int32_t* last_a,
                          float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
                          const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, uint8_t* mark_b, int32_t* last_b,
-                         int dim, int id_type, int64_t n, int split, const void* step_state, double alpha_t, double beta1,
-                         double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream);
+                         int dim, int id_type, int64_t n, int split, const float* hi_scale, const void* step_state, double alpha_t,
+                         double beta1, double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream);
 int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,
                 double beta1, double beta2, double eps, brStream stream);
 int64_t brNeumfStepSizeof(void);
