@@ -20,11 +20,8 @@ class BPREngine:
         assert optimizer in ("adam_dense", "adam_lazy")
         self.device, self.max_batch, self.lr, self.optimizer, self.id_dtype = torch.device(device), int(max_batch), lr, optimizer, id_dtype
         self.dim = int(num_factor)
-        g = torch.Generator(device="cpu").manual_seed(init_seed)
         dev = self.device
-        # [TF-sem] Keras Embedding init U(-0.05, 0.05)
-        self.user = (torch.rand(num_users, self.dim, generator=g) * 0.1 - 0.05).to(dev)
-        self.item = (torch.rand(num_items, self.dim, generator=g) * 0.1 - 0.05).to(dev)
+        self._init_tables(num_users, num_items, init_seed)
         self.user_m, self.user_v = torch.zeros_like(self.user), torch.zeros_like(self.user)
         self.item_m, self.item_v = torch.zeros_like(self.item), torch.zeros_like(self.item)
         B = self.max_batch
@@ -37,10 +34,16 @@ class BPREngine:
         self.item_index = ops.RowIndex(2 * B, id_dtype, dev)
         self.err = ops.new_err_flag(dev)
         if optimizer == "adam_dense":
-            self.user_mark = torch.zeros(num_users, dtype=torch.uint8, device=dev)
-            self.item_mark = torch.zeros(num_items, dtype=torch.uint8, device=dev)
+            self.user_mark = torch.zeros(self.user.shape[0], dtype=torch.uint8, device=dev)
+            self.item_mark = torch.zeros(self.item.shape[0], dtype=torch.uint8, device=dev)
         self.t = 0
         self.n_seen = 0
+
+    def _init_tables(self, num_users, num_items, init_seed):
+        """[TF-sem] Keras Embedding init U(-0.05, 0.05).  (A hook: the row-sharded engine allocates only its shard.)"""
+        g = torch.Generator(device="cpu").manual_seed(init_seed)
+        self.user = (torch.rand(num_users, self.dim, generator=g) * 0.1 - 0.05).to(self.device)
+        self.item = (torch.rand(num_items, self.dim, generator=g) * 0.1 - 0.05).to(self.device)
 
     def train_step(self, users, pos, neg, batch_total: int | None = None):
         """fit step (BPRModel.py:109): users/pos/neg device ids (B,). No host sync."""
@@ -86,3 +89,16 @@ class BPREngine:
 
     def check_ids(self):
         ops.raise_if_flag(self.err)
+
+    # tables + Adam slots (model.save / restoreFromLatestCheckPoint, RModel.py:139,172); row-sharded engines hold their shard
+    STATE_TABLES = ("user", "item", "user_m", "user_v", "item_m", "item_v")
+
+    def state_dict(self) -> dict:
+        sd = {"t": self.t}
+        sd.update({k: getattr(self, k) for k in self.STATE_TABLES})
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        self.t = int(sd["t"])
+        for k in self.STATE_TABLES:
+            getattr(self, k).copy_(sd[k])

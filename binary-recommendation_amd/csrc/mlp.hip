@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void neumf_head_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 33; ++i) gw[i] = 0.f;
   float gb = 0.f;
-  double s_loss = 0.0, s_se = 0.0, s_ae = 0.0, s_ok = 0.0;
+  double s_loss = 0.0, s_se = 0.0, s_ae = 0.0, s_ok = 0.0, s_bce = 0.0, s_tp = 0.0, s_fp = 0.0, s_fn = 0.0;
   const bool flat_in = lda3 == N3, flat_out = da3 && ldda3 == N3;
   const int64_t wave_stride = (int64_t)gridDim.x * 4 * 64;
   for (int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * 64; b0 < batch; b0 += wave_stride) {
@@ -615,17 +615,21 @@ __global__ __launch_bounds__(256) void neumf_head_kernel(const float* __restrict
       if (labels) {
         const float yv = labels[b];
         float l;
+        const float bce = fmaxf(z, 0.f) - z * yv + log1pf(expf(-fabsf(z)));
         if (loss == BR_LOSS_BCE) {
-          l = fmaxf(z, 0.f) - z * yv + log1pf(expf(-fabsf(z)));
+          l = bce;
           dz = (p - yv) * inv_batch;
         } else {
           l = (p - yv) * (p - yv);
           dz = 2.f * (p - yv) * p * (1.f - p) * inv_batch;
         }
+        const bool pp = p > 0.5f, yp = yv > 0.5f;
         s_loss += (double)l;
         s_se += (double)((p - yv) * (p - yv));
         s_ae += (double)fabsf(p - yv);
-        s_ok += ((p > 0.5f) == (yv > 0.5f)) ? 1.0 : 0.0;
+        s_ok += (pp == yp) ? 1.0 : 0.0;
+        s_bce += (double)bce;
+        s_tp += (pp && yp) ? 1.0 : 0.0; s_fp += (pp && !yp) ? 1.0 : 0.0; s_fn += (!pp && yp) ? 1.0 : 0.0;
       }
     }
     if (da3 && labels) {
@@ -645,10 +649,14 @@ __global__ __launch_bounds__(256) void neumf_head_kernel(const float* __restrict
     __builtin_amdgcn_wave_barrier();
   }
   if (!labels) return;
-  __shared__ double redd[4][4];
+  __shared__ double redd[4][BR_METRIC_SUMS];
   __shared__ float redf[4][34];
   s_loss = wave_sum_d(s_loss); s_se = wave_sum_d(s_se); s_ae = wave_sum_d(s_ae); s_ok = wave_sum_d(s_ok);
-  if (lane == 0) { redd[wave][0] = s_loss; redd[wave][1] = s_se; redd[wave][2] = s_ae; redd[wave][3] = s_ok; }
+  s_bce = wave_sum_d(s_bce); s_tp = wave_sum_d(s_tp); s_fp = wave_sum_d(s_fp); s_fn = wave_sum_d(s_fn);
+  if (lane == 0) {
+    redd[wave][0] = s_loss; redd[wave][1] = s_se; redd[wave][2] = s_ae; redd[wave][3] = s_ok;
+    redd[wave][4] = s_bce; redd[wave][5] = s_tp; redd[wave][6] = s_fp; redd[wave][7] = s_fn;
+  }
   if (da3) {
 #pragma unroll
     for (int i = 0; i < 33; ++i) {
@@ -661,9 +669,9 @@ __global__ __launch_bounds__(256) void neumf_head_kernel(const float* __restrict
     if (lane == 0) redf[wave][33] = v;
   }
   __syncthreads();
-  // 4 metric sums per slot, slot = workgroup & 63: same-line double atomics serialise (~12 ns each)
-  if (threadIdx.x < 4 && sums)
-    atomicAdd(sums + (size_t)(blockIdx.x & (BR_SUM_SLOTS - 1)) * 4 + threadIdx.x,
+  // BR_METRIC_SUMS metric sums per slot, slot = workgroup & 63: same-line double atomics serialise (~12 ns each)
+  if (threadIdx.x < BR_METRIC_SUMS && sums)
+    atomicAdd(sums + (size_t)(blockIdx.x & (BR_SUM_SLOTS - 1)) * BR_METRIC_SUMS + threadIdx.x,
               redd[0][threadIdx.x] + redd[1][threadIdx.x] + redd[2][threadIdx.x] + redd[3][threadIdx.x]);
   if (da3 && slabs) {
     // slab layout [dW4 (N3+1, concat order) | db4]

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
   float* hw = cst + 4 * n2;                                 // [b3 (N3P) | w4 for a3 (N3P)]
   float* A3s = hw + 2 * N3P;                                // [128][N3P + 1]  a3 on its way out (coalesced store)
   __shared__ float redf[kTailWaves][N3P + 2];
-  __shared__ double redd[kTailWaves][4];
+  __shared__ double redd[kTailWaves][BR_METRIC_SUMS];
   __shared__ double colred[2][128];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = t >> 2, q = t & 3;
@@ -138,12 +138,13 @@ __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
   }
   const float p = sigmoidf_acc(lz);
   float dzl = 0.f;
-  double s_loss = 0.0, s_se = 0.0, s_ae = 0.0, s_ok = 0.0;
+  double s_loss = 0.0, s_se = 0.0, s_ae = 0.0, s_ok = 0.0, s_bce = 0.0, s_tp = 0.0, s_fp = 0.0, s_fn = 0.0;
   const bool own = live && q == 0;
   if (live) {
     float l;
+    const float bce = fmaxf(lz, 0.f) - lz * yv + log1pf(expf(-fabsf(lz)));
     if (a.loss == BR_LOSS_BCE) {
-      l = fmaxf(lz, 0.f) - lz * yv + log1pf(expf(-fabsf(lz)));
+      l = bce;
       dzl = (p - yv) * a.inv_batch;
     } else {
       l = (p - yv) * (p - yv);
@@ -151,7 +152,9 @@ __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
     }
     if (own) {
       s_loss = (double)l; s_se = (double)((p - yv) * (p - yv)); s_ae = (double)fabsf(p - yv);
-      s_ok = ((p > 0.5f) == (yv > 0.5f)) ? 1.0 : 0.0;
+      const bool pp = p > 0.5f, yp = yv > 0.5f;
+      s_ok = (pp == yp) ? 1.0 : 0.0;
+      s_bce = (double)bce; s_tp = (pp && yp) ? 1.0 : 0.0; s_fp = (pp && !yp) ? 1.0 : 0.0; s_fn = (!pp && yp) ? 1.0 : 0.0;
       a.logit[gr] = lz;
       a.prob[gr] = p;
       a.ddot[gr] = dzl * wdot;
@@ -178,7 +181,11 @@ __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
     const float v0 = group_sum<64>(dzo * d), v1 = group_sum<64>(dzo);
     if (lane == 0) { redf[wave][N3P] = v0; redf[wave][N3P + 1] = v1; }
     s_loss = wave_sum_d(s_loss); s_se = wave_sum_d(s_se); s_ae = wave_sum_d(s_ae); s_ok = wave_sum_d(s_ok);
-    if (lane == 0) { redd[wave][0] = s_loss; redd[wave][1] = s_se; redd[wave][2] = s_ae; redd[wave][3] = s_ok; }
+    s_bce = wave_sum_d(s_bce); s_tp = wave_sum_d(s_tp); s_fp = wave_sum_d(s_fp); s_fn = wave_sum_d(s_fn);
+    if (lane == 0) {
+      redd[wave][0] = s_loss; redd[wave][1] = s_se; redd[wave][2] = s_ae; redd[wave][3] = s_ok;
+      redd[wave][4] = s_bce; redd[wave][5] = s_tp; redd[wave][6] = s_fp; redd[wave][7] = s_fn;
+    }
   }
   __syncthreads();                                           // X, DZ, redf, redd complete
 
@@ -201,10 +208,10 @@ __global__ __launch_bounds__(kTailThreads) void neumf_tail_kernel(TailArgs a) {
   }
   if (t == 64) slab[n2 * n3 + n3 + (a.mf_first ? 0 : n3)] = wsum(N3P);
   if (t == 65) slab[n2 * n3 + 2 * n3 + 1] = wsum(N3P + 1);
-  if (t >= 96 && t < 100 && a.msums) {
+  if (t >= 96 && t < 96 + BR_METRIC_SUMS && a.msums) {
     double v = 0.0;
     for (int w = 0; w < kTailWaves; ++w) v += redd[w][t - 96];
-    atomicAdd(a.msums + (size_t)(blockIdx.x & (BR_SUM_SLOTS - 1)) * 4 + (t - 96), v);
+    atomicAdd(a.msums + (size_t)(blockIdx.x & (BR_SUM_SLOTS - 1)) * BR_METRIC_SUMS + (t - 96), v);
   }
   __syncthreads();                                           // every reader of X is done
 

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
   __shared__ float wsum[kTmWaves][64 * 16];                               // per-wave dW3 partials [k][n]
   __shared__ float wcol[kTmWaves][2][16 + 2];                             // per-wave db3 | dW4(a3) columns, [16]: dW4(dot), [17]: db4
   __shared__ double wbn[2][64];                                           // BatchNorm-2 backward sums of the workgroup
-  __shared__ double wmet[kTmWaves][4];
+  __shared__ double wmet[kTmWaves][BR_METRIC_SUMS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const int n2 = a.n2, n3 = a.n3;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
   float isum[kTmKT], isq[kTmKT];
 #pragma unroll
   for (int kt = 0; kt < kTmKT; ++kt) { isum[kt] = 0.f; isq[kt] = 0.f; }
-  double s_loss = 0.0, s_se = 0.0, s_ae = 0.0, s_ok = 0.0;
+  double s_loss = 0.0, s_se = 0.0, s_ae = 0.0, s_ok = 0.0, s_bce = 0.0, s_tp = 0.0, s_fp = 0.0, s_fn = 0.0;
   const float4 w4q = *reinterpret_cast<const float4*>(&hv[1][4 * g]);    // B operand of the logit product: w4[4g+q]
   const float b3c = hv[0][c16], w4c = hv[1][c16];
   const float ik = a.inv_keep;
@@ -170,14 +170,17 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
       const float rinv = 1.0f / (1.0f + e);
       const float p = lz >= 0.f ? rinv : e * rinv;
       float l, d;
-      if (a.loss == BR_LOSS_BCE) { l = fmaxf(lz, 0.f) - lz * yv[r] + log1pf(e); d = (p - yv[r]) * a.inv_batch; }
+      const float bce = fmaxf(lz, 0.f) - lz * yv[r] + log1pf(e);
+      if (a.loss == BR_LOSS_BCE) { l = bce; d = (p - yv[r]) * a.inv_batch; }
       else { l = (p - yv[r]) * (p - yv[r]); d = 2.f * (p - yv[r]) * p * (1.f - p) * a.inv_batch; }
       dzl[r] = __int_as_float(__float_as_int(d) & vm[r]);
       if (c16 == 0 && vm[r]) {
         const int64_t row = rbase + 4 * g + r;
         a.logit[row] = lz; a.prob[row] = p; a.ddot[row] = dzl[r] * wdot;
         s_loss += (double)l; s_se += (double)((p - yv[r]) * (p - yv[r])); s_ae += (double)fabsf(p - yv[r]);
-        s_ok += ((p > 0.5f) == (yv[r] > 0.5f)) ? 1.0 : 0.0;
+        const bool pp = p > 0.5f, yp = yv[r] > 0.5f;
+        s_ok += (pp == yp) ? 1.0 : 0.0;
+        s_bce += (double)bce; s_tp += (pp && yp) ? 1.0 : 0.0; s_fp += (pp && !yp) ? 1.0 : 0.0; s_fn += (!pp && yp) ? 1.0 : 0.0;
         dw4dot = fmaf(dzl[r], dv[r], dw4dot);
         db4 += dzl[r];
       }
@@ -247,7 +250,11 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
     u0 = group_sum<64>(u0); u1 = group_sum<64>(u1);
     if (lane == 0) { wcol[wave][0][16] = u0; wcol[wave][0][17] = u1; }
     s_loss = wave_sum_d(s_loss); s_se = wave_sum_d(s_se); s_ae = wave_sum_d(s_ae); s_ok = wave_sum_d(s_ok);
-    if (lane == 0) { wmet[wave][0] = s_loss; wmet[wave][1] = s_se; wmet[wave][2] = s_ae; wmet[wave][3] = s_ok; }
+    s_bce = wave_sum_d(s_bce); s_tp = wave_sum_d(s_tp); s_fp = wave_sum_d(s_fp); s_fn = wave_sum_d(s_fn);
+    if (lane == 0) {
+      wmet[wave][0] = s_loss; wmet[wave][1] = s_se; wmet[wave][2] = s_ae; wmet[wave][3] = s_ok;
+      wmet[wave][4] = s_bce; wmet[wave][5] = s_tp; wmet[wave][6] = s_fp; wmet[wave][7] = s_fn;
+    }
   }
   __syncthreads();
   // slab of this workgroup: [dW3 (n2 x n3) | db3 (n3) | dW4 (n3 + 1, concat order) | db4]; dW3 carries the 1/(1-p) folded out of T()
@@ -270,12 +277,12 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
     if (t == 16) slab[n2 * n3 + n3 + (a.mf_first ? 0 : n3)] = s0;
     if (t == 17) slab[n2 * n3 + 2 * n3 + 1] = s0;
   }
-  if (threadIdx.x >= 64 && threadIdx.x < 68 && a.msums) {
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + BR_METRIC_SUMS && a.msums) {
     const int t = threadIdx.x - 64;
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < kTmWaves; ++w) v += wmet[w][t];
-    atomicAdd(a.msums + (size_t)(blockIdx.x & (BR_SUM_SLOTS - 1)) * 4 + t, v);
+    atomicAdd(a.msums + (size_t)(blockIdx.x & (BR_SUM_SLOTS - 1)) * BR_METRIC_SUMS + t, v);
   }
   if (a.bn_sums && threadIdx.x >= 128 && threadIdx.x < 128 + 64) {
     const int k = threadIdx.x - 128;

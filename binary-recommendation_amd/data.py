@@ -59,28 +59,30 @@ def ml1m_shaped(seed: int = 0, n_users=ML1M_USERS, n_items=ML1M_ITEMS, n_pos=ML1
     return (pairs // n_items).astype(np.int32), (pairs % n_items).astype(np.int32)
 
 
-def generate_negative_feedback(users, items, n_users, n_items, size, seed=0):
-    """generateNegativeFeedback (synthetic.py:237-256): `size` distinct (user,item) pairs outside the
-    positives.  Users are drawn from the positives' user column and items uniformly (the reference
-    re-samples rows of the data and re-draws the product column), rejecting collisions."""
-    rng = np.random.default_rng(seed)
-    pos = np.unique(users.astype(np.int64) * n_items + items)
-    neg = np.empty(0, dtype=np.int64)
-    while neg.size < size:
-        need = int((size - neg.size) * 1.2) + 1000
-        u = users[rng.integers(0, len(users), need)].astype(np.int64)
-        i = rng.integers(0, n_items, need)
-        cand = np.unique(u * n_items + i)
-        cand = cand[~np.isin(cand, pos, assume_unique=True)]
-        neg = np.unique(np.concatenate([neg, cand]))
-    neg = rng.permutation(neg)[:size]
-    return (neg // n_items).astype(np.int32), (neg % n_items).astype(np.int32)
+def _dev_ids(a, device):
+    import torch
+    t = a if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(np.asarray(a)))
+    if t.dtype not in (torch.int32, torch.int64):
+        t = t.to(torch.int32)
+    return t.to(device).contiguous()
 
 
-def make_ncf_chunks(users, items, n_users, n_items, k=5, neg_per_pos=2, seed=0):
+def generate_negative_feedback(users, items, n_users, n_items, size, seed=0, device="cuda:0"):
+    """generateNegativeFeedback (synthetic.py:237-256) on the device (csrc/sampling.hip): `size` DISTINCT (user,item) pairs
+    outside the positives; customers and products are drawn by shuffling the two columns of the data independently, round
+    after round (generateSyntethic, synthetic.py:208-223).  -> (users, items) numpy int32.
+    oracle/binrec_oracle.py::ncf_negatives restates it bit for bit."""
+    from . import ops
+    u, i = _dev_ids(users, device), _dev_ids(items, device)
+    off, pit = ops.positives_csr(u, i, n_users, u.device)
+    nu, ni = ops.ncf_negatives(u, i, off, pit, n_items, int(size), int(seed))
+    return nu.cpu().numpy().astype(np.int32), ni.cpu().numpy().astype(np.int32)
+
+
+def make_ncf_chunks(users, items, n_users, n_items, k=5, neg_per_pos=2, seed=0, device="cuda:0"):
     """makeNCFDatasets (synthetic.py:152-164): k chunks, each = its slice of the positives (label 1)
     + its slice of the `neg_per_pos x` negatives (label 0)."""
-    nu, ni = generate_negative_feedback(users, items, n_users, n_items, neg_per_pos * len(users), seed)
+    nu, ni = generate_negative_feedback(users, items, n_users, n_items, neg_per_pos * len(users), seed, device)
     chunks = []
     for pu, pi, qu, qi in zip(np.array_split(users, k), np.array_split(items, k), np.array_split(nu, k), np.array_split(ni, k)):
         chunks.append({"users": np.concatenate([pu, qu]), "items": np.concatenate([pi, qi]),
@@ -88,15 +90,21 @@ def make_ncf_chunks(users, items, n_users, n_items, k=5, neg_per_pos=2, seed=0):
     return chunks
 
 
-def bootstrap_dataset(users, items, neg_ratio=3.0, seed=0):
-    """NeuMFModel.bootstrapDataset (NeuMFModel.py:102-109): positives + `neg_ratio x` rows sampled with
-    replacement whose item column is permuted (no collision check), shuffled."""
-    rng = np.random.default_rng(seed)
-    n = len(users)
-    k = int(round(neg_ratio * n))
-    pick = rng.integers(0, n, size=k)
-    nu, ni = users[pick], items[pick][rng.permutation(k)]
-    U, I = np.concatenate([users, nu]), np.concatenate([items, ni])
-    Y = np.concatenate([np.ones(n, np.float32), np.zeros(k, np.float32)])
-    perm = rng.permutation(n + k)
-    return U[perm], I[perm], Y[perm]
+def bootstrap_dataset(users, items, neg_ratio=3.0, seed=0, device="cuda:0"):
+    """NeuMFModel.bootstrapDataset (NeuMFModel.py:102-109) on the device: positives + round(neg_ratio x n) rows sampled with
+    replacement whose item column is permuted (no collision check), shuffled.  -> device tensors (users, items, labels);
+    oracle/binrec_oracle.py::bootstrap_dataset restates it bit for bit."""
+    from . import ops
+    u, i = _dev_ids(users, device), _dev_ids(items, device)
+    return ops.bootstrap_dataset(u, i, int(round(neg_ratio * u.shape[0])), int(seed))
+
+
+def sample_bpr_triplets(users, items, n_users, n_items, neg_per_pos=1, seed=0, cand_items=None, device="cuda:0"):
+    """BPR training triplets (customer, positive, negative) - the sampled replacement of BPRModel.extractPositivesNegatives'
+    O(U*I) enumeration (src/models/BPRModel.py:111-119): neg_per_pos negatives per positive, uniform over the candidate products
+    and never a positive of the customer.  -> device tensors (users, positives, negatives)."""
+    from . import ops
+    u, i = _dev_ids(users, device), _dev_ids(items, device)
+    off, pit = ops.positives_csr(u, i, n_users, u.device)
+    cand = None if cand_items is None else _dev_ids(cand_items, device).to(u.dtype)
+    return ops.bpr_sample_triplets(u, i, off, pit, neg_per_pos, seed, int(n_items if cand is None else cand.shape[0]), cand)

@@ -41,12 +41,25 @@ def _to_dev(a, device, dtype):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(a)), device=device).to(dtype).contiguous()
 
 
-class KerasLikeNeuMF:
-    METRICS = ["mse", "mae", "binary_accuracy"]   # RModel.METRICS (RModel.py:20)
+# the compiled metric lists of the reference, by the names Keras gives them in `history` / `evaluate`
+RMODEL_METRICS = ["mse", "mae", "binary_accuracy"]                                   # RModel.METRICS (RModel.py:20)
+NFC_PLAIN_METRICS = ["binary_crossentropy", "mse", "mae", "false_negatives", "false_positives", "true_negatives", "true_positives",
+                     "binary_accuracy", "top_k_categorical_accuracy"]                   # trainers/NFC_plain.py:155
 
-    def __init__(self, engine: NeuMFEngine, user_first_inputs: bool = True):
+
+class KerasLikeNeuMF:
+    METRICS = RMODEL_METRICS
+
+    def __init__(self, engine: NeuMFEngine, user_first_inputs: bool = True, metrics=None):
         self.engine = engine
         self.user_first_inputs = user_first_inputs   # Model([customer_input, material_input]) (NFC_plain.py:154)
+        self.metrics_names = ["loss"] + list(metrics if metrics is not None else self.METRICS)
+
+    def _metric_values(self, mt: dict) -> list:
+        """[loss, *compiled metrics] in compiled order.  top_k_categorical_accuracy (NFC_plain.py:155, k = 10) on a 1-unit
+        output is in_top_k(argmax(y_true) = 0, y_pred, 10) over ONE column: 1.0 for every sample [TF-sem] - reported as that
+        constant, it carries no information."""
+        return [1.0 if k == "top_k_categorical_accuracy" else float(mt[k]) for k in self.metrics_names]
 
     def _xy(self, x, y=None):
         e = self.engine
@@ -82,10 +95,10 @@ class KerasLikeNeuMF:
             for s in range(0, n, bs):
                 e.train_step(uu[s:s + bs], ii[s:s + bs], ll[s:s + bs])
             e.check_ids()
-            logs = e.pop_metrics(n)
+            logs = dict(zip(self.metrics_names, self._metric_values(e.pop_metrics(n))))
             if validation_data is not None:
                 vl = self.evaluate(validation_data[0], validation_data[1], batch_size=bs)
-                logs.update({"val_loss": vl[0], "val_mse": vl[1], "val_mae": vl[2], "val_binary_accuracy": vl[3]})
+                logs.update({"val_" + k: v for k, v in zip(self.metrics_names, vl)})
             hist.add(logs)
             for cb in callbacks or []:
                 cb.on_epoch_end(ep, logs)
@@ -98,7 +111,8 @@ class KerasLikeNeuMF:
         return self.engine.predict(u, i).cpu().numpy().reshape(-1, 1)
 
     def evaluate(self, x, y, batch_size=None, verbose=0, callbacks=None, steps=None):
-        """-> [loss, mse, mae, binary_accuracy] (model.evaluate, NFC_plain.py:183; RModel.py:147)."""
+        """-> [loss, *compiled metrics] (model.evaluate, NFC_plain.py:183; RModel.py:147): `metrics_names` says which -
+        RModel.METRICS by default, NFC_PLAIN_METRICS for the graph of trainers/NFC_plain.py:155."""
         e = self.engine
         u, i, yy = self._xy(x, y)
         bs = min(int(batch_size or e.max_batch), e.max_batch)
@@ -108,8 +122,7 @@ class KerasLikeNeuMF:
         for s in range(0, n, bs):
             m = min(n, s + bs) - s
             e.evaluate_batch(u[s:s + m], i[s:s + m], yy[s:s + m])
-        mt = e.pop_metrics(n)
-        return [mt["loss"], mt["mse"], mt["mae"], mt["binary_accuracy"]]
+        return self._metric_values(e.pop_metrics(n))
 
     def save(self, path):
         """model.save(path) (NFC_plain.py:166, RModel.py:139): tables, dense params, BN moving stats and
@@ -182,8 +195,9 @@ class NeuMFModel(RModel):
         return self.model
 
     def bootstrapDataset(self, df, negRatio=3.0, batchSize=128, shuffle=True, seed=0):
-        """NeuMFModel.py:102-123 -> dict(user, item, label, batch_size) instead of a tf.data.Dataset."""
-        u, i, y = _data.bootstrap_dataset(df[self.CUSTOMER_ID].to_numpy(), df[self.PRODUCT_ID].to_numpy(), negRatio, seed)
+        """NeuMFModel.py:102-123 -> dict(user, item, label, batch_size) of DEVICE tensors instead of a tf.data.Dataset: the
+        negatives are sampled on the GPU (csrc/sampling.hip, brBootstrapDataset)."""
+        u, i, y = _data.bootstrap_dataset(df[self.CUSTOMER_ID].to_numpy(), df[self.PRODUCT_ID].to_numpy(), negRatio, seed, self.device)
         return {"user": u, "item": i, "label": y, "batch_size": batchSize, "shuffle": shuffle}
 
     def prepareToTrain(self, distributedConfig, path, rowLimit):
@@ -214,11 +228,17 @@ class NeuMFModel(RModel):
     def getPredictableUsers(self) -> list:
         return list(self._users)
 
-    def predictForUser(self, customerId, numberOfItem=5):
-        """NeuMFModel.py:133-150: scores of the test-split products for one customer, best first
-        (the reference sorts the *string* scores; here the float scores)."""
+    def predictForUser(self, customerId, numberOfItem=5, sort="float"):
+        """NeuMFModel.py:133-150 -> [(item, score)] as strings, best first.
+        The reference sorts the STRING scores (`sorted(extractFeatures.items(), key=lambda x: x[1], reverse=True)`, :150).
+        For sigmoid outputs printed in positional notation ("0.73...") that is the numeric order; it differs only where str()
+        switches to scientific notation (scores < 1e-4: "9.5e-05" sorts above "0.9").  sort="float" (default) ranks by value -
+        what the endpoint means; sort="str" reproduces the reference's lexicographic order exactly."""
         items = np.asarray(self._products)
         p = self.model.predict({"user": np.full(len(items), customerId), "item": items}).reshape(-1)
+        if sort == "str":
+            feats = {str(items[j]): str(p[j]) for j in range(len(items))}
+            return sorted(feats.items(), key=lambda x: x[1], reverse=True)[:numberOfItem]
         order = np.argsort(-p, kind="stable")[:numberOfItem]
         return [(str(items[j]), str(p[j])) for j in order]
 
@@ -239,6 +259,71 @@ class BPRModel(RModel):
         existing = trainDf[trainDf.CUSTOMER_ID == customerId].PRODUCT_ID.tolist()
         ex = set(existing)
         return [{"CUSTOMER_ID": customerId, "pPRODUCT_ID": p, "nPRODUCT_ID": n} for p in existing for n in productIds if n not in ex]
+
+    def readData(self, path, rowLimit):
+        """(numItem, numUser, transactions) like NeuMFModel.readData (the reference's BPRModel has none and fails at
+        BPRModel.py:79; RModel.readData returns None)."""
+        import pandas as pd
+        df = pd.read_csv(path, nrows=rowLimit)
+        return int(df.PRODUCT_ID.max()) + 1, int(df.CUSTOMER_ID.max()) + 1, df
+
+    def train(self, path, rowLimit, metricDict: dict = None, distributedConfig=None, negPerPos: int = 4, exhaustive: bool = False, seed: int = 0):
+        """BPRModel.train (src/models/BPRModel.py:76-109): batchSize 64, train/test split, triplets, compileModel, fit for
+        `epochs`.  The reference enumerates EVERY (positive, non-interacted product) pair of every customer with Pool(5)
+        (O(U*I) rows, :94-98,111-119); here `negPerPos` negatives per positive are sampled on the GPU (brBprSampleTriplets);
+        exhaustive=True reproduces the enumeration for small data.  -> {'result': 'completed', 'metrics': [last epoch loss]}
+        in RModel.train's convention (the reference's BPR train returns None)."""
+        from sklearn.model_selection import train_test_split
+        self.batchSize = 64
+        numItem, numUser, df = self.readData(path, rowLimit)
+        self.trainDf, self.testDf = train_test_split(df, test_size=self.testSize, random_state=seed)
+        customerIds = self.trainDf.CUSTOMER_ID.unique().tolist()
+        self.productIds = self.trainDf.PRODUCT_ID.unique().tolist()
+        self.compileModel(distributedConfig, max(customerIds) + 1, max(self.productIds) + 1, self.numFactor)
+        tu, ti = self.trainDf.CUSTOMER_ID.to_numpy(), self.trainDf.PRODUCT_ID.to_numpy()
+        if exhaustive:
+            rows = [r for c in customerIds for r in self.extractPositivesNegatives(self.trainDf, c, self.productIds)]
+            X = {"customerId_input": np.array([r["CUSTOMER_ID"] for r in rows], np.float32),
+                 "pProduct_input": np.array([r["pPRODUCT_ID"] for r in rows], np.float32),
+                 "nProduct_input": np.array([r["nPRODUCT_ID"] for r in rows], np.float32)}
+        else:
+            u, p, n = _data.sample_bpr_triplets(tu, ti, max(customerIds) + 1, max(self.productIds) + 1, negPerPos, seed,
+                                                cand_items=np.asarray(self.productIds), device=self.device)
+            X = {"customerId_input": u, "pProduct_input": p, "nProduct_input": n}
+        hist = self.fit(X, None, batch_size=self.batchSize, epochs=self.epochs, seed=seed)
+        return {"result": "completed", "metrics": [hist.history["loss"][-1]], "history": hist}
+
+    # ---- the evaluation functions of the stand-alone BPR notebook (src/models/bpr.py) on the GPU ----
+    def _scores(self, user_ids, items):
+        e = self.model
+        u = _to_dev(np.asarray(user_ids), e.device, e.id_dtype)
+        it = _to_dev(np.asarray(items), e.device, e.id_dtype)
+        return e.predict_scores(u, it)                                   # bpr_predict (bpr.py:122-133) for all users at once
+
+    def full_auc(self, ground_truth, items) -> float:
+        """full_auc (src/models/bpr.py:230-254): mean over the users that have positives of roc_auc_score(ground truth over all
+        `items`, bpr_predict scores).  ground_truth: iterable of (user_id, [true item ids])."""
+        gt = list(ground_truth)
+        col = {it: j for j, it in enumerate(items)}
+        rows = [r for r, (_u, t) in enumerate(gt) for _ in t]
+        cols = [col[p] for _u, t in gt for p in t]
+        off, idx = ops.truth_csr(len(gt), rows, cols, self.model.device)
+        auc = ops.full_auc(self._scores([u for u, _ in gt], items), off, idx).cpu().numpy()
+        has = np.array([len(t) > 0 for _u, t in gt])
+        return float(np.mean(auc[has]))
+
+    def mean_average_precision_k(self, ground_truth, items, k=100) -> float:
+        """mean_average_precision_k (src/models/bpr.py:257-289): AP of the top-k of the bpr_predict scores per user / min(len(actual), k)."""
+        gt = list(ground_truth)
+        col = {it: j for j, it in enumerate(items)}
+        rows = [r for r, (_u, t) in enumerate(gt) for _ in t]
+        cols = [col[p] for _u, t in gt for p in t if p in col]
+        rows = [r for r, (_u, t) in enumerate(gt) for p in t if p in col]
+        off, idx = ops.truth_csr(len(gt), rows, cols, self.model.device)
+        k = min(int(k), len(items))
+        _ts, ti = ops.topk_rows(self._scores([u for u, _ in gt], items), k)
+        ap, _ = ops.map_at_k(ti, off, idx, want_hits=False)
+        return float(ap.double().mean().item())
 
     def fit(self, X: dict, y=None, batch_size=64, epochs=1, seed=0):
         """model.fit({'customerId_input','pProduct_input','nProduct_input'}, ones, batch_size, epochs) (BPRModel.py:100-109)."""
@@ -268,6 +353,7 @@ class TwoTowerModel:
         self.engine = TwoTowerEngine(embedDim, nbrItem, nbrUser, semb, device, max_batch, lr=learningRate, optimizer=optimiser, rd_zero=rdZero)
         self.device = self.engine.device
         self._cand, self._cand_ids, self._k = None, None, None
+        self._loss_seen = torch.zeros((), dtype=torch.float64, device=self.device)
 
     def _ids(self, info):
         return (self.userTowerIn(info[self.userKey], self.device), self.itemTowerIn(info[self.itemKey], self.device))
@@ -276,16 +362,25 @@ class TwoTowerModel:
         u, i = self._ids(info)
         return self.engine.compute_emb(u, i, u.shape[0])
 
+    def _step_loss(self, batch, mean):
+        """the step's loss as a 0-dim DEVICE tensor (metrics["loss"] = loss, twoTower.py:99-102,107-111): the difference of the
+        engine's running loss sum across the step (softmax: the TFRS SUM over the batch; rdZero: mean BCE) - no host sync;
+        float() / .item() on it is the caller's."""
+        total = self.engine.loss_slots.sum()
+        loss = total - self._loss_seen
+        self._loss_seen = total
+        return loss / batch if mean else loss
+
     def train_step(self, info):
         u, i = self._ids(info)
         y = None if not self.rdZero else _to_dev(info[self.resKey], self.device, torch.float32)
         self.engine.train_step(u, i, y)
-        return {"loss": None}     # read back with engine.pop_loss() (no per-step host sync)
+        return {"loss": self._step_loss(u.shape[0], self.rdZero)}
 
     def test_step(self, info):
         u, i = self._ids(info)
         self.engine.test_step(u, i)
-        return {"loss": None}
+        return {"loss": self._step_loss(u.shape[0], False)}
 
     def fit(self, batches, epochs=1):
         """model.fit(trainSetCached, epochs) (twoTower.py:214): `batches` = iterable of info dicts."""
@@ -295,6 +390,7 @@ class TwoTowerModel:
                 self.train_step(info)
             self.engine.check_ids()
             hist.add({"loss": self.engine.pop_loss()})
+            self._loss_seen.zero_()          # pop_loss cleared the running sum
         return hist
 
     def setCandidates(self, items, k):

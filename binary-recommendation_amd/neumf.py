@@ -210,7 +210,7 @@ class NeuMFEngine:
         self.stats2 = self.dstat[o:o + R * 2 * n2]; o += R * 2 * n2
         self.bsum1 = self.dstat[o:o + R * 2 * n1]; o += R * 2 * n1
         self.bsum2 = self.dstat[o:o + R * 2 * n2]
-        self.msums = torch.zeros(ops.SUM_SLOTS, 4, dtype=torch.float64, device=dev)   # [slot][loss, se, ae, correct] (epoch)
+        self.msums = torch.zeros(ops.SUM_SLOTS, ops.METRIC_SUMS, dtype=torch.float64, device=dev)   # [slot][loss, se, ae, correct, bce, tp, fp, fn] (epoch)
         self.bn_buf = f(4 * n1 + 4 * n2)      # [scale1|shift1|mean1|rstd1|scale2|shift2|mean2|rstd2]
         self.bn, o = {}, 0
         for k, n in (("scale1", n1), ("shift1", n1), ("mean1", n1), ("rstd1", n1), ("scale2", n2), ("shift2", n2), ("mean2", n2), ("rstd2", n2)):
@@ -332,6 +332,9 @@ class NeuMFEngine:
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch {self.max_batch}")
         if B == 0:
+            if self.dist is not None and self.dist.world > 1:
+                # the peers are about to enter the step's collectives: returning here would leave them waiting forever
+                raise ValueError("empty local batch in a data-parallel step: give every rank at least one pair (pad or drop the ragged tail)")
             return
         batch_total = B if batch_total is None else batch_total
         if self.deferred:
@@ -537,11 +540,13 @@ class NeuMFEngine:
         self._infer(users, items, labels, users.shape[0])
 
     def pop_metrics(self, n_samples: int) -> dict:
-        """Host sync: mean loss / mse / mae / binary_accuracy since the last call (RModel.py:20)."""
+        """Host sync: the compiled metrics since the last call - mean loss / mse / mae / binary_accuracy (RModel.py:20) and the
+        rest of trainers/NFC_plain.py:155: binary_crossentropy, true/false positives/negatives at threshold 0.5."""
         s = self.msums.sum(dim=0).cpu().tolist()
         self.msums.zero_()
         n = max(1, n_samples)
-        return {"loss": s[0] / n, "mse": s[1] / n, "mae": s[2] / n, "binary_accuracy": s[3] / n}
+        return {"loss": s[0] / n, "mse": s[1] / n, "mae": s[2] / n, "binary_accuracy": s[3] / n, "binary_crossentropy": s[4] / n,
+                "true_positives": s[5], "false_positives": s[6], "false_negatives": s[7], "true_negatives": n_samples - s[5] - s[6] - s[7]}
 
     def check_ids(self):
         ops.raise_if_flag(self.err)

@@ -366,6 +366,7 @@ def bce_logits(z, y, inv_batch, prob=None, dz=None, sums=None):
 
 # ------------------------------------------------------------------------------ L4 in-batch softmax / E1 scoring + top-k
 SUM_SLOTS = 64   # BR_SUM_SLOTS
+METRIC_SUMS = 8  # BR_METRIC_SUMS: [loss, se, ae, correct, bce, tp, fp, fn]
 
 
 def inbatch_softmax_lse(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, loss_sum):
@@ -398,3 +399,109 @@ def topk_rows(scores, k):
     oi = torch.empty(U, k, dtype=torch.int32, device=scores.device)
     check(_lib.load().brTopKRows(_f32(scores, "scores").data_ptr(), U, I, int(k), os_.data_ptr(), oi.data_ptr(), _stream()), "brTopKRows")
     return os_, oi
+
+
+# ------------------------------------------------------------------------------ 8f-1 evaluation: full AUC, MAP@k, hit counts
+def truth_csr(n_users: int, user_rows, item_cols, device):
+    """Ground truth of `n_users` rows as the CSR the eval kernels take: (offsets int64 (n_users + 1), column indices int32 ascending
+    per user).  user_rows / item_cols: equal-length integer sequences (row index into the scored users, column index into the
+    scored items); duplicates are dropped.  Host-side index plumbing (numpy), done once per evaluation."""
+    import numpy as np
+    u = np.asarray(user_rows, dtype=np.int64); c = np.asarray(item_cols, dtype=np.int64)
+    key = np.unique(u * (int(c.max()) + 1 if c.size else 1) + c) if u.size else np.empty(0, np.int64)
+    m = int(c.max()) + 1 if c.size else 1
+    uu, cc = key // m, key % m
+    off = np.zeros(n_users + 1, dtype=np.int64)
+    np.add.at(off, uu + 1, 1)
+    off = np.cumsum(off)
+    return torch.from_numpy(off).to(device), torch.from_numpy(cc.astype(np.int32)).to(device)
+
+
+def full_auc(scores, truth_off, truth_idx):
+    """per-user roc_auc_score over all scored items (src/models/bpr.py:230-254); NaN where undefined."""
+    U, I = scores.shape
+    out = torch.empty(U, dtype=torch.float32, device=scores.device)
+    check(_lib.load().brFullAuc(_f32(scores, "scores").data_ptr(), scores.stride(0), truth_off.data_ptr(), truth_idx.data_ptr(), U, I,
+                                out.data_ptr(), _stream()), "brFullAuc")
+    return out
+
+
+def map_at_k(topk_index, truth_off, truth_idx, want_ap=True, want_hits=True):
+    """(AP@k per user, hits per user) of top-k index lists (src/models/bpr.py:257-289; trainers/topKmetrics.py:85-93)."""
+    U, k = topk_index.shape
+    ap = torch.empty(U, dtype=torch.float32, device=topk_index.device) if want_ap else None
+    hits = torch.empty(U, dtype=torch.int32, device=topk_index.device) if want_hits else None
+    check(_lib.load().brMapAtK(topk_index.contiguous().data_ptr(), U, k, truth_off.data_ptr(), truth_idx.data_ptr(), _p(ap), _p(hits), _stream()),
+          "brMapAtK")
+    return ap, hits
+
+
+# ------------------------------------------------------------------------------ 8f-2 batch construction on the device
+def positives_csr(users, items, num_users: int, device):
+    """The users' positives as CSR (offsets int64 (num_users + 1), items ascending per user, dtype of `items`): the membership
+    structure of the rejection samplers.  Built once per dataset on the host (numpy lexsort: index plumbing, not the hot path)."""
+    import numpy as np
+    u = np.asarray(users.cpu() if torch.is_tensor(users) else users).astype(np.int64)
+    i = np.asarray(items.cpu() if torch.is_tensor(items) else items).astype(np.int64)
+    order = np.lexsort((i, u))
+    u, i = u[order], i[order]
+    keep = np.ones(len(u), bool)
+    keep[1:] = (u[1:] != u[:-1]) | (i[1:] != i[:-1])
+    u, i = u[keep], i[keep]
+    off = np.zeros(num_users + 1, dtype=np.int64)
+    np.add.at(off, u + 1, 1)
+    dt = items.dtype if torch.is_tensor(items) else torch.int32
+    return torch.from_numpy(np.cumsum(off)).to(device), torch.from_numpy(i).to(device).to(dt)
+
+
+def bootstrap_dataset(users, items, n_neg: int, seed: int):
+    """NeuMFModel.bootstrapDataset on the device -> (users, items, labels) of n + n_neg shuffled samples."""
+    u, ut = _ids(users, "users"); i, it = _ids(items, "items")
+    ty = _same_id_type(ut, it)
+    n = u.shape[0]
+    ou, oi = torch.empty(n + n_neg, dtype=u.dtype, device=u.device), torch.empty(n + n_neg, dtype=u.dtype, device=u.device)
+    oy = torch.empty(n + n_neg, dtype=torch.float32, device=u.device)
+    check(_lib.load().brBootstrapDataset(u.data_ptr(), i.data_ptr(), ty, n, int(n_neg), int(seed), ou.data_ptr(), oi.data_ptr(), oy.data_ptr(), _stream()),
+          "brBootstrapDataset")
+    return ou, oi, oy
+
+
+def bpr_sample_triplets(users, items, pos_off, pos_items, neg_per_pos: int, seed: int, n_cand: int, cand_items=None, max_tries: int = 16):
+    """Sampled BPR triplets -> (users, positives, negatives), n * neg_per_pos each."""
+    u, ut = _ids(users, "users"); i, it = _ids(items, "items")
+    ty = _same_id_type(ut, it)
+    n = u.shape[0]
+    T = n * int(neg_per_pos)
+    ou, op, on = (torch.empty(T, dtype=u.dtype, device=u.device) for _ in range(3))
+    check(_lib.load().brBprSampleTriplets(u.data_ptr(), i.data_ptr(), ty, n, int(neg_per_pos), pos_off.data_ptr(), pos_items.data_ptr(), _p(cand_items),
+                                          int(n_cand), int(seed), int(max_tries), ou.data_ptr(), op.data_ptr(), on.data_ptr(), _stream()),
+          "brBprSampleTriplets")
+    return ou, op, on
+
+
+def ncf_negatives(users, items, pos_off, pos_items, num_items: int, size: int, seed: int, oversample: float = 1.3, max_rounds: int = 8):
+    """generateNegativeFeedback on the device: `size` DISTINCT (user, item) pairs outside the positives, users and items drawn by
+    shuffling the two columns independently.  One host sync per round (the count of distinct valid candidates)."""
+    u, ut = _ids(users, "users"); i, it = _ids(items, "items")
+    ty = _same_id_type(ut, it)
+    n, dev, lib = u.shape[0], u.device, _lib.load()
+    n_cand = int(size * oversample) + n
+    for _ in range(max_rounds):
+        keys = torch.empty(n_cand, dtype=torch.int64, device=dev)
+        check(lib.brNcfNegativeCandidates(u.data_ptr(), i.data_ptr(), ty, n, n_cand, pos_off.data_ptr(), pos_items.data_ptr(), int(num_items), int(seed),
+                                          keys.data_ptr(), _stream()), "brNcfNegativeCandidates")
+        wsb = int(lib.brSortUniqueWorkspaceBytes(n_cand))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        uniq = torch.empty(n_cand, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(lib.brSortUniqueKeys64(keys.data_ptr(), n_cand, uniq.data_ptr(), cnt.data_ptr(), ws.data_ptr(), wsb, _stream()), "brSortUniqueKeys64")
+        n_u = int(cnt.item())
+        if n_u and int(uniq[n_u - 1].item()) == -1:      # the ~0 key of the rejected candidates sorts last
+            n_u -= 1
+        if n_u >= size:
+            ou, oi = torch.empty(size, dtype=u.dtype, device=dev), torch.empty(size, dtype=u.dtype, device=dev)
+            check(lib.brGatherPermutedPairs(uniq.data_ptr(), n_u, size, int(num_items), int(seed), ty, ou.data_ptr(), oi.data_ptr(), _stream()),
+                  "brGatherPermutedPairs")
+            return ou, oi
+        n_cand = int(n_cand * 1.6) + n        # more rounds of column shuffles
+    raise RuntimeError("ncf_negatives: not enough distinct negatives (is the interaction matrix nearly full?)")

@@ -179,6 +179,58 @@ class ShardExchange:
         return self.ctx.all_to_all(out, grads_bucket_order, self.recv_counts, self.send_counts)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Checkpoint / restore of row-sharded engines.  The reference writes ONE SavedModel: the chief to
+# checkpoints/<model>/cp, every other worker to a temporary cp/workertemp_<id> that it deletes again, because all its variables
+# are mirrored (src/models/RModel.py:139,175-196).  Here every rank OWNS different table rows, so every rank writes its shard:
+#   <path>.shard<rank>-of-<world>.pt   state_dict() of the rank's engine (row r of a table = global row r * world + rank)
+#   <path>.meta.json                   written by rank 0: world size, names of the row-sharded entries
+# Restore accepts any world size: with the same one a rank reads its own file, otherwise every saved shard is read and the
+# global rows are dealt out again (owner = row mod new world; also world 1 = the single-GPU engines).
+# ---------------------------------------------------------------------------------------------------------------------
+def _shard_file(path, rank, world):
+    return f"{path}.shard{rank:03d}-of-{world:03d}.pt"
+
+
+def save_sharded(engine, path, ctx: "DistCtx", sharded_keys):
+    """sharded_keys: state_dict entries whose dim 0 is row-sharded (tables and their optimizer slots)."""
+    import json
+    import os
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in engine.state_dict().items()}
+    torch.save(sd, _shard_file(path, ctx.rank, ctx.world))
+    if ctx.rank == 0:
+        with open(path + ".meta.json", "w") as f:
+            json.dump({"world": ctx.world, "sharded_keys": list(sharded_keys)}, f)
+    ctx.barrier()
+
+
+def load_sharded(engine, path, rank: int, world: int, global_rows: dict):
+    """global_rows: {sharded key: rows of the GLOBAL table}.  Works for any saved world size."""
+    import json
+    with open(path + ".meta.json") as f:
+        meta = json.load(f)
+    W0, keys = int(meta["world"]), set(meta["sharded_keys"])
+    if W0 == world:
+        engine.load_state_dict(torch.load(_shard_file(path, rank, world), map_location="cpu", weights_only=True))
+        return
+    shards = [torch.load(_shard_file(path, r, W0), map_location="cpu", weights_only=True) for r in range(W0)]
+    sd = {}
+    for k, v in shards[0].items():
+        if k not in keys:
+            sd[k] = v                                     # replicated (dense parameters, counters)
+            continue
+        rows = int(global_rows[k])
+        full = torch.zeros((rows,) + tuple(v.shape[1:]), dtype=v.dtype)
+        for r in range(W0):
+            n = shard_rows(rows, r, W0)
+            if n:
+                full[r::W0] = shards[r][k][:n]
+        mine = full[rank::world]
+        sd[k] = mine if mine.shape[0] else torch.zeros((1,) + tuple(v.shape[1:]), dtype=v.dtype)
+    engine.load_state_dict(sd)
+
+
 def make_sharded_engine(base_cls):
     """ShardedNeuMFEngine = NeuMFEngine with its embed / table-optimizer hooks replaced by the
     row-sharded exchange.  (Factory so this module stays importable without the HIP library.)"""
@@ -244,6 +296,31 @@ def make_sharded_engine(base_cls):
             ops.neumf_embed_forward(self.r_user[:, :D], self.r_item[:, :D], self.r_user[:, D:], self.r_item[:, D:], self.pos_u,
                                     self.pos_i, self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
 
+        SHARDED_KEYS = ("table.user", "table.user.m", "table.user.v", "table.item", "table.item.m", "table.item.v")
+
+        def save_sharded(self, path):
+            """model.save for the row-sharded engine (every rank writes its shard; see save_sharded above)."""
+            save_sharded(self, path, self.ctx, self.SHARDED_KEYS)
+
+        def load_sharded(self, path):
+            rows = {k: (self.num_user_rows if ".user" in k else self.num_item_rows) for k in self.SHARDED_KEYS}
+            load_sharded(self, path, self.ctx.rank, self.ctx.world, rows)
+
+        def state_dict(self):
+            """Per-replica BatchNorm (sync_bn=False) updates the moving statistics from each rank's own batch: reconcile them first
+            (MirroredStrategy keeps them as ON_READ variables aggregated by MEAN [TF-sem]), so every rank saves / predicts the same."""
+            self.sync_moving_stats()
+            return super().state_dict()
+
+        def sync_moving_stats(self):
+            if self.ctx.world > 1 and not self.cfg.sync_bn:
+                self.ctx.all_reduce_sum(self.moving_buf)
+                self.moving_buf.div_(self.ctx.world)
+
+        def _infer(self, users, items, labels, n):
+            self.sync_moving_stats()
+            return super()._infer(users, items, labels, n)
+
         def _serve_rows(self, stream, local_ids):
             """owner side of the lookup: rows of this rank's shard for the ids its peers asked for."""
             if self.deferred:      # rows as of the previous step, replayed in registers (binrec.h "Deferred dense Adam")
@@ -281,24 +358,36 @@ def make_sharded_two_tower(base_cls):
 
     class ShardedTwoTowerEngine(base_cls):
         def __init__(self, embed_dim, nbr_item, nbr_user, semb, device, max_batch, ctx: DistCtx, full_tables=None, **kw):
-            self.ctx = ctx
-            super().__init__(embed_dim, nbr_item, nbr_user, semb, device, max_batch, **kw)
+            self.ctx, self._full_tables = ctx, full_tables
+            self.user_rows_global, self.item_rows_global = nbr_user + 2, nbr_item + 2
+            super().__init__(embed_dim, nbr_item, nbr_user, semb, device, max_batch, **kw)     # tables and slots: this rank's shard only
             self.dist = ctx
-            r, W = ctx.rank, ctx.world
-            full = full_tables or {"user_emb": self.user_emb, "item_emb": self.item_emb}   # same seed on every rank
-            for name in ("user_emb", "item_emb"):
-                shard = full[name].to(self.device)[r::W].contiguous()
-                if shard.shape[0] == 0:
-                    shard = torch.zeros(1, embed_dim, device=self.device)
-                setattr(self, name, shard)
-                acc0 = 0.1 if self.optimizer == "Adagrad" else 0.0
-                setattr(self, name.replace("_emb", "_acc"), torch.full_like(shard, acc0))
-                if self.optimizer == "Adam":
-                    setattr(self, name.replace("_emb", "_v"), torch.zeros_like(shard))
+            self._full_tables = None
             self.xu, self.xi = ShardExchange(ctx), ShardExchange(ctx)
             cap = int(2.5 * self.max_batch) + 64
             self.user_index, self.item_index = ops.RowIndex(cap, self.id_dtype, self.device), ops.RowIndex(cap, self.id_dtype, self.device)
             self._idx_cap = cap
+
+        def _init_tables(self, user_rows, item_rows, g):
+            """only the rows this rank owns (r mod W == rank): a slice of `full_tables` (tests), else drawn with a rank-offset
+            seed - peak memory per GPU is the shard, not the replicated model"""
+            r, W = self.ctx.rank, self.ctx.world
+            gl = torch.Generator(device="cpu").manual_seed(int(g.initial_seed()) + 104729 * (r + 1))
+            for name, rows in (("user_emb", user_rows), ("item_emb", item_rows)):
+                if self._full_tables is not None:
+                    shard = self._full_tables[name][r::W].contiguous().to(self.device)
+                else:
+                    shard = (torch.rand(shard_rows(rows, r, W), self.E, generator=gl) * 0.1 - 0.05).to(self.device)
+                setattr(self, name, shard if shard.shape[0] else torch.zeros(1, self.E, device=self.device))
+
+        SHARDED_KEYS = ("user_emb", "item_emb", "user_acc", "item_acc", "user_v", "item_v")
+
+        def save_sharded(self, path):
+            save_sharded(self, path, self.ctx, [k for k in self.SHARDED_KEYS if k in self.state_dict()])
+
+        def load_sharded(self, path):
+            rows = {k: (self.user_rows_global if k.startswith("user") else self.item_rows_global) for k in self.SHARDED_KEYS}
+            load_sharded(self, path, self.ctx.rank, self.ctx.world, rows)
 
         def _lookup(self, users, items, B):
             xu, xi = ShardExchange.plan_pair(self.xu, users, self.xi, items)
@@ -349,24 +438,26 @@ def make_sharded_bpr(base_cls):
 
     class ShardedBPREngine(base_cls):
         def __init__(self, num_users, num_items, num_factor, device, max_batch, ctx: DistCtx, full_tables=None, **kw):
-            self.ctx = ctx
-            super().__init__(num_users, num_items, num_factor, device, max_batch, **kw)
-            r, W = ctx.rank, ctx.world
-            full = full_tables or {"user": self.user, "item": self.item}          # same seed on every rank
-            for name in ("user", "item"):
-                shard = full[name].to(self.device)[r::W].contiguous()
-                if shard.shape[0] == 0:
-                    shard = torch.zeros(1, self.dim, device=self.device)
-                setattr(self, name, shard)
-                setattr(self, name + "_m", torch.zeros_like(shard))
-                setattr(self, name + "_v", torch.zeros_like(shard))
-                if self.optimizer == "adam_dense":
-                    setattr(self, name + "_mark", torch.zeros(shard.shape[0], dtype=torch.uint8, device=self.device))
+            self.ctx, self._full_tables = ctx, full_tables
+            self.num_users_global, self.num_items_global = int(num_users), int(num_items)
+            super().__init__(num_users, num_items, num_factor, device, max_batch, **kw)      # tables, slots, marks: this rank's shard only
+            self._full_tables = None
             self.xu, self.xi = ShardExchange(ctx), ShardExchange(ctx)
             B = self.max_batch
             self._idx_cap = int(5 * B) + 64
             self.user_index, self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device), ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
             self.pos_b = torch.arange(B, device=self.device).to(self.id_dtype)
+
+        def _init_tables(self, num_users, num_items, init_seed):
+            """only the rows this rank owns: a slice of `full_tables` (tests), else drawn with a rank-offset seed"""
+            r, W = self.ctx.rank, self.ctx.world
+            g = torch.Generator(device="cpu").manual_seed(init_seed + 104729 * (r + 1))
+            for name, rows in (("user", num_users), ("item", num_items)):
+                if self._full_tables is not None:
+                    shard = self._full_tables[name][r::W].contiguous().to(self.device)
+                else:
+                    shard = (torch.rand(shard_rows(rows, r, W), self.dim, generator=g) * 0.1 - 0.05).to(self.device)
+                setattr(self, name, shard if shard.shape[0] else torch.zeros(1, self.dim, device=self.device))
 
         def train_step(self, users, pos, neg, batch_total: int | None = None):
             B = users.shape[0]
@@ -411,7 +502,33 @@ def make_sharded_bpr(base_cls):
                     ops.adam_dense_sweep(tab, m, v, a, mark=mark)
             self.n_seen += B
 
+        def _gather_global(self, name, ids):
+            """rows `ids` (global ids, any owner) of the row-sharded table `name` -> (len(ids), dim) on this rank."""
+            x = ShardExchange(self.ctx).plan(ids)
+            x.exchange_counts()
+            served = x.send_ids()
+            empty = torch.empty(0, self.dim, device=self.device)
+            rows = ops.gather_rows([getattr(self, name)], [served], err_flag=self.err)[0] if served.numel() else empty
+            back = x.return_rows(rows)                                               # bucket order
+            return ops.gather_rows([back], [x.inv.to(self.id_dtype)])[0] if ids.numel() else empty
+
         def predict_scores(self, user_ids, item_ids=None):
-            raise NotImplementedError("row-sharded scoring: gather the shards (state) or score per shard")
+            """bpr_predict (src/models/bpr.py:122-133) on row-sharded tables: the user vectors (and the item rows, all of them when
+            item_ids is None) come through the same id -> owner exchange as the training step; every rank must call this (it is a
+            collective) and gets the scores of ITS user_ids."""
+            u = self._gather_global("user", user_ids)
+            if item_ids is None:
+                item_ids = torch.arange(self.num_items_global, device=self.device).to(self.id_dtype)
+            it = self._gather_global("item", item_ids)
+            return ops.score_matrix(u, it)
+
+        SHARDED_KEYS = ("user", "item", "user_m", "user_v", "item_m", "item_v")
+
+        def save_sharded(self, path):
+            save_sharded(self, path, self.ctx, self.SHARDED_KEYS)
+
+        def load_sharded(self, path):
+            rows = {k: (self.num_users_global if k.startswith("user") else self.num_items_global) for k in self.SHARDED_KEYS}
+            load_sharded(self, path, self.ctx.rank, self.ctx.world, rows)
 
     return ShardedBPREngine

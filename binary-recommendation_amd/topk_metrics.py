@@ -49,21 +49,32 @@ def topKRatings(k, model, usersId, itemsId, mtype=None):
 
 
 def topKMetrics(predictions, positives, usersId, itemsId):
-    """trainers/topKmetrics.py:74-99, verbatim semantics."""
+    """trainers/topKmetrics.py:74-99: {tp, tn, fp, fn, precision, recall, hitRate}; hitRate = users with at least one hit /
+    len(usersId) over ALL users.  The reference walks every (user, item) of every top-k list against a python set (:85-93); here
+    the lists become an index matrix, the positives a CSR, and brMapAtK counts the hits per user on the GPU."""
     nbrUser, nbrItem = len(usersId), len(itemsId)
     total = nbrUser * nbrItem
     real = set(positives)
-    tp = fp = hits = 0
-    for u, topk in predictions:
-        hit = False
-        for _r, i in topk:
-            if (u, i) in real:
-                tp += 1
-                hit = True
-            else:
-                fp += 1
-        if hit:
-            hits += 1
+    urow = {u: n for n, (u, _) in enumerate(predictions)}
+    icol = {}
+    for _u, lst in predictions:
+        for _r, i in lst:
+            icol.setdefault(i, len(icol))
+    k = max((len(lst) for _u, lst in predictions), default=0)
+    tp = hits = n_pred = 0
+    if predictions and k:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        topk = np.full((len(predictions), k), -1, dtype=np.int32)          # ragged lists: -1 never matches
+        for n, (_u, lst) in enumerate(predictions):
+            topk[n, :len(lst)] = [icol[i] for _r, i in lst]
+            n_pred += len(lst)
+        rows = [urow[u] for (u, i) in real if u in urow and i in icol]
+        cols = [icol[i] for (u, i) in real if u in urow and i in icol]
+        off, idx = ops.truth_csr(len(predictions), rows, cols, dev)
+        _, h = ops.map_at_k(torch.from_numpy(topk).to(dev), off, idx, want_ap=False)
+        h = h.cpu().numpy()
+        tp, hits = int(h.sum()), int((h > 0).sum())
+    fp = n_pred - tp
     fn = len(real) - tp
     tn = total - tp - fp - fn
     return {"tp": tp, "tn": tn, "fp": fp, "fn": fn, "precision": tp / (tp + fp) if tp + fp else 0.0,

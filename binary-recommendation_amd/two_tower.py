@@ -40,8 +40,7 @@ class TwoTowerEngine:
         self.E, self.S, self.max_batch, self.lr, self.optimizer, self.rd_zero, self.id_dtype = embed_dim, semb, int(max_batch), lr, optimizer, rd_zero, id_dtype
         g = torch.Generator(device="cpu").manual_seed(init_seed)
         E, S, B = embed_dim, semb, self.max_batch
-        self.user_emb = (torch.rand(nbr_user + 2, E, generator=g) * 0.1 - 0.05).to(dev)
-        self.item_emb = (torch.rand(nbr_item + 2, E, generator=g) * 0.1 - 0.05).to(dev)
+        self._init_tables(nbr_user + 2, nbr_item + 2, g)
         # dense params flat: [Wu (E x S) | bu (S) | Wi (E x S) | bi (S)]  ([W|b] adjacent: slab layout)
         lim = math.sqrt(6.0 / (E + S))
         self.theta = torch.zeros(2 * (E * S + S), device=dev)
@@ -64,6 +63,12 @@ class TwoTowerEngine:
         self.user_index, self.item_index = ops.RowIndex(B, id_dtype, dev), ops.RowIndex(B, id_dtype, dev)
         self.err = ops.new_err_flag(dev)
         self.t, self.n_seen = 0, 0
+
+    def _init_tables(self, user_rows, item_rows, g):
+        """[TF-sem] Embedding init U(-0.05, 0.05) (rows = vocabulary + 2: '' and OOV).  A hook: the row-sharded engine allocates
+        only its shard."""
+        self.user_emb = (torch.rand(user_rows, self.E, generator=g) * 0.1 - 0.05).to(self.device)
+        self.item_emb = (torch.rand(item_rows, self.E, generator=g) * 0.1 - 0.05).to(self.device)
 
     # views
     def W(self, tower):
@@ -177,3 +182,20 @@ class TwoTowerEngine:
 
     def check_ids(self):
         ops.raise_if_flag(self.err)
+
+    # embedding tables, towers and optimizer slots (row-sharded engines hold their shard of the tables)
+    def _state_names(self):
+        names = ["user_emb", "item_emb", "theta", "user_acc", "item_acc", "theta_acc"]
+        if self.optimizer == "Adam":
+            names += ["user_v", "item_v", "theta_v"]
+        return names
+
+    def state_dict(self) -> dict:
+        sd = {"t": self.t}
+        sd.update({k: getattr(self, k) for k in self._state_names()})
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        self.t = int(sd["t"])
+        for k in self._state_names():
+            getattr(self, k).copy_(sd[k])

@@ -38,7 +38,7 @@ enum { BR_OK = 0, BR_ERR_ARG = -1, BR_ERR_HIP = -2, BR_ERR_UNSUPPORTED = -3, BR_
 enum { BR_IDS_I32 = 0, BR_IDS_I64 = 1 };
 enum { BR_ACT_LINEAR = 0, BR_ACT_SIGMOID = 1, BR_ACT_RELU = 2 };
 enum { BR_LOSS_BCE = 0, BR_LOSS_MSE = 1 };
-enum { BR_MAX_TABLES = 8, BR_SUM_SLOTS = 64, BR_STAT_REPLICAS = 8 };
+enum { BR_MAX_TABLES = 8, BR_SUM_SLOTS = 64, BR_STAT_REPLICAS = 8, BR_METRIC_SUMS = 8 };
 
 const char* brGetLastError(void);
 int brVersion(void);
@@ -279,8 +279,10 @@ int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, const float
 /* ---- head: concat [GMF dot | MLP out] -> Dense(1) -> sigmoid -> loss, and its backward --------
  * NFC_plain.py:149-155 (mf_first=1, BCE) / NeuMFModel.py:80-91 (mf_first=0, MSE).
  * a3: (B x N3); dot: (B); w4: (N3+1) in concat order; b4: (1).  Outputs: logit, prob (B);
- * sums (double[BR_SUM_SLOTS][4], slot = workgroup & 63) += [loss, sum (p-y)^2, sum |p-y|,
- * #correct@0.5] (the caller adds the slots); when labels && training:
+ * sums (double[BR_SUM_SLOTS][BR_METRIC_SUMS], slot = workgroup & 63) += [loss, sum (p-y)^2, sum |p-y|, #correct@0.5,
+ * sum BCE(logit, y), TP, FP, FN at threshold 0.5] - the sums behind the compiled metrics of trainers/NFC_plain.py:155
+ * (BinaryCrossentropy, mse, mae, FalseNegatives, FalsePositives, TrueNegatives = n - TP - FP - FN, TruePositives,
+ * BinaryAccuracy); the caller adds the slots; when labels && training:
  * da3 (B x N3), ddot (B), head_slabs (n_slabs x (N3+2)) partials of [dW4 | db4].
  * inv_batch = 1/global batch. */
 int brHeadSlabs(int64_t batch);
@@ -319,6 +321,47 @@ int brScoreMatrix(const float* Q, const float* C, int64_t n_q, int64_t n_c, int 
  * (strict '>' in __topk, topKmetrics.py:59,68).  out_scores/out_index: (U x k). */
 int brTopKRows(const float* scores, int64_t n_users, int64_t n_items, int k, float* out_scores,
                int32_t* out_index, brStream stream);
+
+/* ---- evaluation of the BPR notebook model and hit counting -------------------
+ * Ground truth per user = CSR list of COLUMN indices into the scored item list, ascending: truth_off (n_users + 1), truth_idx.
+ * brFullAuc: full_auc (src/models/bpr.py:230-254) = per user sklearn.roc_auc_score(ground truth, scores over all items): the
+ *   Mann-Whitney statistic with ties counted one half.  auc[u] = NaN for a user without positives (skipped by the reference,
+ *   bpr.py:251) or without negatives; the caller averages the others.
+ * brMapAtK: mean_average_precision_k (bpr.py:257-289) on the top-k lists of brTopKRows: ap[u] = sum over hits of
+ *   (hits so far / rank) / min(len(actual), k) (0 for a user without positives); hits[u] = hits of the list = the per-user true
+ *   positives of topKMetrics (trainers/topKmetrics.py:85-93).  ap or hits may be NULL. */
+int brFullAuc(const float* scores, int64_t ld_scores, const int64_t* truth_off, const int32_t* truth_idx, int64_t n_users,
+              int64_t n_items, float* auc, brStream stream);
+int brMapAtK(const int32_t* topk_index, int64_t n_users, int k, const int64_t* truth_off, const int32_t* truth_idx, float* ap,
+             int32_t* hits, brStream stream);
+
+/* ---- batch construction on the device: csrc/sampling.hip ---------------------
+ * Pure functions of (seed, output position): Philox4x32-10 draws + 4-round Feistel permutations with cycle walking, restated
+ * bit for bit in oracle/binrec_oracle.py.  [pandas-sem] the reference's samplers are unseeded pandas calls: the distributions
+ * are restated, not the streams.
+ * brBootstrapDataset: NeuMFModel.bootstrapDataset (src/models/NeuMFModel.py:102-109): n positives (label 1) + n_neg rows sampled
+ *   with replacement whose item column is permuted (label 0, no collision check), all shuffled.  Outputs have n + n_neg entries.
+ * brBprSampleTriplets: for every positive (user, item) row neg_per_pos triplets (user, item, negative): the negative is drawn
+ *   uniformly from cand_items (n_cand ids; NULL = 0..n_cand-1) and re-drawn while it is a positive of the user (at most max_tries
+ *   draws) - the sampled replacement of the O(U*I) enumeration of src/models/BPRModel.py:111-119.  pos_off (num_users + 1) /
+ *   pos_items: the users' positives as CSR with ascending items.
+ * brNcfNegativeCandidates + brSortUniqueKeys64 + brGatherPermutedPairs: generateNegativeFeedback (Data handling/synthetic.py:
+ *   208-223,237-256): candidates = customer column and product column shuffled independently, round after round (candidate j:
+ *   round j / n); keys[j] = user * num_items + item, or ~0 for a positive pair.  Sorted and de-duplicated they are the pool of
+ *   distinct negatives (n_unique counts a trailing ~0 if any candidate was invalid); brGatherPermutedPairs takes n_out of the
+ *   first n_keys of them in a shuffled order (the reference's head(size)). */
+int brBootstrapDataset(const void* users, const void* items, int id_type, int64_t n, int64_t n_neg, uint64_t seed, void* out_users,
+                       void* out_items, float* out_labels, brStream stream);
+int brBprSampleTriplets(const void* users, const void* items, int id_type, int64_t n, int neg_per_pos, const int64_t* pos_off,
+                        const void* pos_items, const void* cand_items, int64_t n_cand, uint64_t seed, int max_tries, void* out_users,
+                        void* out_pos, void* out_neg, brStream stream);
+int brNcfNegativeCandidates(const void* users, const void* items, int id_type, int64_t n, int64_t n_cand, const int64_t* pos_off,
+                            const void* pos_items, int64_t num_items, uint64_t seed, uint64_t* keys, brStream stream);
+int64_t brSortUniqueWorkspaceBytes(int64_t n);
+int brSortUniqueKeys64(const uint64_t* keys, int64_t n, uint64_t* out_keys, int64_t* n_unique, void* workspace, int64_t workspace_bytes,
+                       brStream stream);
+int brGatherPermutedPairs(const uint64_t* keys, int64_t n_keys, int64_t n_out, int64_t num_items, uint64_t seed, int id_type, void* out_users,
+                          void* out_items, brStream stream);
 
 /* ---- fused step driver: the whole NeuMF training / inference step from ONE host call ----------
  * trainers/NFC_plain.py:165 `model.fit` step, src/models/RModel.py:130.  Pure launch sequencing
@@ -371,7 +414,7 @@ typedef struct brNeumfStep {
   float* da3; float* ddot; float* gh2; float* gh1; float* dx0; float* g_user; float* g_item;
   float* bn;                               /* [scale1|shift1|mean1|rstd1] n1 each, then the same for layer 2 */
   double* dstat;                           /* [stats1 | stats2 | bsum1 | bsum2], each [BR_STAT_REPLICAS][2n]; zeroed in FWD1 */
-  double* msums;                           /* [BR_SUM_SLOTS][loss, sum sq err, sum abs err, #correct] accumulated */
+  double* msums;                           /* [BR_SUM_SLOTS][BR_METRIC_SUMS] accumulated (brNeumfHead) */
   float* slabs; float* hslabs;
   float* dz_ws;                            /* brDenseBackwardWorkspaceFloats(max layer) floats */
   uint32_t* keep_bits;                     /* the three dropout planes of a step back to back: brDropoutKeepWords(batch, 2*dim) +

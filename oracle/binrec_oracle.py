@@ -625,6 +625,171 @@ def topk_metrics(predictions, positives, users_id, items_id):
 
 
 # ----------------------------------------------------------------------------
+# negative sampling / batch construction, restating csrc/sampling.hip bit for bit
+#   NeuMFModel.bootstrapDataset          src/models/NeuMFModel.py:102-109
+#   BPR triplets                         src/models/BPRModel.py:94-98,111-119 (sampled instead of enumerated)
+#   generateNegativeFeedback             Data handling/synthetic.py:208-223,237-256
+# [pandas-sem] the reference's samplers are unseeded pandas calls: the distributions are restated (rows sampled with
+# replacement, a permuted item column, independently shuffled columns, distinct non-interacted pairs), not the streams.
+# ----------------------------------------------------------------------------
+def mix32(x):
+    """murmur3 finaliser on uint32 arrays."""
+    x = np.asarray(x, dtype=np.uint64) & _MASK32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x85ebca6b)) & _MASK32
+    x ^= x >> np.uint64(13); x = (x * np.uint64(0xc2b2ae35)) & _MASK32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def perm_key(seed: int, stream: int):
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    return [int(mix32((lo + 0x9E3779B9 * (r + 1)) & 0xFFFFFFFF)) ^ int(mix32(hi ^ ((stream * 0x85ebca6b + r) & 0xFFFFFFFF))) for r in range(4)]
+
+
+def feistel_perm(x, M: int, key):
+    """keyed bijection of [0, M): 4-round Feistel over ceil(log2 M) bits, cycle walking (vectorised over x)."""
+    x = np.asarray(x, dtype=np.uint64).copy()
+    if M <= 1:
+        return np.zeros_like(x)
+    b = 1
+    while b < 32 and (1 << b) < M:
+        b += 1
+    hb = np.uint64((b + 1) >> 1)
+    mask = np.uint64((1 << int(hb)) - 1)
+    todo = np.ones(x.shape, dtype=bool)
+    while todo.any():
+        v = x[todo]
+        L, R = v >> hb, v & mask
+        for r in range(4):
+            F = mix32(R ^ np.uint64(key[r])) & mask
+            L, R = R, L ^ F
+        v = (L << hb) | R
+        x[todo] = v
+        todo[todo] = v >= np.uint64(M)
+    return x.astype(np.int64)
+
+
+def draw_below(seed: int, c0, c1, stream: int, n: int):
+    """uniform integer in [0, n): floor(philox(...).x * n / 2^32)."""
+    d = philox4x32_10(c0, c1, np.uint64(stream), np.uint64(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)[0]
+    return ((d.astype(np.uint64) * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
+
+
+def bootstrap_dataset(users, items, n_neg: int, seed: int):
+    """brBootstrapDataset: positives (label 1) + n_neg rows sampled with replacement whose item column is permuted (label 0,
+    no collision check: NeuMFModel.py:103-105), all shuffled (:109).  -> (users, items, labels)."""
+    users, items = np.asarray(users), np.asarray(items)
+    n, K = len(users), int(n_neg)
+    t = np.arange(n + K, dtype=np.uint64)
+    src = feistel_perm(t, n + K, perm_key(seed, 1))
+    ou, oi, oy = np.empty(n + K, users.dtype), np.empty(n + K, items.dtype), np.empty(n + K, np.float32)
+    pos = src < n
+    ou[pos], oi[pos], oy[pos] = users[src[pos]], items[src[pos]], 1.0
+    j = (src[~pos] - n).astype(np.uint64)
+    a = draw_below(seed, j, 0, 2, n)
+    b = draw_below(seed, feistel_perm(j, K, perm_key(seed, 3)).astype(np.uint64), 0, 2, n)
+    ou[~pos], oi[~pos], oy[~pos] = users[a], items[b], 0.0
+    return ou, oi, oy
+
+
+def _positive_sets(users, items):
+    sets = {}
+    for u, i in zip(np.asarray(users).tolist(), np.asarray(items).tolist()):
+        sets.setdefault(u, set()).add(i)
+    return sets
+
+
+def bpr_sample_triplets(users, items, neg_per_pos: int, seed: int, n_cand: int, cand_items=None, max_tries: int = 16):
+    """brBprSampleTriplets: per positive row neg_per_pos negatives, uniform over the candidates, re-drawn while they are
+    positives of the user (at most max_tries draws; the last one stands)."""
+    users, items = np.asarray(users), np.asarray(items)
+    pos = _positive_sets(users, items)
+    n = len(users)
+    T = n * neg_per_pos
+    ou, op, on = np.empty(T, users.dtype), np.empty(T, items.dtype), np.empty(T, items.dtype)
+    draws = np.stack([draw_below(seed, np.arange(T, dtype=np.uint64), a, 4, n_cand) for a in range(max_tries)], axis=1)
+    for t in range(T):
+        row = t // neg_per_pos
+        u = users[row]
+        neg = 0
+        for a in range(max_tries):
+            c = int(draws[t, a])
+            neg = int(cand_items[c]) if cand_items is not None else c
+            if neg not in pos[int(u)]:
+                break
+        ou[t], op[t], on[t] = u, items[row], neg
+    return ou, op, on
+
+
+def ncf_negative_candidates(users, items, n_cand: int, num_items: int, seed: int):
+    """brNcfNegativeCandidates: candidate j = (users[perm_u_round(slot)], items[perm_i_round(slot)]) with round = j // n,
+    slot = j % n (generateSyntethic: independently shuffled columns); key = user * num_items + item, -1 for a positive pair."""
+    users, items = np.asarray(users).astype(np.int64), np.asarray(items).astype(np.int64)
+    n = len(users)
+    pos = set((users * num_items + items).tolist())
+    keys = np.empty(n_cand, np.int64)
+    for r in range((n_cand + n - 1) // n):
+        m = min(n, n_cand - r * n)
+        slot = np.arange(m, dtype=np.uint64)
+        u = users[feistel_perm(slot, n, perm_key(seed, 16 + 2 * r))]
+        i = items[feistel_perm(slot, n, perm_key(seed, 17 + 2 * r))]
+        k = u * num_items + i
+        keys[r * n:r * n + m] = np.where(np.isin(k, list(pos)), -1, k)
+    return keys
+
+
+def ncf_negatives(users, items, num_items: int, size: int, seed: int, n_cand: int):
+    """the whole generateNegativeFeedback contract on n_cand candidates: distinct valid keys in ascending order, then
+    out[t] = pool[feistel_perm(t, len(pool))] for t < size (brSortUniqueKeys64 + brGatherPermutedPairs)."""
+    keys = ncf_negative_candidates(users, items, n_cand, num_items, seed)
+    pool = np.unique(keys[keys >= 0])
+    assert len(pool) >= size
+    sel = pool[feistel_perm(np.arange(size, dtype=np.uint64), len(pool), perm_key(seed, 5))]
+    return sel // num_items, sel % num_items
+
+
+# ----------------------------------------------------------------------------
+# BPR notebook evaluation (src/models/bpr.py:230-289)
+# ----------------------------------------------------------------------------
+def roc_auc(truth, scores):
+    """sklearn.metrics.roc_auc_score for binary truth: the Mann-Whitney statistic, ties one half."""
+    truth = np.asarray(truth).astype(bool)
+    s = np.asarray(scores, dtype=np.float64)
+    pos, neg = s[truth], s[~truth]
+    if len(pos) == 0 or len(neg) == 0:
+        return float("nan")
+    below = (neg[None, :] < pos[:, None]).sum() + 0.5 * (neg[None, :] == pos[:, None]).sum()
+    return float(below) / (len(pos) * len(neg))
+
+
+def full_auc(score_rows, ground_truth, items):
+    """full_auc (bpr.py:230-254): mean over the users with positives of roc_auc_score(ground truth over ALL items, scores).
+    score_rows[u] = scores of `items` for the u-th (user_id, true_item_ids) pair of ground_truth."""
+    out = []
+    for row, (_user, true_items) in zip(score_rows, ground_truth):
+        grnd = np.zeros(len(items), dtype=np.int32)
+        for p_ in true_items:
+            grnd[items.index(p_)] = 1
+        if true_items:
+            out.append(roc_auc(grnd, row))
+    return sum(out) / len(out), out
+
+
+def mean_average_precision_k(score_rows, ground_truth, items, k=100):
+    """mean_average_precision_k (bpr.py:257-289), literally: stable descending sort, AP over the top k / min(len(actual), k)."""
+    scores = []
+    for row, (_user, actual) in zip(score_rows, ground_truth):
+        pred = sorted(dict(zip(items, row)).items(), key=lambda kv: kv[1], reverse=True)[:k]
+        score, hits = 0.0, 0.0
+        for i, (p_, _s) in enumerate(pred):
+            if p_ in actual:
+                hits += 1.0
+                score += hits / (i + 1.0)
+        scores.append(score / min(len(actual), k))
+    return float(np.mean(scores)), scores
+
+
+# ----------------------------------------------------------------------------
 # negative sampling (NeuMFModel.bootstrapDataset, NeuMFModel.py:102-123)
 # ----------------------------------------------------------------------------
 def bootstrap_negatives(users, items, neg_ratio=3.0, seed=0):

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, variant, dim, optimizer, impl, q, idt=torch.int32):
+def _worker(rank, world, port, variant, dim, optimizer, impl, q, idt=torch.int32, ckdir="/tmp"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -79,6 +79,26 @@ def _worker(rank, world, port, variant, dim, optimizer, impl, q, idt=torch.int32
             assert np.median(np.abs(got - ref)) <= 1e-7
         for k in O.DENSE_ORDER:
             np.testing.assert_allclose(eng.theta.view(k).cpu().numpy().reshape(P[k].shape), P[k], rtol=1e-5, atol=2e-2 * travel, err_msg=k)
+        # sharded checkpoint (8f-3): every rank writes its shard; restore at world 1 (re-dealt rows) and at world 2 (own file)
+        path = os.path.join(ckdir, f"ck_{variant}_{dim}_{impl}")
+        eng.save_sharded(path)
+        ue, ie = td(u[sl], idt), td(i[sl], idt)
+        pr = eng.predict(ue, ie).clone()                                   # collective: both ranks score their slice
+        again = Sharded(cfg, U, I, dev, Bl, ctx, id_dtype=idt)
+        again.load_sharded(path)
+        assert again.t == nsteps
+        for k in neumf.TABLES:
+            assert torch.equal(again.tables[k], eng.tables[k]), k
+        assert torch.equal(again.predict(ue, ie), pr)
+        if rank == 0:
+            single = neumf.NeuMFEngine(cfg, U, I, dev, Bl, id_dtype=idt)
+            par.load_sharded(single, path, 0, 1, {k: (U if ".user" in k else I) for k in eng.SHARDED_KEYS})
+            for k in neumf.TABLES:
+                full = single.tables[k]
+                assert torch.equal(full[rank::world][: eng.tables[k].shape[0]], eng.tables[k][: full[rank::world].shape[0]]), k
+                np.testing.assert_allclose(full.cpu().numpy(), P[k], rtol=1e-5, atol=5e-3 * travel, err_msg=k)
+            np.testing.assert_allclose(single.predict(ue, ie).cpu().numpy(), pr.cpu().numpy(), rtol=2e-6, atol=1e-7)
+        ctx.barrier()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -94,11 +114,11 @@ def _worker(rank, world, port, variant, dim, optimizer, impl, q, idt=torch.int32
 @pytest.mark.parametrize("variant,dim,optimizer,impl,idt", [("A", 64, "adam_dense", "deferred", torch.int32), ("A", 64, "adam_dense", "sweep", torch.int32),
                                                             ("B", 32, "adam_lazy", "sweep", torch.int32),
                                                             ("A", 128, "adam_dense", "deferred", torch.int64)])     # config 5: dim 128 (K = 256 first layer), int64 ids
-def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer, impl, idt):
+def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer, impl, idt, tmp_path):
     world, port = 2, _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, variant, dim, optimizer, impl, q, idt)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, variant, dim, optimizer, impl, q, idt, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -172,7 +192,7 @@ def test_sharded_two_tower_global_negatives(dev):
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
 
-def _bpr_worker(rank, world, port, optimizer, q):
+def _bpr_worker(rank, world, port, optimizer, q, ckdir="/tmp"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -213,6 +233,23 @@ def _bpr_worker(rank, world, port, optimizer, q):
             g = got.cpu().numpy()[: r.shape[0]]
             np.testing.assert_allclose(g, r, rtol=1e-5, atol=5e-3 * 3e-3)
             assert np.median(np.abs(g - r)) <= 1e-7
+        # sharded scoring (8f-3): bpr_predict through the id -> owner exchange; every rank asks for its own users
+        mine = rng.integers(0, U, 7 + rank)
+        items_q = np.arange(I)[::-1].copy()
+        sc = eng.predict_scores(td(mine), td(items_q)).cpu().numpy()
+        ref = np.stack([O.bpr_predict(ut, it, int(a), items_q.tolist()) for a in mine])
+        np.testing.assert_allclose(sc, ref, rtol=1e-4, atol=2e-5)          # tables within the Adam tolerance above
+        sc_all = eng.predict_scores(td(mine)).cpu().numpy()
+        np.testing.assert_allclose(sc_all[:, ::-1], sc, rtol=0, atol=1e-7)
+        path = os.path.join(ckdir, "bpr_" + optimizer)
+        eng.save_sharded(path)
+        if rank == 0:
+            single = bpr.BPREngine(U, I, F, dev, Bl, optimizer=optimizer)
+            par.load_sharded(single, path, 0, 1, {k: (U if k.startswith("user") else I) for k in eng.SHARDED_KEYS})
+            np.testing.assert_allclose(single.user.cpu().numpy(), ut, rtol=1e-5, atol=5e-3 * 3e-3)
+            assert torch.equal(single.item[rank::world], eng.item[: single.item[rank::world].shape[0]]) and single.t == eng.t
+            np.testing.assert_array_equal(single.predict_scores(td(mine), td(items_q)).cpu().numpy(), sc)
+        ctx.barrier()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -225,12 +262,12 @@ def _bpr_worker(rank, world, port, optimizer, q):
 
 
 @pytest.mark.parametrize("optimizer", ["adam_dense", "adam_lazy"])
-def test_sharded_bpr_two_ranks(dev, optimizer):
+def test_sharded_bpr_two_ranks(dev, optimizer, tmp_path):
     """BPR (config 3) with both tables row-sharded over 2 ranks == the oracle's single global step."""
     world, port = 2, _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_bpr_worker, args=(r, world, port, optimizer, q)) for r in range(world)]
+    procs = [ctxm.Process(target=_bpr_worker, args=(r, world, port, optimizer, q, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -283,6 +320,15 @@ def _local_bn_worker(rank, world, port, q):
         for k in O.DENSE_ORDER:
             got = eng.grad.view(k).cpu().numpy().reshape(gsum[k].shape).astype(np.float64)
             assert np.all(np.abs(got - gsum[k]) <= 4e-5 * gabs[k] + 1e-12), "grad " + k
+        # the replicas' moving statistics differ after the step; state_dict / predict reconcile them (mean, ON_READ [TF-sem])
+        mine = {k: eng.moving[k].clone() for k in eng.moving}
+        sd = eng.state_dict()
+        for k in mine:
+            both = ctx.all_gather_rows(mine[k].view(1, -1))
+            assert not torch.equal(both[0], both[1]), k
+            np.testing.assert_allclose(sd[k].cpu().numpy(), both.mean(0).cpu().numpy(), rtol=1e-6, atol=1e-8)
+            same = ctx.all_gather_rows(eng.moving[k].view(1, -1))
+            assert torch.equal(same[0], same[1]), k
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
