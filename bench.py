@@ -11,9 +11,12 @@ on one synthetic batch already resident in HBM.  Default optimizer = "adam_dense
 NON-lazy sparse Adam (every row of every table decays m, v and moves each step [TF-sem]) — the
 reference's semantics; the lazy-row variant is timed too and reported under "adam_lazy".
 
-Rank 0 prints ONE JSON line (metric/value/... + "roofline" for the dominant kernel, measured
-with HIP events on the launch stream inside the timed region, + "cpu_baseline": the torch-CPU
-fp32 port of trainers/NFC_plain.py's step from oracle/torch_ref.py on a bounded sample).
+Rank 0 prints ONE JSON line (metric/value/... + "roofline" for the kernel that takes the most time
+per step - chosen from the per-kernel HIP-event table of an eager pass, then bracketed by events on the
+launch stream INSIDE the timed region - + "kernels": one entry per kernel, + "legs": the plain 4-table
+gather (north_star's HBM-read target), Zipf(1.05) ids, the BPR step (config 3) and the TwoTower
+in-batch-softmax step (config 4 on one GPU), + "cpu_baseline": the torch-CPU fp32 port of
+trainers/NFC_plain.py's step from oracle/torch_ref.py on a bounded sample).
 """
 from __future__ import annotations
 
@@ -80,18 +83,124 @@ def make_batches(n, B, U, I, dev, seed, zipf):
     for _ in range(n):
         if zipf:
             # Zipf(alpha=1.05)-like ranks by inverse-CDF on a truncated power law
-            def draw(N):
-                u = torch.rand(B, generator=g, dtype=torch.float64)
-                a = 1.05
-                r = ((N ** (1 - a) - 1) * u + 1) ** (1 / (1 - a))
-                return (r.long().clamp_(1, N) - 1)
-            users, items = draw(U), draw(I)
+            users, items = zipf_ids(B, U, g), zipf_ids(B, I, g)
         else:
             users = torch.randint(0, U, (B,), generator=g)
             items = torch.randint(0, I, (B,), generator=g)
         labels = (torch.rand(B, generator=g) < 0.25).float()   # 1 pos : 3 neg (NeuMFModel.py:102)
         out.append((users.int().to(dev), items.int().to(dev), labels.to(dev)))
     return out
+
+
+def zipf_ids(n, N, g, a=1.05):
+    u = torch.rand(n, generator=g, dtype=torch.float64)
+    r = ((N ** (1 - a) - 1) * u + 1) ** (1 / (1 - a))
+    return r.long().clamp_(1, N) - 1
+
+
+def time_us(fn, reps=20, rounds=5):
+    """mean microseconds of one fn() (a short launch sequence on torch's current stream): `reps` calls captured into a hipGraph
+    (no host launch gaps), replayed `rounds` times between two events; eager loop when the capture is refused."""
+    fn()
+    torch.cuda.synchronize()
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        replay, mode = g.replay, "hipGraph replay"
+    except Exception:  # noqa: BLE001
+        replay, mode = (lambda: [fn() for _ in range(reps)]), "eager loop"
+    replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(rounds):
+        replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / (reps * rounds), mode
+
+
+def loop_ms(step, n=30, warm=5):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def gather_leg(ops, dev, U, I, D, B, seed):
+    """north_star's target: the embedding gather alone at batch 65 536 / dim 64 - (a) brGatherRows over the four separate
+    (rows x D) tables of the reference graph (NFC_plain.py:118-126), (b) the engine's form: two fused [mlp | mf] tables, lookup +
+    GMF dot + MLP concat in one launch (brNeumfEmbedForward).  frac_read = gathered bytes / time / 8 TB/s (reads only, the
+    north_star figure); the kernels also write what they read (frac_all counts both directions + ids)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    tabs = [torch.rand(U, D, device=dev), torch.rand(I, D, device=dev), torch.rand(U, D, device=dev), torch.rand(I, D, device=dev)]
+    fu, fi = torch.rand(U, 2 * D, device=dev), torch.rand(I, 2 * D, device=dev)
+    outs = [torch.empty(B, D, device=dev) for _ in range(4)]
+    x0, dot = torch.empty(B, 2 * D, device=dev), torch.empty(B, device=dev)
+    rd = B * 4 * D * 4
+    for name, draw in (("uniform", lambda N: torch.randint(0, N, (B,), generator=g)), ("zipf", lambda N: zipf_ids(B, N, g))):
+        users, items = draw(U).int().to(dev), draw(I).int().to(dev)
+        t4, mode = time_us(lambda: ops.gather_rows(tabs, [users, items, users, items], outs))
+        tf, _ = time_us(lambda: ops.neumf_embed_forward(fu[:, :D], fi[:, :D], fu[:, D:], fi[:, D:], users, items, 1, x0, dot))
+        out[name] = {"gather_rows_4_tables": {"kernel": "gather_rows_kernel", "us": t4, "read_GBps": rd / t4 * 1e-3, "frac_read": rd / t4 * 1e-3 / HBM_PEAK_GBPS,
+                                              "frac_all": (2 * rd + 16 * B) / t4 * 1e-3 / HBM_PEAK_GBPS},
+                     "neumf_embed_fwd_fused_tables": {"kernel": "neumf_embed_fwd_kernel", "us": tf, "read_GBps": rd / tf * 1e-3, "frac_read": rd / tf * 1e-3 / HBM_PEAK_GBPS,
+                                                      "frac_all": (rd + B * 2 * D * 4 + 12 * B) / tf * 1e-3 / HBM_PEAK_GBPS}}
+    out.update({"batch": B, "dim": D, "tables": f"{U} x {D} (x2), {I} x {D} (x2)", "gathered_bytes": rd, "peak_GBps": HBM_PEAK_GBPS, "timing": mode,
+                "target": "north_star: >= 0.40 of the HBM-read roofline on the gather at batch 65 536 / dim 64"})
+    return out
+
+
+def bpr_leg(dev, U, I, F, B, seed):
+    """BASELINE configs[2]: the BPR triplet step (src/models/BPRModel.py:38-74) at the same synthetic scale, Keras-Adam."""
+    bpr = importlib.import_module("binary-recommendation_amd.bpr")
+    g = torch.Generator().manual_seed(seed)
+    out = {"workload": f"BPR step, {U} users x {I} items, {F} factors, {B} triplets, uniform ids"}
+    for opt in ("adam_dense", "adam_lazy"):
+        e = bpr.BPREngine(U, I, F, dev, B, optimizer=opt)
+        u, p, n = (torch.randint(0, N, (B,), generator=g).int().to(dev) for N in (U, I, I))
+        ms = loop_ms(lambda: e.train_step(u, p, n))
+        e.check_ids()
+        uu = int(torch.unique(u).numel()) + int(torch.unique(torch.cat([p, n])).numel())
+        # 3 rows in, 3 row gradients out and in again, touched rows of table + m + v read and written; non-lazy: every row of both tables
+        alg = B * 3 * F * 4 * 3 + (6 * 4 * F * (U + I) if opt == "adam_dense" else uu * 6 * 4 * F)
+        out[opt] = {"ms_per_step": ms, "triplets_per_s": B / ms * 1e3, "algorithmic_bytes_per_step": alg, "frac_of_hbm_peak": alg / ms * 1e-6 / HBM_PEAK_GBPS}
+        del e
+        torch.cuda.empty_cache()
+    out["adam_lazy"]["note"] = "touched rows only: NOT the reference's (Keras non-lazy) semantics"
+    return out
+
+
+def twotower_leg(ops, dev, U, I, E, S, B, seed):
+    """BASELINE configs[3] on one GPU: trainers/twoTower.py's step (2 lookups, two E x S towers, in-batch softmax over the batch's B
+    candidates, Adagrad) + the in-batch softmax kernels alone against the fp32 MFMA peak (3 GEMMs of B x B x S: S = Q C^T, dQ = P C,
+    dC = P^T Q; the recomputation of S in the gradient sweep is not counted)."""
+    tt = importlib.import_module("binary-recommendation_amd.two_tower")
+    g = torch.Generator().manual_seed(seed)
+    e = tt.TwoTowerEngine(E, I, U, S, dev, B)
+    u, it = (torch.randint(0, U, (B,), generator=g) + 2).int().to(dev), (torch.randint(0, I, (B,), generator=g) + 2).int().to(dev)
+    ms = loop_ms(lambda: e.train_step(u, it))
+    e.check_ids()
+    del e
+    q, c = torch.randn(B, S, device=dev) * 0.3, torch.randn(B, S, device=dev) * 0.3
+    lse, slots = torch.empty(B, device=dev), torch.zeros(64, dtype=torch.float64, device=dev)
+    dq, dc = torch.empty_like(q), torch.empty_like(c)
+    t_lse, mode = time_us(lambda: ops.inbatch_softmax_lse(q, c, it, it, 0, lse, slots), reps=10)
+    t_grad, _ = time_us(lambda: ops.inbatch_softmax_grad(q, c, it, it, 0, lse, dq, dc), reps=10)
+    flop = 2.0 * B * B * S
+    return {"workload": f"TwoTower step, {U} users x {I} items, embed {E}, semb {S}, batch {B} (in-batch negatives: {B} candidates), Adagrad, uniform ids",
+            "ms_per_step": ms, "pairs_per_s": B / ms * 1e3, "launch_mode": "eager launches from the Python host",
+            "inbatch_softmax": {"lse_us": t_lse, "grad_us": t_grad, "bound": "mfma", "algorithmic_flop": 3 * flop,
+                                "achieved_TFLOPs": 3 * flop / (t_lse + t_grad) * 1e-6, "frac": 3 * flop / (t_lse + t_grad) * 1e-6 / MFMA_F32_PEAK_TFLOPS,
+                                "lse_frac": flop / t_lse * 1e-6 / MFMA_F32_PEAK_TFLOPS, "grad_frac": 2 * flop / t_grad * 1e-6 / MFMA_F32_PEAK_TFLOPS,
+                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "timing": mode}}
 
 
 def run_steps(eng, batches, n, row0, batch_total):
@@ -170,6 +279,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the extra adam_lazy timing")
     ap.add_argument("--no-graph", action="store_true", help="single GPU: time the eager launch sequence instead of hipGraph replay")
+    ap.add_argument("--no-legs", action="store_true", help="skip the gather / Zipf / BPR / TwoTower legs")
     ap.add_argument("--profile-steps", type=int, default=10, help="graph mode: eager steps probed per kernel before the timed region")
     args = ap.parse_args()
 
@@ -221,31 +331,84 @@ def main():
     n_batches = min(args.steps + args.warmup, 32)
     batches = make_batches(n_batches, B, U, I, dev, 1234 + rank, args.zipf)
 
-    # ---- timed region.  HIP events recorded by the step driver on the launch stream bracket the kernel
-    #      launches; the roofline figures come from these.
-    #      single GPU (default): the step is replayed as hipGraph A -> eager adam_dense_sweep[user] -> hipGraph B,
-    #      so the dominant kernel is still bracketed by events INSIDE the timed region (timed events cannot be
-    #      recorded into a capture on ROCm 7.2); the other kernels' table comes from an eager pass before it.
+    # ---- per-kernel table, then the timed region.
+    #      single GPU (default): (1) an eager pass with a HIP event pair around every launch of the step driver, the dedup sorts kept
+    #      on the launch stream so each kernel runs alone -> the per-kernel table; (2) the kernel with the largest time per step is
+    #      left OUTSIDE the hipGraphs (graph A -> eager launch with events -> graph B) so it is bracketed by events INSIDE the timed
+    #      region (timed events cannot be recorded into a capture on ROCm 7.2); (3) the whole step in one graph is timed too.
     lib = _lib.load()
     TAG = {k[7:]: v for k, v in _lib.parse_enums().items() if k.startswith("BR_TAG_")}
+    n1, n2, n3 = eng.cfg.hidden
+    l1, l2 = (n1 + 3) & ~3, (n2 + 3) & ~3
+    loc_users, loc_items = eng.local_rows("user_mf"), eng.local_rows("item_mf")
+    deferred_mode = bool(getattr(eng, "deferred", False))
+    fused_rows = deferred_mode and world == 1      # the pair launch forms the MF-row gradients itself (neumf_step.cpp fuse_mf)
+    uniq_u = sum(int(torch.unique(b[0]).numel()) for b in batches) / len(batches)
+    uniq_i = sum(int(torch.unique(b[1]).numel()) for b in batches) / len(batches)
+    # algorithmic work per launch (DESIGN.md "Algorithmic bytes"): name, kernel symbol, bound, work, phases to keep eager
+    rows_pair = 8 + 2 * D * 4 + (4 if fused_rows else 0)            # sorted id + position, one 2D-float gradient row (+ ddot)
+    per_uniq = 6 * 2 * D * 4 + (8 if deferred_mode else 0)           # table, m, v rows read and written (+ last[])
+    ROWS_ALL = ("OPT_TABLES", "ROWS_USER", "SWEEP_USER", "ROWS_ITEM", "SWEEP_ITEM")
+    SPEC = {
+        "EMBED_FWD": (("neumf_embed_fwd_deferred (4 lookups + replay of lagging rows + GMF dot + concat)", "neumf_embed_fwd_deferred_kernel", "hbm",
+                       B * (4 * D * 4 + 2 * D * 4 + 2 * D * 4 + 12)) if deferred_mode and world == 1 else
+                      ("neumf_embed_fwd (4 lookups + GMF dot + concat)", "neumf_embed_fwd_kernel", "hbm", B * (4 * D * 4 + 2 * D * 4 + 12)), ("FWD1",)),
+        "EMBED_BWD": (("mf_grad_inplace" if deferred_mode and world == 1 else "neumf_embed_bwd", "neumf_embed_bwd_kernel", "hbm", B * (4 * D * 4 + 8)), ("OPT_TABLES",)),
+        "KEEP_BITS": ((f"dropout keep-bit planes (Philox4x32-10, {2 * D} + {n1} + {n2} bits per row)", "keep_bits_kernel", None, None), ("FWD1",)),
+        "STEP_STATE": (("step counter / alpha_t advance + BatchNorm sum reset", "step_state_advance_kernel", None, None), ("FWD1",)),
+        "FWD_L1": ((f"dense_fwd[{2 * D}x{n1}]", "dense_fwd_kernel", "mfma", 2.0 * B * 2 * D * n1), ("FWD1",)),
+        "FWD_L2": ((f"dense_fwd[{n1}x{n2}] (+ BatchNorm 1 finalize)", "dense_fwd_kernel", "mfma", 2.0 * B * n1 * n2), ("FWD2",)),
+        "FWD_L3": ((f"dense_fwd[{n2}x{n3}]", "dense_fwd_kernel", "mfma", 2.0 * B * n2 * n3), ("FWD3",)),
+        "HEAD": ((f"tail: BatchNorm 2 finalize + dense {n2}x{n3} fwd + head + loss + their backward (one launch)", "neumf_tail_mfma_kernel", "mfma",
+                  6.0 * B * n2 * n3), ("FWD3",)),
+        "BWD_L3": ((f"dense_bwd[{n2}x{n3}]", "dense_bwd_kernel", "mfma", 4.0 * B * n2 * n3), ("FWD3",)),
+        "BWD_L2": ((f"dense_bwd[{n1}x{n2}] (dx + dW + db + BatchNorm sums, one launch)", "dense_bwd_kernel", "mfma", 4.0 * B * n1 * n2), ("BWD2",)),
+        "BWD_L1": ((f"dense_bwd[{2 * D}x{n1}] (dx + dW + db, one launch)", "dense_bwd_kernel", "mfma", 4.0 * B * 2 * D * n1), ("BWD1",)),
+        "INDEX_SORT": (("row index, both tables: chunk sort", "chunk_sort_kernel", None, None), ("FWD1",)),
+        "INDEX_USER": (("row index, both tables: chunk rank / merge", "chunk_rank_kernel", None, None), ("FWD1",)),
+        "INDEX_ITEM": (("row index [item]", "chunk_rank_kernel", None, None), ("FWD1",)),
+        "SEG_PARTIALS": (("segment partial sums of long duplicate runs (both tables)", "segment_partials_kernel", None, None), ROWS_ALL),
+        "ADAM_ROWS_USER": ((("adam_rows_sorted[user + item, one launch]", "adam_rows_sorted_kernel", "hbm", 2 * B * rows_pair + (uniq_u + uniq_i) * per_uniq) if world == 1 else
+                            ("adam_rows_sorted[user]", "adam_rows_sorted_kernel", "hbm", B * rows_pair + uniq_u * per_uniq)), ROWS_ALL),
+        "ADAM_ROWS_ITEM": (("adam_rows_sorted[item]", "adam_rows_sorted_kernel", "hbm", B * rows_pair + uniq_i * per_uniq), ROWS_ALL),
+        "SWEEP_USER": ((f"adam_dense_sweep[user {loc_users}x{2 * D}]", "adam_dense_sweep_kernel", "hbm", 6 * 4 * loc_users * 2 * D), ("SWEEP_USER",)),
+        "SWEEP_ITEM": ((f"adam_dense_sweep[item {loc_items}x{2 * D}]", "adam_dense_sweep_kernel", "hbm", 6 * 4 * loc_items * 2 * D), ("SWEEP_ITEM",)),
+        "ADAM_FLAT": (("dense finalize: slab reduce x3 + BatchNorm grads + Adam (one launch)" if world == 1 else "adam_flat", "dense_finalize_kernel", None, None), ("OPT_DENSE",)),
+        "REDUCE": (("reduce_slabs (each)", "reduce_slabs_kernel", None, None), ("BWD1",)),
+        "SMALL": (("bn / small (each)", "-", None, None), ("BNG",)),
+    }
     use_graph = world == 1 and not args.no_graph
     run_steps(eng, batches, args.warmup, row0, batch_total)   # warm-up outside the probe
     pyprobe = None
     eager_profile = None
     graph_error = None
+    dom_tag = None
+
+    def per_step_us(per_tag, nsteps):
+        return {t: us * n / nsteps for t, (us, n) in per_tag.items()}
+
+    def pick_dominant(per_tag, nsteps):
+        share = per_step_us(per_tag, nsteps)
+        inv = {v: k for k, v in TAG.items()}
+        cands = [(share[t], inv[t]) for t in share if inv.get(t) in SPEC and SPEC[inv[t]][0][2] is not None]
+        return max(cands)[1] if cands else None
+
     if use_graph:
         np_ = max(1, min(args.profile_steps, args.steps))
         if lib.brProbeEnable(64 * np_) != 0:
             raise RuntimeError(lib.brGetLastError().decode())
+        aux = eng.step_struct.aux_stream
+        eng.step_struct.aux_stream = None        # dedup sorts on the launch stream: every kernel alone between its two events
         dte = timed(eng, batches, np_, 0, ctx, row0, batch_total)
+        eng.step_struct.aux_stream = aux
         per_tag = read_probe(lib)
         lib.brProbeEnable(0)
         eager_profile = {"steps": np_, "ms_per_step": dte / np_ * 1e3, "value": B * np_ / dte, "unit": "pairs/s",
-                         "note": "eager launch sequence with a HIP event pair around every launch (source of the per-kernel table)"}
+                         "note": "eager, serial launch sequence with a HIP event pair around every launch (source of the per-kernel table)"}
         log(f"eager profiling pass: {dte / np_ * 1e3:.3f} ms/step")
-        sweeping = args.optimizer == "adam_dense" and not eng.deferred
+        dom_tag = pick_dominant(per_tag, np_)
         try:
-            eng.enable_graph(B, eager_phases=("SWEEP_USER",) if sweeping else ("BWD1",))
+            eng.enable_graph(B, eager_phases=SPEC[dom_tag][1])
             run_steps(eng, batches, max(2, args.warmup), row0, batch_total)
         except Exception as exc:  # noqa: BLE001  - a driver / runtime that cannot capture this step: time the eager sequence
             log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
@@ -253,11 +416,12 @@ def main():
             use_graph = False
             graph_error = f"{type(exc).__name__}: {exc}"
     if use_graph:
-        if lib.brProbeEnable(4 * args.steps) != 0:
+        if lib.brProbeEnable(16 * args.steps) != 0:
             raise RuntimeError(lib.brGetLastError().decode())
         dt = timed(eng, batches, args.steps, 0, ctx, row0, batch_total)
         live = read_probe(lib)          # only the launches outside the graphs
         lib.brProbeEnable(0)
+        live = {t: v for t, v in live.items() if t == TAG[dom_tag]}     # its phase neighbours keep their serial-pass figures
         per_tag.update(live)
         probe_src = {t: (("timed region", args.steps) if t in live else ("eager profiling pass", np_)) for t in per_tag}
     else:
@@ -277,83 +441,51 @@ def main():
             pyprobe.merge_into(per_tag)
         lib.brProbeEnable(0)
         probe_src = {t: ("timed region", args.steps) for t in per_tag}
+        dom_tag = pick_dominant(per_tag, args.steps)
     eng.check_ids()
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     pairs_per_s = B * world * args.steps / dt
 
-    n1, n2, n3 = eng.cfg.hidden
-    loc_users, loc_items = eng.local_rows("user_mf"), eng.local_rows("item_mf")
     kernels = {}
-
-    def hbm(name, tag, bytes_):
-        if TAG[tag] in per_tag:
-            us, n = per_tag[TAG[tag]]
-            kernels[name] = {"_tag": TAG[tag], "us": us, "launches": n, "bound": "hbm", "achieved_GBps": bytes_ / us * 1e-3,
-                             "frac": bytes_ / us * 1e-3 / HBM_PEAK_GBPS, "bytes": bytes_}
-
-    def mfma(name, tag, flop):
-        if TAG[tag] in per_tag:
-            us, n = per_tag[TAG[tag]]
-            kernels[name] = {"_tag": TAG[tag], "us": us, "launches": n, "bound": "mfma", "achieved_TFLOPs": flop / us * 1e-6,
-                             "frac": flop / us * 1e-6 / MFMA_F32_PEAK_TFLOPS, "flop": flop}
-
-    # algorithmic work per launch: gather 4*D*4 B + 8 B ids per pair; Adam sweep 6*4 B per
-    # table element; Adam rows: g row + read/write theta,m,v = 7*4 B per element of a touched row (upper bound: no dups)
-    if getattr(eng, "deferred", False) and not eng.sharded:
-        # deferred lookup: a lagging row also brings its m and v (upper bound: every row lags), plus x0 and the MF stash out
-        hbm("neumf_embed_fwd_deferred(gather4 + replay + dot + concat)", "EMBED_FWD", B * (3 * 4 * D * 4 + 4 * D * 4 + 16))
-        hbm("mf_grad_inplace", "EMBED_BWD", B * (2 * 2 * D * 4 + 4))
-    else:
-        hbm("neumf_embed_fwd(gather4+dot+concat)", "EMBED_FWD", B * (4 * D * 4 + 8))
-        hbm("neumf_embed_bwd", "EMBED_BWD", B * (4 * D * 4 + 8))
-    hbm(f"adam_dense_sweep[user {loc_users}x{2 * D}]", "SWEEP_USER", 6 * 4 * loc_users * 2 * D)
-    hbm(f"adam_dense_sweep[item {loc_items}x{2 * D}]", "SWEEP_ITEM", 6 * 4 * loc_items * 2 * D)
-    if world == 1:   # the step driver updates both fused tables in one launch
-        hbm("adam_rows_sorted[user + item, one launch]", "ADAM_ROWS_USER", 2 * B * 7 * 2 * D * 4)
-    else:
-        hbm("adam_rows_sorted[user]", "ADAM_ROWS_USER", B * 7 * 2 * D * 4)
-        hbm("adam_rows_sorted[item]", "ADAM_ROWS_ITEM", B * 7 * 2 * D * 4)
-    mfma(f"dense_fwd[{2 * D}x{n1}]", "FWD_L1", 2.0 * B * 2 * D * n1)
-    mfma(f"dense_fwd[{n1}x{n2}]", "FWD_L2", 2.0 * B * n1 * n2)
-    mfma(f"dense_fwd[{n2}x{n3}]", "FWD_L3", 2.0 * B * n2 * n3)
-    mfma(f"dense_bwd[{2 * D}x{n1}]", "BWD_L1", 4.0 * B * 2 * D * n1)
-    mfma(f"dense_bwd[{n1}x{n2}]", "BWD_L2", 4.0 * B * n1 * n2)
-    mfma(f"dense_bwd[{n2}x{n3}]", "BWD_L3", 4.0 * B * n2 * n3)
-    for name, tag in (("row_index_build[user]", "INDEX_USER"), ("row_index_build[item]", "INDEX_ITEM"), ("tail: dense 3 fwd + head + loss + their backward (one launch)", "HEAD"),
-                      ("reduce_slabs (each)", "REDUCE"), ("bn/small (each)", "SMALL"),
-                      ("dense finalize: slab reduce x3 + BN grads + Adam (one launch)" if world == 1 else "adam_flat", "ADAM_FLAT")):
-        if TAG[tag] in per_tag:
-            kernels[name] = {"_tag": TAG[tag], "us": per_tag[TAG[tag]][0], "launches": per_tag[TAG[tag]][1]}
     gpu_us_per_step = 0.0
-    for v in kernels.values():
-        v["measured_in"], nsteps = probe_src[v.pop("_tag")]
-        gpu_us_per_step += v["us"] * v["launches"] / nsteps
+    for tname, ((name, sym, bound, work), _ph) in SPEC.items():
+        if TAG.get(tname) not in per_tag:
+            continue
+        us, n = per_tag[TAG[tname]]
+        src, nsteps = probe_src[TAG[tname]]
+        k = {"kernel": sym, "us": us, "launches_per_step": n / nsteps, "us_per_step": us * n / nsteps, "measured_in": src}
+        if bound == "hbm":
+            k.update({"bound": "hbm", "bytes": work, "achieved_GBps": work / us * 1e-3, "frac": work / us * 1e-3 / HBM_PEAK_GBPS})
+        elif bound == "mfma":
+            k.update({"bound": "mfma", "flop": work, "achieved_TFLOPs": work / us * 1e-6, "frac": work / us * 1e-6 / MFMA_F32_PEAK_TFLOPS})
+        kernels[name] = k
+        gpu_us_per_step += k["us_per_step"]
+    for k in kernels.values():
+        k["share_of_kernel_time"] = k["us_per_step"] / gpu_us_per_step
 
-    # dominant kernel of the step
-    if args.optimizer == "adam_dense" and not eng.deferred:
-        dom_key, dom_name = f"adam_dense_sweep[user {loc_users}x{2 * D}]", "adam_dense_sweep_kernel"
-    else:
-        dom_key, dom_name = f"dense_bwd[{2 * D}x{n1}]", "dense_dx_kernel+dense_dw_kernel"
-    dom = kernels.get(dom_key)
-    traffic = None
+    # the roofline entry = the kernel with the largest time per step (measured, not assumed)
+    roofline = traffic = tmeta = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom_name)
-        except Exception:  # noqa: BLE001
-            traffic = None
-    roofline = None
-    if dom is not None:
-        if dom["bound"] == "hbm":
-            roofline = {"bound": "hbm", "kernel": f"{dom_name} ({dom_key})", "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": dom["frac"], "traffic": traffic, "avg_launch_us": dom["us"],
-                        "algorithmic_bytes_per_launch": dom["bytes"], "measured_in": dom["measured_in"]}
-        else:
-            roofline = {"bound": "mfma", "kernel": f"{dom_name} ({dom_key})", "achieved": dom["achieved_TFLOPs"],
-                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
-                        "avg_launch_us": dom["us"], "algorithmic_flop_per_launch": dom["flop"], "measured_in": dom["measured_in"]}
+    if dom_tag is not None:
+        (dom_key, dom_sym, _b, _w), _ = SPEC[dom_tag]
+        dom = kernels[dom_key]
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch", {}).get(dom_sym)
+                tmeta = {"source": tj.get("source"), "commit": tj.get("commit")}
+            except Exception:  # noqa: BLE001
+                traffic = None
+        roofline = {"bound": dom["bound"], "kernel": f"{dom_sym} ({dom_key})", "achieved": dom["achieved_GBps" if dom["bound"] == "hbm" else "achieved_TFLOPs"],
+                    "peak": HBM_PEAK_GBPS if dom["bound"] == "hbm" else MFMA_F32_PEAK_TFLOPS, "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s",
+                    "frac": dom["frac"], "traffic": traffic, "traffic_from": tmeta, "avg_launch_us": dom["us"], "measured_in": dom["measured_in"],
+                    "share_of_kernel_time": dom["share_of_kernel_time"], "chosen_by": "largest measured time per step among the kernels of the eager pass"}
+        roofline["algorithmic_bytes_per_launch" if dom["bound"] == "hbm" else "algorithmic_flop_per_launch"] = dom["bytes" if dom["bound"] == "hbm" else "flop"]
+        if dom["bound"] == "hbm" and dom_tag.startswith("ADAM_ROWS"):
+            roofline["unique_rows_per_batch"] = {"user": uniq_u, "item": uniq_i}
+    else:
+        dom_key = None
 
-    deferred_mode = bool(getattr(eng, "deferred", False))
     lazy = sweep_leg = flush_info = full_graph = None
     if use_graph:
         # the same engine with the WHOLE step in one graph (what a training loop runs; no launch is left
@@ -412,6 +544,37 @@ def main():
                 "note": "touched-rows-only Adam: NOT the reference's (Keras non-lazy) semantics"}
         del eng2
 
+    legs = None
+    if rank == 0 and world == 1 and not args.no_legs:
+        ops = importlib.import_module("binary-recommendation_amd.ops")
+        try:
+            del eng
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        legs = {}
+        log("legs: gather")
+        legs["gather"] = gather_leg(ops, dev, args.users, args.items, D, B, 99)
+        torch.cuda.empty_cache()
+        log("legs: zipf")
+        zb = make_batches(n_batches, B, U, I, dev, 4321, True)
+        ez = build(args.optimizer)
+        run_steps(ez, zb, 2, row0, batch_total)
+        ez.enable_graph(B)
+        dz = timed(ez, zb, args.steps, args.warmup, None, row0, batch_total)
+        ez.check_ids()
+        legs["zipf"] = {"workload": "the headline step with Zipf(1.05) user and item ids (whole step in one hipGraph)", "value": B * args.steps / dz, "unit": "pairs/s",
+                        "ms_per_step": dz / args.steps * 1e3,
+                        "unique_rows_per_batch": {"user": sum(int(torch.unique(b[0]).numel()) for b in zb) / len(zb),
+                                                  "item": sum(int(torch.unique(b[1]).numel()) for b in zb) / len(zb)}}
+        del ez, zb
+        torch.cuda.empty_cache()
+        log("legs: bpr")
+        legs["bpr"] = bpr_leg(dev, args.users, args.items, D, B, 7)
+        log("legs: twotower")
+        legs["twotower"] = twotower_leg(ops, dev, args.users, args.items, 64, 64, 8192, 11)
+        torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline start")
@@ -429,7 +592,8 @@ def main():
                                    f"{'Zipf(1.05)' if args.zipf else 'uniform'} ids",
                        "global_batch": batch_total, "parallelism": "single GPU" if world == 1 else f"row-sharded tables x{world} + dp{world}, {'global' if args.sync_bn else 'per-replica'} BatchNorm",
                        "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
+            "roofline": roofline, "cpu_baseline": cpu, "legs": legs, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
+            "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i},
             "launch_mode": (f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)" if use_graph
                             else "eager launches (brNeumfStepRun)"),
             "eager": eager_profile, "graph_error": graph_error,

@@ -35,6 +35,15 @@ inline void probe_end(hipStream_t s) {
 }
 }  // namespace
 
+// a call that launches two kernels splits its record: what ran so far is retagged `first_tag`, the rest keeps the call's tag
+void br::probe_split(int first_tag, hipStream_t s) {
+  if (!g_probe.open) return;
+  const int tag = g_probe.tag[g_probe.n];
+  g_probe.tag[g_probe.n] = first_tag;
+  probe_end(s);
+  probe_begin(tag, s);
+}
+
 extern "C" int brProbeEnable(int capacity) {
   for (hipEvent_t e : g_probe.ev) (void)hipEventDestroy(e);
   g_probe.ev.clear(); g_probe.tag.clear(); g_probe.n = 0; g_probe.cap = 0;
@@ -156,7 +165,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const int64_t n_dstat = (int64_t)BR_STAT_REPLICAS * (4 * n1 + 4 * n2);
   // (a host that runs the embedding exchange itself - no EMBED bit - advanced the state before its lookup)
   if ((ph & BR_PH_FWD1) && (ph & BR_PH_EMBED) && train && s->step_state)
-    RUN(BR_TAG_SMALL, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, s->dstat, n_dstat, stream));
+    RUN(BR_TAG_STEP_STATE, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, s->dstat, n_dstat, stream));
   // dropout keep-bit planes of the three sites [2D | n1 | n2], filled once per step (after the step counter advanced)
   uint32_t *keep0 = nullptr, *keep1 = nullptr, *keep2 = nullptr;
   if (p > 0.f) {
@@ -167,7 +176,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     const uint32_t sites[3] = {0, 1, 2};
     const int widths[3] = {2 * D, n1, n2};
     uint32_t* const outs[3] = {keep0, keep1, keep2};
-    RUN(BR_TAG_SMALL, brDropoutKeepBits(p, s->seed, (uint32_t)s->step, s->row0, B, 3, sites, widths, outs, stream));
+    RUN(BR_TAG_KEEP_BITS, brDropoutKeepBits(p, s->seed, (uint32_t)s->step, s->row0, B, 3, sites, widths, outs, stream));
   }
   if (ph & BR_PH_FWD1) {
     if (train && !s->step_state) {

@@ -455,11 +455,11 @@ static int index_build_rank(IdxJobs& jobs, int n_jobs, int id_type, int64_t n, h
   const int n_chunks = (int)ceil_div(n, large ? kChunkL : kChunkS);
   const dim3 g1((unsigned)n_chunks, (unsigned)n_jobs), g2((unsigned)ceil_div(n, 256), (unsigned)n_jobs);
   if (id_type == BR_IDS_I32) {
-    if (large) { chunk_sort_kernel<int32_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
-    else { chunk_sort_kernel<int32_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); chunk_rank_kernel<int32_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    if (large) { chunk_sort_kernel<int32_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    else { chunk_sort_kernel<int32_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int32_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
   } else {
-    if (large) { chunk_sort_kernel<int64_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
-    else { chunk_sort_kernel<int64_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); chunk_rank_kernel<int64_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    if (large) { chunk_sort_kernel<int64_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    else { chunk_sort_kernel<int64_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int64_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
   }
   BR_CHECK_LAUNCH("brRowIndexBuild");
   return BR_OK;
@@ -643,6 +643,7 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   if (with_partials) {
     const int rc = launch_partials(segs, n_jobs, id_type, n, dim, g, split, (hipStream_t)stream);
     if (rc != BR_OK) return rc;
+    probe_split(BR_TAG_SEG_PARTIALS, (hipStream_t)stream);
   }
   const dim3 grid((unsigned)ceil_div(n, 256 >> g.lpr_log2), (unsigned)n_jobs);
   AdamHp h = make_hp(alpha_t, beta1, beta2, eps);

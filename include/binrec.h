@@ -500,7 +500,9 @@ enum {
   BR_TAG_BWD_L3 = 6, BR_TAG_BWD_L2 = 7, BR_TAG_BWD_L1 = 8, BR_TAG_EMBED_BWD = 9,
   BR_TAG_INDEX_USER = 10, BR_TAG_INDEX_ITEM = 11, BR_TAG_ADAM_ROWS_USER = 12, BR_TAG_SWEEP_USER = 13,
   BR_TAG_ADAM_ROWS_ITEM = 14, BR_TAG_SWEEP_ITEM = 15, BR_TAG_ADAM_FLAT = 16, BR_TAG_REDUCE = 17,
-  BR_TAG_SMALL = 18
+  BR_TAG_SMALL = 18, BR_TAG_KEEP_BITS = 19, BR_TAG_STEP_STATE = 20,
+  BR_TAG_SEG_PARTIALS = 21,   /* first kernel of an ADAM_ROWS_* call */
+  BR_TAG_INDEX_SORT = 22      /* first kernel of an INDEX_* call (chunk sort); the rank / merge kernel keeps INDEX_* */
 };
 int brProbeEnable(int capacity);
 int brProbeCount(void);

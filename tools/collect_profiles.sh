@@ -3,11 +3,11 @@
 # cannot share a pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots") of the default bench workload.
 # Outputs land in $GRAFT_REPO_ROOT/gpurun_out/prof_<tag>/ ; tools/summarize_profile.py turns them into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-lazy"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-lazy --no-legs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err && echo "trace ok" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err && echo "fetch ok" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err && echo "write ok" &&
