@@ -1,269 +1,353 @@
 // L4: in-batch softmax of the TwoTower retrieval task (tfrs.tasks.Retrieval, twoTower.py:47,82-83)
-// and E1 full-catalogue scoring — the only MFMA-bound pieces of the path (2*B^2*semb flop).
+// and E1 full-catalogue scoring - the only MFMA-bound pieces of the path (2*B^2*semb flop per GEMM).
 //
-//   S = Q C^T (Bq x Bc) is NEVER materialised for the loss: 64 x 64 tiles of S are formed on fp32
-//   MFMA (v_mfma_f32_16x16x4_f32) from LDS-staged Q / C tiles and consumed in registers.
-//   MODE_SCORES : write S (candidate scoring for top-k: topKmetrics.py:17-43, twoTower.py:64-69)
-//   MODE_LSE    : streaming logsumexp per query row (online max / sum), accidental-hit mask,
-//                 loss_sum += sum_i (lse_i - S_i,diag)
-//   MODE_GRAD_R : rows = queries      : dQ_i  = sum_j (exp(S_ij - lse_i) - [j = diag(i)]) C_j
-//   MODE_GRAD_C : rows = candidates   : dC_j  = sum_i (exp(S_ij - lse_i) - [j = diag(i)]) Q_i
+//   S = Q C^T (Bq x Bc) is NEVER materialised for the loss.  One kernel, four modes; in each the workgroup OWNS 128 rows of one
+//   operand (32 per wave, kept in registers as the stationary MFMA operand for the whole sweep) and STREAMS 64-row tiles of the
+//   other operand through LDS:
+//     MODE_LSE    owned = queries     streamed = candidates   online logsumexp per query, loss_sum += sum_i (lse_i - S_i,diag)
+//     MODE_GRAD_R owned = queries     streamed = candidates   dQ_i = sum_j (exp(S_ij - lse_i) - [j = diag(i)]) C_j
+//     MODE_GRAD_C owned = candidates  streamed = queries      dC_j = sum_i (exp(S_ij - lse_i) - [j = diag(i)]) Q_i
+//     MODE_SCORES owned = candidates  streamed = queries      scores[q][c] (top-k scoring: topKmetrics.py:17-43, twoTower.py:64-69)
+//   MFMA: v_mfma_f32_32x32x2_f32.  The score tile is formed TRANSPOSED, D[m = streamed entity][n = owned row]: in the result
+//   layout a lane then holds ONE owned row (n = lane % 32) and its 16 registers hold 16 streamed entities
+//   (m = 8 (r / 4) + 4 (lane / 32) + r % 4), so
+//     * everything that is per owned row (its lse, its id, the running max / sum, the diagonal column) is one register per lane,
+//       and the softmax reductions run over a lane's own registers - no cross-lane traffic until the very end;
+//     * P = exp(S - lse) - [diag] feeds the second GEMM straight from those registers as the B operand
+//       (k = streamed entity = register index, n = owned row): out^T[f][owned] += sum_k T[k][f] P[k][owned]; the A operand
+//       T[k][f] comes from a transposed copy of the streamed tile in LDS (one ds_read_b128 = 4 consecutive k).  P never goes
+//       through LDS (the previous kernel wrote it out and read it back in the A layout).
+//   Contraction order of the score product: k = KH * (lane / 32) + kk (each lane half walks its own half of the feature
+//   axis), so both operands are read as whole 16-byte vectors.  Two 32-entity sub-tiles are interleaved so that consecutive
+//   MFMAs never depend on each other.
+//   Occupancy: 128 owned rows per workgroup would leave most of the chip idle at the batch sizes of the reference (8 192 rows =
+//   64 workgroups), so the streamed axis is SPLIT over blockIdx.y: each split writes partial results (per-row (max, sum, diag) or
+//   a dQ / dC slab) into the caller's workspace and a small second kernel combines them in a fixed order (deterministic; no
+//   float atomics).  Without a workspace the split count is 1 and results are written directly.
 // [TF-sem] accidental hits: S_ij += FLT_MIN_TFRS (= float32 min / 100) when cand_ids[j] equals the
 // id of query i's own positive and j is not that positive's column; SUM reduction over rows.
 #include "common.h"
 
 namespace br {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-__device__ __forceinline__ f32x4 mfma16s(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 enum { MODE_SCORES = 0, MODE_LSE = 1, MODE_GRAD_R = 2, MODE_GRAD_C = 3 };
 
-// exp of a non-positive argument (score - running max, score - lse) on the hardware exp2: 16 evaluations per lane and
-// 64-column tile made these kernels VALU-bound with the accurate expf (~30 instructions each).  |x| <= ~88; the relative
+// exp of a non-positive argument (score - running max, score - lse) on the hardware exp2: one evaluation per score made
+// these kernels VALU-bound with the accurate expf (~30 instructions each).  |x| <= ~88; the relative
 // error grows like |x| * 6e-8, i.e. it is largest on the terms that contribute least to the sums.
 __device__ __forceinline__ float exp_hw(float x) { return __expf(x); }
-constexpr int kT = 64;                       // tile edge (rows and columns of S per step)
+constexpr int kOwn = 128;                    // owned rows per workgroup (32 per wave)
+constexpr int kTs = 64;                      // streamed entities per step (two sub-tiles of 32)
+constexpr int kLdT = kTs + 4;                // row pitch of the transposed tile
 constexpr float kMinFloat = -3.4028234663852886e+36f;   // np.finfo(float32).min / 100
 
-// stage rows [r0, r0+64) of M (n_rows x dim, row-major) into LDS [64][ld], zero padded to Dp columns
-__device__ __forceinline__ void stage_rows(float* dst, int ld, const float* __restrict__ M, int64_t n_rows, int64_t r0, int dim, int Dp) {
-  const int cq = Dp >> 2;
-  for (int idx = threadIdx.x; idx < kT * cq; idx += blockDim.x) {
-    const int r = idx / cq, c = (idx - r * cq) << 2;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    const int64_t gr = r0 + r;
-    if (gr < n_rows) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (c + e < dim) v[e] = M[gr * dim + c + e];
-    }
-    *reinterpret_cast<float4*>(dst + r * ld + c) = make_float4(v[0], v[1], v[2], v[3]);
-  }
-}
+struct InbatchArgs {
+  const float* R; const float* T;            // owned / streamed operand (n_r x dim, n_t x dim, row-major)
+  int64_t n_r, n_t; int dim;
+  const void* own_ids; const void* str_ids;  // id of each owned / streamed entity (both or neither)
+  int64_t diag;                              // streamed index of owned row o's diagonal partner = o + diag
+  const float* lse_in;                       // GRAD_R: per owned row; GRAD_C: per streamed row
+  float* out; int64_t ldo;                   // GRAD: [split][n_r][ldo] (split 0 only when n_split == 1); SCORES: scores[streamed][owned]
+  float* part;                               // LSE with splits: [3][n_split][n_r] (max, sum, diag score)
+  float* lse_out; double* loss_sum;          // LSE without splits
+  int64_t t_per_split;                       // streamed rows per blockIdx.y (multiple of kTs)
+};
 
-// One workgroup (256 threads = 4 waves) owns 64 rows of R and sweeps all column tiles of Cm.
-// wave w: rows 16w..16w+15 of the tile; S accumulators: 4 column tiles x f32x4.
-// Accumulator layout: lane (c16, g) holds S[row = 16w + 4g + r][col = ct*16 + c16], r = 0..3.
-template <int MODE, typename IdT>
-__global__ __launch_bounds__(256) void inbatch_kernel(const float* __restrict__ R, const float* __restrict__ Cm, int64_t n_r, int64_t n_c, int dim,
-                                                       const IdT* __restrict__ q_pos_ids, const IdT* __restrict__ cand_ids,
-                                                       int64_t diag_offset, const float* __restrict__ lse_in, float* __restrict__ out,
-                                                       int64_t ldo, float* __restrict__ lse_out, double* __restrict__ loss_sum) {
+// KQ = 16-byte vectors per lane half of the feature axis: features are padded to Kp = 8 KQ
+template <int MODE, int KQ, typename IdT>
+__global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
+  constexpr int KH = 4 * KQ, Kp = 8 * KQ, ldt = Kp + 4;
+  constexpr int FT = (Kp + 31) / 32;                     // 32-feature tiles of the second GEMM
+  constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C;
+  constexpr int NPRE = (2 * KQ + 3) / 4;                 // 16-byte vectors each thread stages per step
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int Dp = (dim + 15) & ~15, ld = Dp + 4, DT = Dp >> 4;
-  float* Rs = smem;                 // [64][ld]
-  float* Cs = Rs + kT * ld;         // [64][ld]
-  float* Ps = Cs + kT * ld;         // [64][68]  P tile (grad modes)
-  float* CsT = Ps + kT * 68;        // [Dp][68]  the column tile transposed (grad modes: B operand of P·C as ds_read_b128)
-  float* aux = CsT + ((MODE == MODE_GRAD_R || MODE == MODE_GRAD_C) ? Dp * 68 : 0);   // [64] per-column lse (GRAD_C)
-  int64_t* cid = reinterpret_cast<int64_t*>(aux + kT);   // [64] ids of the column entities
-  constexpr int ldp = 68;
+  float* Ts = smem;                                      // [64][ldt]     streamed tile, row-major (A operand of the score product)
+  float* TsT = Ts + kTs * ldt;                           // [FT*32][68]   transposed (A operand of the second GEMM), GRAD only
+  float* tlse = TsT + (GRAD ? FT * 32 * kLdT : 0);       // [64]          GRAD_C: lse of the streamed queries
+  IdT* tid = reinterpret_cast<IdT*>(tlse + kTs);         // [64]          ids of the streamed entities
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c16 = lane & 15, g = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * kT;
-  stage_rows(Rs, ld, R, n_r, r0, dim, Dp);
+  const int l32 = lane & 31, hb = lane >> 5;
+  const int dim = a.dim;
+  const int64_t own = (int64_t)blockIdx.x * kOwn + wave * 32 + l32;       // this lane's owned row
+  const bool own_ok = own < a.n_r;
+  const bool has_ids = a.own_ids != nullptr;
+  const int64_t t_begin = (int64_t)blockIdx.y * a.t_per_split;
+  const int64_t t_end = t_begin + a.t_per_split < a.n_t ? t_begin + a.t_per_split : a.n_t;
 
-  // per-lane row constants (rows 16w+4g+r)
-  int64_t row_id[4];      // GRAD_C: candidate id of the row; else: id of the query's positive
-  float row_lse[4], run_m[4], run_l[4], diag_s[4];
-  bool has_ids = cand_ids != nullptr;
+  // stationary operand: R[own][KH * hb + kk]
+  float rf[KH];
+  {
+    const float* rp = a.R + (own_ok ? own : 0) * dim;
+    const bool v4 = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(a.R) & 15) == 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t gr = r0 + wave * 16 + 4 * g + r;
-    row_id[r] = -1; row_lse[r] = 0.f; run_m[r] = -INFINITY; run_l[r] = 0.f; diag_s[r] = 0.f;
-    if (gr < n_r) {
-      if (has_ids) row_id[r] = (MODE == MODE_GRAD_C) ? (int64_t)cand_ids[gr] : (int64_t)q_pos_ids[gr];
-      if (MODE == MODE_GRAD_R) row_lse[r] = lse_in[gr];
+    for (int q = 0; q < KQ; ++q) {
+      const int k = KH * hb + 4 * q;
+      if (v4) {
+        const float4 t = (own_ok && k < dim) ? *reinterpret_cast<const float4*>(rp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rf[4 * q] = t.x; rf[4 * q + 1] = t.y; rf[4 * q + 2] = t.z; rf[4 * q + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rf[4 * q + e] = (own_ok && k + e < dim) ? rp[k + e] : 0.f;
+      }
     }
   }
-  f32x4 gacc[8];          // grad modes: out[16 rows][Dp] as DT column tiles
+  IdT own_id = (IdT)-1;
+  float own_lse = 0.f;
+  if (own_ok) {
+    if (has_ids) own_id = reinterpret_cast<const IdT*>(a.own_ids)[own];
+    if (MODE == MODE_GRAD_R) own_lse = a.lse_in[own];
+  }
+  float run_m = -INFINITY, run_l = 0.f, diag_s = 0.f;    // LSE
+  f32x16 gacc[GRAD ? FT : 1];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) gacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < (GRAD ? FT : 1); ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
+  if (GRAD) {     // feature rows of the transposed tile that no step writes (Kp <= f < 32 FT) stay zero
+    for (int idx = threadIdx.x; idx < (FT * 32 - Kp) * kLdT; idx += 256) TsT[Kp * kLdT + idx] = 0.f;
+  }
 
-  // The column tile of step c0 + 64 is requested into registers BEFORE the MFMA work of step c0 and written to LDS after
-  // it (the staging used to sit between two barriers with its global latency exposed on every one of the n_c / 64 steps).
-  constexpr int MAXQ = kT * (128 / 4) / 256;        // float4 per thread at dim 128
-  const int cq = Dp >> 2, n_q4 = kT * cq;
-  const bool cvec = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cm) & 15) == 0);
-  float4 pre[MAXQ];
-  auto fetch_tile = [&](int64_t c0n) {
+  // staging: thread -> (streamed row sr = tid % 64, 16-byte feature chunks c4 = tid / 64 + 4 q): the transposed stores of a
+  // wave hit 64 consecutive floats, the row-major ones 64 rows at a pitch of ldt floats (ldt % 64 in {36, 44, 60, 4}: conflict free)
+  const int sr = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const bool tvec = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(a.T) & 15) == 0;
+  float4 pre[NPRE];
+  IdT pre_id = (IdT)-2;
+  float pre_lse = 0.f;
+  auto fetch = [&](int64_t c0) {
+    const int64_t gr = c0 + sr;
+    const bool rin = gr < t_end;
+    const float* tp = a.T + (rin ? gr : 0) * dim;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int idx = threadIdx.x + 256 * q;
-      const int idc = idx < n_q4 ? idx : 0;
-      const int r = idc / cq, c = (idc - r * cq) << 2;
-      const int64_t gr = c0n + r;
-      const int64_t grc = gr < n_c ? gr : n_c - 1;
-      float4 v;
-      if (cvec) {
-        const float4 t = *reinterpret_cast<const float4*>(Cm + grc * dim + (c < dim ? c : 0));
-        const bool ok = gr < n_c && c < dim;
-        v = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
-      } else {
-        const float* pr_ = Cm + grc * dim;
-        const float t0 = pr_[c + 0 < dim ? c + 0 : dim - 1], t1 = pr_[c + 1 < dim ? c + 1 : dim - 1];
-        const float t2 = pr_[c + 2 < dim ? c + 2 : dim - 1], t3 = pr_[c + 3 < dim ? c + 3 : dim - 1];
-        const bool rin = gr < n_c;
-        v = make_float4((rin && c + 0 < dim) ? t0 : 0.f, (rin && c + 1 < dim) ? t1 : 0.f, (rin && c + 2 < dim) ? t2 : 0.f, (rin && c + 3 < dim) ? t3 : 0.f);
+    for (int q = 0; q < NPRE; ++q) {
+      const int c = 4 * (cg + 4 * q);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tvec) {
+        if (rin && c < dim) v = *reinterpret_cast<const float4*>(tp + c);
+      } else if (rin) {
+        v.x = c + 0 < dim ? tp[c + 0] : 0.f; v.y = c + 1 < dim ? tp[c + 1] : 0.f;
+        v.z = c + 2 < dim ? tp[c + 2] : 0.f; v.w = c + 3 < dim ? tp[c + 3] : 0.f;
       }
       pre[q] = v;
     }
+    if (cg == 0) {
+      pre_id = (rin && has_ids) ? reinterpret_cast<const IdT*>(a.str_ids)[gr] : (IdT)-2;
+      if (MODE == MODE_GRAD_C) pre_lse = rin ? a.lse_in[gr] : 0.f;
+    }
   };
-  fetch_tile(0);
-  for (int64_t c0 = 0; c0 < n_c; c0 += kT) {
-    __syncthreads();                                 // the previous step's readers of Cs / CsT / cid are done
+  if (t_begin < t_end) fetch(t_begin);
+
+  // diagonal: streamed index of this lane's partner, as an offset into the current tile (compared against the tile-local index)
+  const int64_t partner = own + a.diag;
+  const int jb = 4 * hb;                                  // lane-half part of the tile-local streamed index
+  for (int64_t c0 = t_begin; c0 < t_end; c0 += kTs) {
+    __syncthreads();                                      // the previous step's readers of the tile are done
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int idx = threadIdx.x + 256 * q;
-      if (idx < n_q4) {
-        const int r = idx / cq, c = (idx - r * cq) << 2;
-        *reinterpret_cast<float4*>(Cs + r * ld + c) = pre[q];
-        if (MODE == MODE_GRAD_R || MODE == MODE_GRAD_C) {
-          CsT[(c + 0) * 68 + r] = pre[q].x; CsT[(c + 1) * 68 + r] = pre[q].y;
-          CsT[(c + 2) * 68 + r] = pre[q].z; CsT[(c + 3) * 68 + r] = pre[q].w;
+    for (int q = 0; q < NPRE; ++q) {
+      const int c = 4 * (cg + 4 * q);
+      if (c < Kp) {
+        *reinterpret_cast<float4*>(Ts + sr * ldt + c) = pre[q];
+        if (GRAD) {
+          TsT[(c + 0) * kLdT + sr] = pre[q].x; TsT[(c + 1) * kLdT + sr] = pre[q].y;
+          TsT[(c + 2) * kLdT + sr] = pre[q].z; TsT[(c + 3) * kLdT + sr] = pre[q].w;
         }
       }
     }
-    if (threadIdx.x < kT) {
-      const int64_t gc = c0 + threadIdx.x;
-      int64_t v = -2;
-      if (gc < n_c && has_ids) v = (MODE == MODE_GRAD_C) ? (int64_t)q_pos_ids[gc] : (int64_t)cand_ids[gc];
-      cid[threadIdx.x] = v;
-      if (MODE == MODE_GRAD_C) aux[threadIdx.x] = gc < n_c ? lse_in[gc] : 0.f;
+    if (cg == 0) {
+      tid[sr] = pre_id;
+      if (MODE == MODE_GRAD_C) tlse[sr] = pre_lse;
     }
     __syncthreads();
-    if (c0 + kT < n_c) fetch_tile(c0 + kT);          // in flight during this step's MFMA work
-    // ---- S tile: rows of this wave x 64 columns ----
-    f32x4 s[4];
+    if (c0 + kTs < t_end) fetch(c0 + kTs);                // in flight during this step's MFMA work
+
+    // ---- score tiles: D[m = streamed][n = owned], two sub-tiles interleaved ----
+    f32x16 s0, s1;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) s[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* ar = Rs + (wave * 16 + c16) * ld + 4 * g;
-    for (int j = 0; j < DT; ++j) {
-      const float4 a4 = *reinterpret_cast<const float4*>(ar + 16 * j);
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    const float* ap = Ts + l32 * ldt + KH * hb;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const float4 b4 = *reinterpret_cast<const float4*>(Cs + (ct * 16 + c16) * ld + 16 * j + 4 * g);
-        s[ct] = mfma16s(a4.x, b4.x, s[ct]);
-        s[ct] = mfma16s(a4.y, b4.y, s[ct]);
-        s[ct] = mfma16s(a4.z, b4.z, s[ct]);
-        s[ct] = mfma16s(a4.w, b4.w, s[ct]);
-      }
+    for (int q = 0; q < KQ; ++q) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ap + 4 * q);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * ldt + 4 * q);
+      s0 = mfma32(a0.x, rf[4 * q + 0], s0); s1 = mfma32(a1.x, rf[4 * q + 0], s1);
+      s0 = mfma32(a0.y, rf[4 * q + 1], s0); s1 = mfma32(a1.y, rf[4 * q + 1], s1);
+      s0 = mfma32(a0.z, rf[4 * q + 2], s0); s1 = mfma32(a1.z, rf[4 * q + 2], s1);
+      s0 = mfma32(a0.w, rf[4 * q + 3], s0); s1 = mfma32(a1.w, rf[4 * q + 3], s1);
     }
     if (MODE == MODE_SCORES) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gr = r0 + wave * 16 + 4 * g + r, gc = c0 + ct * 16 + c16;
-          if (gr < n_r && gc < n_c) out[gr * ldo + gc] = s[ct][r];
+        for (int r = 0; r < 16; ++r) {
+          const int64_t gs = c0 + 32 * sub + 8 * (r >> 2) + jb + (r & 3);
+          if (gs < t_end && own_ok) a.out[gs * a.ldo + own] = sub ? s1[r] : s0[r];
         }
       continue;
     }
-    // ---- accidental-hit mask, validity, diagonal ----
-    float p[4][4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const int cl = ct * 16 + c16;
-      const int64_t gc = c0 + cl;
-      const int64_t col_id = cid[cl];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gr = r0 + wave * 16 + 4 * g + r;
-        // diagonal: query index q and its positive's column: col == q + diag_offset
-        const bool is_diag = (MODE == MODE_GRAD_C) ? (gr == gc + diag_offset) : (gc == gr + diag_offset);
-        float v = s[ct][r];
-        if (has_ids && !is_diag && col_id == row_id[r]) v += kMinFloat;
-        const bool valid = gc < n_c && gr < n_r;
-        if (MODE == MODE_LSE) {
-          if (is_diag && valid) diag_s[r] = v;
-          p[ct][r] = valid ? v : -INFINITY;
-        } else {
-          const float l = (MODE == MODE_GRAD_R) ? row_lse[r] : aux[cl];
-          p[ct][r] = valid ? (exp_hw(v - l) - (is_diag ? 1.f : 0.f)) : 0.f;
-        }
-      }
-    }
+    const int dd = (int)((partner - c0 < -1) ? -1 : (partner - c0 > 4096 ? 4096 : partner - c0)) - jb;   // tile-local diag index minus jb
     if (MODE == MODE_LSE) {
-      // online logsumexp over the 64 columns: 4 register tiles, then the 16 lanes that share a row
+      const int lim = (int)(t_end - c0) - jb;             // tile-local validity bound (only the last tile is partial)
+      float v[32];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float m = fmaxf(fmaxf(p[0][r], p[1][r]), fmaxf(p[2][r], p[3][r]));
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        const float nm = fmaxf(run_m[r], m);
-        float sum = 0.f;
-        if (nm > -INFINITY) {
+        for (int rq = 0; rq < 4; ++rq) {
+          IdT ids4[4];
+          if (has_ids) {
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) sum += exp_hw(p[ct][r] - nm);
+            for (int e = 0; e < 4; ++e) ids4[e] = tid[32 * sub + 8 * rq + jb + e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cj = 32 * sub + 8 * rq + e;         // tile-local streamed index minus jb
+            float x = sub ? s1[4 * rq + e] : s0[4 * rq + e];
+            const bool dg = cj == dd;
+            if (has_ids) x += (!dg && ids4[e] == own_id) ? kMinFloat : 0.f;
+            diag_s = dg ? x : diag_s;
+            v[16 * sub + 4 * rq + e] = cj < lim ? x : -INFINITY;
+          }
         }
+      float m = v[0];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        run_l[r] = (nm > -INFINITY ? run_l[r] * exp_hw(run_m[r] - nm) : 0.f) + sum;
-        run_m[r] = nm;
-      }
+      for (int i = 1; i < 32; ++i) m = fmaxf(m, v[i]);
+      const float nm = fmaxf(run_m, m);                   // > -inf: every tile has at least one valid entity
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) sum += exp_hw(v[i] - nm);
+      run_l = run_l * exp_hw(run_m - nm) + sum;
+      run_m = nm;
       continue;
     }
-    // ---- grad modes: out[rows] += P (16 x 64) · Cs (64 x Dp) ----
+    // ---- GRAD: P in registers -> B operand of out^T[f][owned] += sum_k T[k][f] P[k][owned] ----
+    // (streamed rows past the end and owned rows past the end need no mask: their T rows are zero / their results are not stored)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ps[(wave * 16 + 4 * g + r) * ldp + ct * 16 + c16] = p[ct][r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave reads back only its own 16 rows of Ps
-    __builtin_amdgcn_wave_barrier();
-    const float* pr = Ps + (wave * 16 + c16) * ldp + 4 * g;
+      for (int rq = 0; rq < 4; ++rq) {
+        const int j0 = 32 * sub + 8 * rq + jb;
+        IdT ids4[4];
+        float l4[4];
+        if (has_ids) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {          // contraction over the 64 columns of the tile
-      const float4 a4 = *reinterpret_cast<const float4*>(pr + 16 * j);
-      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-      // B operand: 4 consecutive column entities (k = 16j + 4g + e) of feature t*16 + c16 = one ds_read_b128 of the
-      // transposed tile (was one ds_read_b32 per MFMA)
+          for (int e = 0; e < 4; ++e) ids4[e] = tid[j0 + e];
+        }
+        if (MODE == MODE_GRAD_C) {
+          const float4 t = *reinterpret_cast<const float4*>(tlse + j0);
+          l4[0] = t.x; l4[1] = t.y; l4[2] = t.z; l4[3] = t.w;
+        }
+        float p[4];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        if (t < DT) {
-          const float4 b4 = *reinterpret_cast<const float4*>(CsT + (t * 16 + c16) * 68 + 16 * j + 4 * g);
-          gacc[t] = mfma16s(a[0], b4.x, gacc[t]);
-          gacc[t] = mfma16s(a[1], b4.y, gacc[t]);
-          gacc[t] = mfma16s(a[2], b4.z, gacc[t]);
-          gacc[t] = mfma16s(a[3], b4.w, gacc[t]);
+        for (int e = 0; e < 4; ++e) {
+          const int cj = 32 * sub + 8 * rq + e;
+          float x = sub ? s1[4 * rq + e] : s0[4 * rq + e];
+          const bool dg = cj == dd;
+          if (has_ids) x += (!dg && ids4[e] == own_id) ? kMinFloat : 0.f;
+          p[e] = exp_hw(x - (MODE == MODE_GRAD_R ? own_lse : l4[e])) - (dg ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < FT; ++t) {
+          const float4 a4 = *reinterpret_cast<const float4*>(TsT + (32 * t + l32) * kLdT + j0);
+          gacc[t] = mfma32(a4.x, p[0], gacc[t]);
+          gacc[t] = mfma32(a4.y, p[1], gacc[t]);
+          gacc[t] = mfma32(a4.z, p[2], gacc[t]);
+          gacc[t] = mfma32(a4.w, p[3], gacc[t]);
         }
       }
     }
   }
 
   if (MODE == MODE_LSE) {
-    // every lane of a 16-lane row group holds the same (m, l); the diagonal score sits in ONE of them
+    // lanes l and l + 32 hold disjoint streamed entities of the same owned row
+    const float om = __shfl_xor(run_m, 32, 64), ol = __shfl_xor(run_l, 32, 64), od = __shfl_xor(diag_s, 32, 64);
+    const float nm = fmaxf(run_m, om);
+    const float l = (run_m > -INFINITY ? run_l * exp_hw(run_m - nm) : 0.f) + (om > -INFINITY ? ol * exp_hw(om - nm) : 0.f);
+    const float d = diag_s + od;                          // exactly one lane-step saw the diagonal (others hold 0)
     double part = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float d = diag_s[r];
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-      const int64_t gr = r0 + wave * 16 + 4 * g + r;
-      if (c16 == 0 && gr < n_r) {
-        const float l = run_m[r] + logf(run_l[r]);
-        lse_out[gr] = l;
-        part += (double)l - (double)d;
+    if (hb == 0 && own_ok) {
+      if (a.part) {
+        const int64_t ns = gridDim.y;
+        a.part[(0 * ns + blockIdx.y) * a.n_r + own] = nm;
+        a.part[(1 * ns + blockIdx.y) * a.n_r + own] = l;
+        a.part[(2 * ns + blockIdx.y) * a.n_r + own] = d;
+      } else {
+        const float lse = nm + logf(l);
+        a.lse_out[own] = lse;
+        part = (double)lse - (double)d;
       }
     }
-    part = wave_sum_d(part);
-    __shared__ double red[4];
-    if (lane == 0) red[wave] = part;
-    __syncthreads();
-    if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum + (blockIdx.x & (BR_SUM_SLOTS - 1)), red[0] + red[1] + red[2] + red[3]);
+    if (!a.part) {
+      part = wave_sum_d(part);
+      __shared__ double red[4];
+      if (lane == 0) red[wave] = part;
+      __syncthreads();
+      if (threadIdx.x == 0 && a.loss_sum) atomicAdd(a.loss_sum + (blockIdx.x & (BR_SUM_SLOTS - 1)), red[0] + red[1] + red[2] + red[3]);
+    }
     return;
   }
-  if (MODE == MODE_GRAD_R || MODE == MODE_GRAD_C) {
+  if (GRAD) {
+    // gacc[t][r] = out[own][32 t + 8 (r / 4) + 4 hb + r % 4]: four consecutive features per register group
+    float* op = a.out + ((int64_t)blockIdx.y * a.n_r + (own_ok ? own : 0)) * a.ldo;
+    const bool v4 = (a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t < DT) {
-        const int col = t * 16 + c16;
+    for (int t = 0; t < FT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gr = r0 + wave * 16 + 4 * g + r;
-          if (gr < n_r && col < dim) out[gr * ldo + col] = gacc[t][r];
+      for (int rq = 0; rq < 4; ++rq) {
+        const int f = 32 * t + 8 * rq + jb;
+        if (!own_ok || f >= dim) continue;
+        if (v4 && f + 3 < dim) {
+          *reinterpret_cast<float4*>(op + f) = make_float4(gacc[t][4 * rq], gacc[t][4 * rq + 1], gacc[t][4 * rq + 2], gacc[t][4 * rq + 3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (f + e < dim) op[f + e] = gacc[t][4 * rq + e];
         }
       }
+  }
+}
+
+// combine the per-split (max, sum, diag) of every query: lse, loss_sum += sum_i (lse_i - diag_i)
+__global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restrict__ part, int n_split, int64_t n_r, float* __restrict__ lse_out,
+                                                           double* __restrict__ loss_sum) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double mine = 0.0;
+  if (i < n_r) {
+    float m = -INFINITY, d = 0.f;
+    for (int s = 0; s < n_split; ++s) m = fmaxf(m, part[(0 * (int64_t)n_split + s) * n_r + i]);
+    float l = 0.f;
+    for (int s = 0; s < n_split; ++s) {
+      const float ms = part[(0 * (int64_t)n_split + s) * n_r + i];
+      if (ms > -INFINITY) l += part[(1 * (int64_t)n_split + s) * n_r + i] * exp_hw(ms - m);
+      d += part[(2 * (int64_t)n_split + s) * n_r + i];
+    }
+    const float lse = m + logf(l);
+    lse_out[i] = lse;
+    mine = (double)lse - (double)d;
+  }
+  mine = wave_sum_d(mine);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum + (blockIdx.x & (BR_SUM_SLOTS - 1)), red[0] + red[1] + red[2] + red[3]);
+}
+
+// out[i] = sum_s slabs[s][i] in split order (n = rows * ld floats, n % 4 == 0 or scalar tail)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int n_split, int64_t n, float* __restrict__ out) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && (n & 3) == 0) {
+    float4 acc = *reinterpret_cast<const float4*>(slabs + i4);
+    for (int s = 1; s < n_split; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)s * n + i4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i4) = acc;
+  } else {
+    for (int64_t i = i4; i < n && i < i4 + 4; ++i) {
+      float acc = slabs[i];
+      for (int s = 1; s < n_split; ++s) acc += slabs[(int64_t)s * n + i];
+      out[i] = acc;
     }
   }
 }
@@ -312,59 +396,123 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 
 using namespace br;
 
-template <int MODE>
-static int launch_inbatch(const float* R, const float* Cm, int64_t n_r, int64_t n_c, int dim, const void* q_pos_ids, const void* cand_ids,
-                          int id_type, int64_t diag_offset, const float* lse_in, float* out, int64_t ldo, float* lse_out, double* loss_sum,
-                          hipStream_t s) {
-  const int Dp = (dim + 15) & ~15;
-  const bool grad = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C;
-  const size_t shmem = ((size_t)2 * kT * (Dp + 4) + (size_t)kT * 68 + (grad ? (size_t)Dp * 68 : 0) + kT) * sizeof(float) + kT * sizeof(int64_t) + 16;
+namespace {
+constexpr int kTargetWgs = 512;      // two workgroups per CU
+
+// splits of the streamed axis so that row_blocks * splits ~ kTargetWgs (each split: a whole number of 64-row steps)
+int choose_splits(int64_t n_r, int64_t n_t, int64_t max_splits) {
+  const int64_t rb = ceil_div(n_r, (int64_t)kOwn), steps = ceil_div(n_t, (int64_t)kTs);
+  int64_t s = ceil_div((int64_t)kTargetWgs, rb);
+  if (s > steps) s = steps;
+  if (s > max_splits) s = max_splits;
+  if (s > 64) s = 64;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <int MODE, int KQ, typename IdT>
+void launch_inbatch_k(const InbatchArgs& a, int n_split, hipStream_t s) {
+  constexpr int Kp = 8 * KQ, FT = (Kp + 31) / 32;
+  constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C;
+  const size_t shmem = ((size_t)kTs * (Kp + 4) + (GRAD ? (size_t)FT * 32 * kLdT : 0) + kTs) * sizeof(float) + kTs * sizeof(IdT);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)inbatch_kernel<MODE, int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)inbatch_kernel<MODE, int64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)inbatch_kernel<MODE, KQ, IdT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
-  const unsigned grid = (unsigned)ceil_div(n_r, kT);
-  if (id_type == BR_IDS_I64)
-    inbatch_kernel<MODE, int64_t><<<grid, 256, shmem, s>>>(R, Cm, n_r, n_c, dim, (const int64_t*)q_pos_ids, (const int64_t*)cand_ids, diag_offset,
-                                                            lse_in, out, ldo, lse_out, loss_sum);
-  else
-    inbatch_kernel<MODE, int32_t><<<grid, 256, shmem, s>>>(R, Cm, n_r, n_c, dim, (const int32_t*)q_pos_ids, (const int32_t*)cand_ids, diag_offset,
-                                                            lse_in, out, ldo, lse_out, loss_sum);
-  return 0;
+  const dim3 grid((unsigned)ceil_div(a.n_r, (int64_t)kOwn), (unsigned)n_split);
+  inbatch_kernel<MODE, KQ, IdT><<<grid, 256, shmem, s>>>(a);
+}
+
+template <int MODE, typename IdT>
+void launch_inbatch_t(const InbatchArgs& a, int n_split, hipStream_t s) {
+  const int kq = (a.dim + 7) / 8;
+  if (kq <= 4) launch_inbatch_k<MODE, 4, IdT>(a, n_split, s);
+  else if (kq <= 7) launch_inbatch_k<MODE, 7, IdT>(a, n_split, s);
+  else if (kq <= 8) launch_inbatch_k<MODE, 8, IdT>(a, n_split, s);
+  else if (kq <= 13) launch_inbatch_k<MODE, 13, IdT>(a, n_split, s);
+  else launch_inbatch_k<MODE, 16, IdT>(a, n_split, s);
+}
+
+template <int MODE>
+void launch_inbatch(InbatchArgs a, int n_split, int id_type, hipStream_t s) {
+  const int64_t steps = ceil_div(a.n_t, (int64_t)kTs);
+  a.t_per_split = ceil_div(steps, (int64_t)n_split) * kTs;
+  n_split = (int)ceil_div(a.n_t, a.t_per_split);       // no empty split
+  if (id_type == BR_IDS_I64) launch_inbatch_t<MODE, int64_t>(a, n_split, s);
+  else launch_inbatch_t<MODE, int32_t>(a, n_split, s);
+}
+}  // namespace
+
+extern "C" int64_t brInBatchSoftmaxWorkspaceBytes(int64_t Bq, int64_t Bc, int dim) {
+  if (Bq <= 0 || Bc <= 0 || dim <= 0) return 0;
+  const int64_t lse = (int64_t)3 * choose_splits(Bq, Bc, 64) * Bq;
+  const int64_t gq = choose_splits(Bq, Bc, 64) > 1 ? (int64_t)choose_splits(Bq, Bc, 64) * Bq * dim : 0;
+  const int64_t gc = choose_splits(Bc, Bq, 64) > 1 ? (int64_t)choose_splits(Bc, Bq, 64) * Bc * dim : 0;
+  const int64_t fl = lse > gq ? (lse > gc ? lse : gc) : (gq > gc ? gq : gc);
+  return fl * (int64_t)sizeof(float);
 }
 
 extern "C" int brInBatchSoftmaxLse(const float* Q, const float* C, const void* q_pos_ids, const void* cand_ids, int id_type, int64_t Bq,
-                                   int64_t Bc, int dim, int64_t diag_offset, float* row_lse, double* loss_sum, brStream stream) {
+                                   int64_t Bc, int dim, int64_t diag_offset, float* row_lse, double* loss_sum, void* ws, int64_t ws_bytes,
+                                   brStream stream) {
   BR_CHECK_ARG(Q && C && row_lse && Bq >= 0 && Bc >= 1 && dim >= 1 && dim <= 128, "brInBatchSoftmaxLse: bad args (dim <= 128)");
   BR_CHECK_ARG((q_pos_ids == nullptr) == (cand_ids == nullptr), "brInBatchSoftmaxLse: ids both or neither");
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brInBatchSoftmaxLse: bad id_type");
+  BR_CHECK_ARG(ws_bytes >= 0 && (ws != nullptr || ws_bytes == 0), "brInBatchSoftmaxLse: bad workspace");
   if (Bq == 0) return BR_OK;
-  launch_inbatch<MODE_LSE>(Q, C, Bq, Bc, dim, q_pos_ids, cand_ids, id_type, diag_offset, nullptr, nullptr, 0, row_lse, loss_sum, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  const int n_split = choose_splits(Bq, Bc, ws ? ws_bytes / (int64_t)(3 * Bq * sizeof(float)) : 1);
+  InbatchArgs a{Q, C, Bq, Bc, dim, q_pos_ids, cand_ids, diag_offset, nullptr, nullptr, 0, n_split > 1 ? (float*)ws : nullptr, row_lse, loss_sum, 0};
+  launch_inbatch<MODE_LSE>(a, n_split, id_type, s);
   BR_CHECK_LAUNCH("brInBatchSoftmaxLse");
+  if (n_split > 1) {
+    const int64_t tps = ceil_div(ceil_div(Bc, (int64_t)kTs), (int64_t)n_split) * kTs;
+    lse_combine_kernel<<<(unsigned)ceil_div(Bq, (int64_t)256), 256, 0, s>>>((const float*)ws, (int)ceil_div(Bc, tps), Bq, row_lse, loss_sum);
+    BR_CHECK_LAUNCH("brInBatchSoftmaxLse(combine)");
+  }
+  return BR_OK;
+}
+
+// one gradient sweep: rows of `own` are owned, `str` is streamed; direct or through slabs in ws
+template <int MODE>
+static int grad_sweep(const float* own, const float* str, int64_t n_own, int64_t n_str, int dim, const void* own_ids, const void* str_ids, int id_type,
+                      int64_t diag, const float* lse, float* out, void* ws, int64_t ws_bytes, hipStream_t s) {
+  const int n_split = choose_splits(n_own, n_str, ws ? ws_bytes / (int64_t)(n_own * dim * sizeof(float)) : 1);
+  InbatchArgs a{own, str, n_own, n_str, dim, own_ids, str_ids, diag, lse, n_split > 1 ? (float*)ws : out, dim, nullptr, nullptr, nullptr, 0};
+  launch_inbatch<MODE>(a, n_split, id_type, s);
+  BR_CHECK_LAUNCH("brInBatchSoftmaxGrad");
+  if (n_split > 1) {
+    const int64_t tps = ceil_div(ceil_div(n_str, (int64_t)kTs), (int64_t)n_split) * kTs;
+    const int64_t n = n_own * dim;
+    slab_sum_kernel<<<(unsigned)ceil_div(ceil_div(n, (int64_t)4), (int64_t)256), 256, 0, s>>>((const float*)ws, (int)ceil_div(n_str, tps), n, out);
+    BR_CHECK_LAUNCH("brInBatchSoftmaxGrad(slab sum)");
+  }
   return BR_OK;
 }
 
 extern "C" int brInBatchSoftmaxGrad(const float* Q, const float* C, const void* q_pos_ids, const void* cand_ids, int id_type, int64_t Bq,
-                                    int64_t Bc, int dim, int64_t diag_offset, const float* row_lse, float* dQ, float* dC, brStream stream) {
+                                    int64_t Bc, int dim, int64_t diag_offset, const float* row_lse, float* dQ, float* dC, void* ws,
+                                    int64_t ws_bytes, brStream stream) {
   BR_CHECK_ARG(Q && C && row_lse && Bq >= 0 && Bc >= 1 && dim >= 1 && dim <= 128, "brInBatchSoftmaxGrad: bad args (dim <= 128)");
   BR_CHECK_ARG(dQ || dC, "brInBatchSoftmaxGrad: nothing to compute");
   BR_CHECK_ARG((q_pos_ids == nullptr) == (cand_ids == nullptr), "brInBatchSoftmaxGrad: ids both or neither");
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brInBatchSoftmaxGrad: bad id_type");
+  BR_CHECK_ARG(ws_bytes >= 0 && (ws != nullptr || ws_bytes == 0), "brInBatchSoftmaxGrad: bad workspace");
   if (Bq == 0) return BR_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (dQ) launch_inbatch<MODE_GRAD_R>(Q, C, Bq, Bc, dim, q_pos_ids, cand_ids, id_type, diag_offset, row_lse, dQ, dim, nullptr, nullptr, s);
-  // dC: rows = candidates, columns = queries (the kernel swaps the roles of the id arrays itself)
-  if (dC) launch_inbatch<MODE_GRAD_C>(C, Q, Bc, Bq, dim, q_pos_ids, cand_ids, id_type, diag_offset, row_lse, dC, dim, nullptr, nullptr, s);
-  BR_CHECK_LAUNCH("brInBatchSoftmaxGrad");
+  // dQ: queries own, candidates stream; the partner of query i is candidate i + diag_offset
+  if (dQ) { const int rc = grad_sweep<MODE_GRAD_R>(Q, C, Bq, Bc, dim, q_pos_ids, cand_ids, id_type, diag_offset, row_lse, dQ, ws, ws_bytes, s); if (rc) return rc; }
+  // dC: candidates own, queries stream; the partner of candidate j is query j - diag_offset (the slabs of dQ are consumed by then)
+  if (dC) { const int rc = grad_sweep<MODE_GRAD_C>(C, Q, Bc, Bq, dim, cand_ids, q_pos_ids, id_type, -diag_offset, row_lse, dC, ws, ws_bytes, s); if (rc) return rc; }
   return BR_OK;
 }
 
 extern "C" int brScoreMatrix(const float* Q, const float* C, int64_t n_q, int64_t n_c, int dim, float* scores, int64_t ld_scores, brStream stream) {
   BR_CHECK_ARG(Q && C && scores && n_q >= 0 && n_c >= 1 && dim >= 1 && dim <= 128 && ld_scores >= n_c, "brScoreMatrix: bad args (dim <= 128)");
   if (n_q == 0) return BR_OK;
-  launch_inbatch<MODE_SCORES>(Q, C, n_q, n_c, dim, nullptr, nullptr, BR_IDS_I32, 0, nullptr, scores, ld_scores, nullptr, nullptr, (hipStream_t)stream);
+  // candidates own (lanes = consecutive candidates = coalesced score rows), queries stream; the splits write disjoint rows
+  InbatchArgs a{C, Q, n_c, n_q, dim, nullptr, nullptr, 0, nullptr, scores, ld_scores, nullptr, nullptr, nullptr, 0};
+  launch_inbatch<MODE_SCORES>(a, choose_splits(n_c, n_q, 64), BR_IDS_I32, (hipStream_t)stream);
   BR_CHECK_LAUNCH("brScoreMatrix");
   return BR_OK;
 }

@@ -369,19 +369,36 @@ SUM_SLOTS = 64   # BR_SUM_SLOTS
 METRIC_SUMS = 8  # BR_METRIC_SUMS: [loss, se, ae, correct, bce, tp, fp, fn]
 
 
+_softmax_ws = {}
+
+
+def _softmax_workspace(Q, C):
+    """scratch of the split in-batch softmax sweeps, one grow-only buffer per (device, stream)."""
+    need = int(_lib.load().brInBatchSoftmaxWorkspaceBytes(Q.shape[0], C.shape[0], Q.shape[1]))
+    key = (Q.device, _stream())
+    buf = _softmax_ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 16), dtype=torch.uint8, device=Q.device)
+        _softmax_ws[key] = buf
+    return buf
+
+
 def inbatch_softmax_lse(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, loss_sum):
     qi, qt = _ids(q_pos_ids, "q_pos_ids"); ci, ct = _ids(cand_ids, "cand_ids")
     id_type = _same_id_type(qt, ct) if qi is not None else I32
+    ws = _softmax_workspace(Q, C)
     check(_lib.load().brInBatchSoftmaxLse(_f32(Q, "Q").data_ptr(), _f32(C, "C").data_ptr(), _p(qi), _p(ci), id_type, Q.shape[0], C.shape[0],
-                                          Q.shape[1], int(diag_offset), _f32(row_lse, "row_lse").data_ptr(), loss_sum.data_ptr(), _stream()),
-          "brInBatchSoftmaxLse")
+                                          Q.shape[1], int(diag_offset), _f32(row_lse, "row_lse").data_ptr(), loss_sum.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _stream()), "brInBatchSoftmaxLse")
 
 
 def inbatch_softmax_grad(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, dQ=None, dC=None):
     qi, qt = _ids(q_pos_ids, "q_pos_ids"); ci, ct = _ids(cand_ids, "cand_ids")
     id_type = _same_id_type(qt, ct) if qi is not None else I32
+    ws = _softmax_workspace(Q, C)
     check(_lib.load().brInBatchSoftmaxGrad(_f32(Q, "Q").data_ptr(), _f32(C, "C").data_ptr(), _p(qi), _p(ci), id_type, Q.shape[0], C.shape[0],
-                                           Q.shape[1], int(diag_offset), row_lse.data_ptr(), _p(dQ), _p(dC), _stream()), "brInBatchSoftmaxGrad")
+                                           Q.shape[1], int(diag_offset), row_lse.data_ptr(), _p(dQ), _p(dC), ws.data_ptr(), ws.numel(), _stream()),
+          "brInBatchSoftmaxGrad")
 
 
 def score_matrix(Q, C, out=None):

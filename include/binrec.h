@@ -300,16 +300,22 @@ int brBceLogits(const float* z, const float* y, int64_t batch, float inv_batch, 
  * S = Q C^T (Bq x Bc), accidental hits (cand_ids[j]==q_pos_ids[i], j != diag) masked, loss =
  * SUM_i [logsumexp_j S_ij - S_i,diag(i)].  Streaming (the Bq x Bc matrix is never stored).
  * Pass 1 (brInBatchSoftmaxLse): row_lse (Bq), loss_sum (double[BR_SUM_SLOTS], slot = workgroup & 63) +=.
- * Pass 2 (brInBatchSoftmaxGrad): dQ = (P - I) C, dC += (P - I)^T Q.
+ * Pass 2 (brInBatchSoftmaxGrad): dQ = (P - I) C, dC = (P - I)^T Q (each optional).
  * diag_offset: column of C holding query i's positive = i + diag_offset (data-parallel ranks
- * all-gather C; rank r's queries sit at offset r*Bq). */
+ * all-gather C; rank r's queries sit at offset r*Bq).
+ * ws / ws_bytes: optional scratch (brInBatchSoftmaxWorkspaceBytes; 16-byte aligned).  A workgroup owns 128 rows, so at the
+ * reference's batch sizes the row blocks alone do not fill 256 CUs: with a workspace the other axis is split over more
+ * workgroups and the partial results (per-row max / sum / diagonal score, dQ / dC slabs) are combined by a second launch in a
+ * fixed order (bit-reproducible).  ws = NULL: one workgroup per 128 rows, results written directly. */
+int64_t brInBatchSoftmaxWorkspaceBytes(int64_t Bq, int64_t Bc, int dim);
 int brInBatchSoftmaxLse(const float* Q, const float* C, const void* q_pos_ids,
                         const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
-                        int64_t diag_offset, float* row_lse, double* loss_sum, brStream stream);
+                        int64_t diag_offset, float* row_lse, double* loss_sum, void* ws,
+                        int64_t ws_bytes, brStream stream);
 int brInBatchSoftmaxGrad(const float* Q, const float* C, const void* q_pos_ids,
                          const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
                          int64_t diag_offset, const float* row_lse, float* dQ, float* dC,
-                         brStream stream);
+                         void* ws, int64_t ws_bytes, brStream stream);
 
 /* scores[q][c] = Q[q]·C[c] (n_q x n_c, row stride ld_scores): candidate scoring for top-k
  * (TwoTower BruteForce, twoTower.py:64-69,229-230; bpr_predict, src/models/bpr.py:122-133). */
