@@ -221,7 +221,7 @@ def timed(eng, batches, steps, warmup, ctx, row0, batch_total):
     if ctx is not None:
         ctx.barrier()
     dt = time.perf_counter() - t0
-    if ctx is not None and ctx.world > 1:
+    if ctx is not None and not ctx.local:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device if ctx.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -301,13 +301,19 @@ def main():
     _lib.load()
 
     ctx = None
-    if world > 1:
+    # BR_BENCH_FORCE_SHARDED=1 (one-GPU box): the whole N > 1 path - RCCL process group, row-sharded engine, every collective really
+    # issued - on a 1-rank group; a rehearsal of the multi-GPU code, its figure is not a bench line
+    force_sharded = world == 1 and os.environ.get("BR_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if force_sharded:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
-        ctx = par.DistCtx()
+        ctx = par.DistCtx(force_collectives=force_sharded)
 
     B, D = args.batch, args.dim
     # weak scaling: per-GPU batch AND per-GPU table shard are fixed as N grows
@@ -321,7 +327,7 @@ def main():
         # N > 1: per-replica BatchNorm = what the reference's MirroredStrategy does with a plain BatchNormalization
         # [TF-sem] (and no BatchNorm collective in the step); --sync-bn makes the statistics global
         cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl, sync_bn=args.sync_bn)
-        if world == 1:
+        if ctx is None:
             return neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=1)
         return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1)
 
@@ -342,7 +348,7 @@ def main():
     l1, l2 = (n1 + 3) & ~3, (n2 + 3) & ~3
     loc_users, loc_items = eng.local_rows("user_mf"), eng.local_rows("item_mf")
     deferred_mode = bool(getattr(eng, "deferred", False))
-    fused_rows = deferred_mode and world == 1      # the pair launch forms the MF-row gradients itself (neumf_step.cpp fuse_mf)
+    fused_rows = deferred_mode and ctx is None      # the pair launch forms the MF-row gradients itself (neumf_step.cpp fuse_mf)
     uniq_u = sum(int(torch.unique(b[0]).numel()) for b in batches) / len(batches)
     uniq_i = sum(int(torch.unique(b[1]).numel()) for b in batches) / len(batches)
     # algorithmic work per launch (DESIGN.md "Algorithmic bytes"): name, kernel symbol, bound, work, phases to keep eager
@@ -351,9 +357,9 @@ def main():
     ROWS_ALL = ("OPT_TABLES", "ROWS_USER", "SWEEP_USER", "ROWS_ITEM", "SWEEP_ITEM")
     SPEC = {
         "EMBED_FWD": (("neumf_embed_fwd_deferred (4 lookups + replay of lagging rows + GMF dot + concat)", "neumf_embed_fwd_deferred_kernel", "hbm",
-                       B * (4 * D * 4 + 2 * D * 4 + 2 * D * 4 + 12)) if deferred_mode and world == 1 else
+                       B * (4 * D * 4 + 2 * D * 4 + 2 * D * 4 + 12)) if deferred_mode and ctx is None else
                       ("neumf_embed_fwd (4 lookups + GMF dot + concat)", "neumf_embed_fwd_kernel", "hbm", B * (4 * D * 4 + 2 * D * 4 + 12)), ("FWD1",)),
-        "EMBED_BWD": (("mf_grad_inplace" if deferred_mode and world == 1 else "neumf_embed_bwd", "neumf_embed_bwd_kernel", "hbm", B * (4 * D * 4 + 8)), ("OPT_TABLES",)),
+        "EMBED_BWD": (("mf_grad_inplace" if deferred_mode and ctx is None else "neumf_embed_bwd", "neumf_embed_bwd_kernel", "hbm", B * (4 * D * 4 + 8)), ("OPT_TABLES",)),
         "KEEP_BITS": ((f"dropout keep-bit planes (Philox4x32-10, {2 * D} + {n1} + {n2} bits per row)", "keep_bits_kernel", None, None), ("FWD1",)),
         "STEP_STATE": (("step counter / alpha_t advance + BatchNorm sum reset", "step_state_advance_kernel", None, None), ("FWD1",)),
         "FWD_L1": ((f"dense_fwd[{2 * D}x{n1}]", "dense_fwd_kernel", "mfma", 2.0 * B * 2 * D * n1), ("FWD1",)),
@@ -368,16 +374,16 @@ def main():
         "INDEX_USER": (("row index, both tables: chunk rank / merge", "chunk_rank_kernel", None, None), ("FWD1",)),
         "INDEX_ITEM": (("row index [item]", "chunk_rank_kernel", None, None), ("FWD1",)),
         "SEG_PARTIALS": (("segment partial sums of long duplicate runs (both tables)", "segment_partials_kernel", None, None), ROWS_ALL),
-        "ADAM_ROWS_USER": ((("adam_rows_sorted[user + item, one launch]", "adam_rows_sorted_kernel", "hbm", 2 * B * rows_pair + (uniq_u + uniq_i) * per_uniq) if world == 1 else
+        "ADAM_ROWS_USER": ((("adam_rows_sorted[user + item, one launch]", "adam_rows_sorted_kernel", "hbm", 2 * B * rows_pair + (uniq_u + uniq_i) * per_uniq) if ctx is None else
                             ("adam_rows_sorted[user]", "adam_rows_sorted_kernel", "hbm", B * rows_pair + uniq_u * per_uniq)), ROWS_ALL),
         "ADAM_ROWS_ITEM": (("adam_rows_sorted[item]", "adam_rows_sorted_kernel", "hbm", B * rows_pair + uniq_i * per_uniq), ROWS_ALL),
         "SWEEP_USER": ((f"adam_dense_sweep[user {loc_users}x{2 * D}]", "adam_dense_sweep_kernel", "hbm", 6 * 4 * loc_users * 2 * D), ("SWEEP_USER",)),
         "SWEEP_ITEM": ((f"adam_dense_sweep[item {loc_items}x{2 * D}]", "adam_dense_sweep_kernel", "hbm", 6 * 4 * loc_items * 2 * D), ("SWEEP_ITEM",)),
-        "ADAM_FLAT": (("dense finalize: slab reduce x3 + BatchNorm grads + Adam (one launch)" if world == 1 else "adam_flat", "dense_finalize_kernel", None, None), ("OPT_DENSE",)),
+        "ADAM_FLAT": (("dense finalize: slab reduce x3 + BatchNorm grads + Adam (one launch)" if ctx is None else "adam_flat", "dense_finalize_kernel", None, None), ("OPT_DENSE",)),
         "REDUCE": (("reduce_slabs (each)", "reduce_slabs_kernel", None, None), ("BWD1",)),
         "SMALL": (("bn / small (each)", "-", None, None), ("BNG",)),
     }
-    use_graph = world == 1 and not args.no_graph
+    use_graph = ctx is None and not args.no_graph
     run_steps(eng, batches, args.warmup, row0, batch_total)   # warm-up outside the probe
     pyprobe = None
     eager_profile = None
@@ -427,7 +433,7 @@ def main():
     else:
         if lib.brProbeEnable(64 * args.steps) != 0:
             raise RuntimeError(lib.brGetLastError().decode())
-        if world > 1:
+        if ctx is not None:
             users_rows = eng.local_rows("user_mf")
             pyprobe = PyProbe({"brAdamDenseSweep": lambda a: TAG["SWEEP_USER"] if int(a[3]) == users_rows else TAG["SWEEP_ITEM"],
                                "brAdamRowsSorted": lambda a: TAG["ADAM_ROWS_USER"] if int(a[3]) == users_rows else TAG["ADAM_ROWS_ITEM"],
@@ -498,7 +504,7 @@ def main():
         except Exception as exc:  # noqa: BLE001
             log(f"whole-step graph leg failed: {exc}")
             eng.disable_graph()
-    if deferred_mode and world == 1:
+    if deferred_mode and ctx is None:
         # the deferred tables must be flushed at least every BR_ALPHA_RING-8 steps: run up to that point and
         # time the flush a long job pays there (worst case: every row replays a full ring of steps)
         period = eng.ALPHA_RING - 8
@@ -527,7 +533,7 @@ def main():
         del e2
         return {"value": B * world * args.steps / d2, "unit": "pairs/s", "ms_per_step": d2 / args.steps * 1e3}
 
-    if not args.no_lazy and args.optimizer == "adam_dense" and world == 1:     # the extra legs are single-GPU information
+    if not args.no_lazy and args.optimizer == "adam_dense" and ctx is None:     # the extra legs are single-GPU information
         del eng
         if deferred_mode:
             sweep_leg = extra_leg("adam_dense", "sweep")
@@ -545,7 +551,7 @@ def main():
         del eng2
 
     legs = None
-    if rank == 0 and world == 1 and not args.no_legs:
+    if rank == 0 and ctx is None and not args.no_legs:
         ops = importlib.import_module("binary-recommendation_amd.ops")
         try:
             del eng
@@ -576,7 +582,7 @@ def main():
         torch.cuda.empty_cache()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and ctx is None and not args.no_cpu_baseline:
         log("cpu baseline start")
         cpu = cpu_baseline(args, D)
         log("cpu baseline done")
@@ -590,7 +596,7 @@ def main():
                                    f"{2 * D}->{'->'.join(map(str, eng_hidden(args, neumf)))}->1, BCE, Keras-Adam {args.optimizer}), "
                                    f"embed_dim={D}, {args.users} users x {args.items} items per GPU, batch {B} per GPU, "
                                    f"{'Zipf(1.05)' if args.zipf else 'uniform'} ids",
-                       "global_batch": batch_total, "parallelism": "single GPU" if world == 1 else f"row-sharded tables x{world} + dp{world}, {'global' if args.sync_bn else 'per-replica'} BatchNorm",
+                       "global_batch": batch_total, "parallelism": "single GPU" if ctx is None else f"row-sharded tables x{world} + dp{world}, {'global' if args.sync_bn else 'per-replica'} BatchNorm",
                        "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
             "roofline": roofline, "cpu_baseline": cpu, "legs": legs, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
             "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i},
@@ -600,7 +606,7 @@ def main():
             "kernels": kernels,
         }
         print(json.dumps(line))
-    if world > 1:
+    if ctx is not None:
         torch.distributed.destroy_process_group()
 
 

@@ -20,6 +20,10 @@ struct BwdArgs {
   float* slabs; int64_t slab_elems; int64_t db_off;   // slab of workgroup b: slabs + b*slab_elems; db at +db_off (< 0: not written)
 };
 
+// dense_fwd.hip: brDropoutKeepBits for the step (resolved step counter + step_add)
+int dropout_keep_bits_ahead(float drop_p, uint64_t seed, uint32_t step, uint32_t step_add, int64_t row0, int64_t batch, int n_sites,
+                            const uint32_t* sites, const int* widths, uint32_t* const* out, brStream stream);
+
 int dense_backward_fused(const BwdArgs& a, hipStream_t s);    // BR_ERR_UNSUPPORTED when the LDS image does not fit
 int dense_bwd_fused_grid(int64_t batch);                      // workgroups = slabs written
 size_t dense_bwd_fused_lds(int NT, int KT);

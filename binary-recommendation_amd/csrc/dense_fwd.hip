@@ -23,6 +23,7 @@
 //   regenerated inside the forward, the dx and the dW kernel of each layer (~120 VALU per 8 elements, three times).
 #include "common.h"
 #include "philox.h"
+#include "dense.h"
 
 namespace br {
 
@@ -422,6 +423,12 @@ extern "C" int64_t brDropoutKeepWords(int64_t batch, int K) { return (batch > 0 
 
 extern "C" int brDropoutKeepBits(float drop_p, uint64_t seed, uint32_t step, int64_t row0, int64_t batch, int n_sites, const uint32_t* sites,
                                  const int* widths, uint32_t* const* out, brStream stream) {
+  return br::dropout_keep_bits_ahead(drop_p, seed, step, 0, row0, batch, n_sites, sites, widths, out, stream);
+}
+
+// step_add: masks of step (resolved counter + step_add) - the step driver prefetches the next step's planes
+int br::dropout_keep_bits_ahead(float drop_p, uint64_t seed, uint32_t step, uint32_t step_add, int64_t row0, int64_t batch, int n_sites,
+                                const uint32_t* sites, const int* widths, uint32_t* const* out, brStream stream) {
   BR_CHECK_ARG(n_sites >= 1 && n_sites <= 3 && sites && widths && out && batch >= 0, "brDropoutKeepBits: bad args (1..3 sites)");
   BR_CHECK_ARG(drop_p > 0.f && drop_p < 1.f, "brDropoutKeepBits: drop_p must be in (0,1)");
   if (batch == 0) return BR_OK;
@@ -436,6 +443,7 @@ extern "C" int brDropoutKeepBits(float drop_p, uint64_t seed, uint32_t step, int
   }
   a.drop = make_dropout(drop_p, seed, step, 0);
   if (const StepStateDev* ss = current_step_state()) a.drop.step_ptr = &ss->step;
+  a.drop.step_add = step_add;
   a.row0 = row0; a.batch = batch;
   const dim3 grid((unsigned)ceil_div(batch * kwmax, 256), (unsigned)n_sites);
   keep_bits_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);

@@ -1,5 +1,6 @@
 // brNeumfStepRun: the NeuMF step as one host call (launch sequencing only; see include/binrec.h).
 #include "common.h"
+#include "dense.h"
 
 #include <vector>
 
@@ -76,11 +77,13 @@ extern "C" int brProbeRead(int i, int* tag, float* ms) {
 
 // fork/join events of the optional aux stream (created once, on first use)
 namespace {
-hipEvent_t g_fork = nullptr, g_join = nullptr;
+hipEvent_t g_fork = nullptr, g_join = nullptr, g_kfork = nullptr, g_kjoin = nullptr;
 bool ensure_events() {
   if (g_fork) return true;
   return hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&g_join, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&g_join, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&g_kfork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&g_kjoin, hipEventDisableTiming) == hipSuccess;
 }
 }  // namespace
 
@@ -128,6 +131,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   BR_CHECK_ARG(!deferred || (s->step_state && s->user_last && s->item_last), "brNeumfStepRun: deferred Adam needs step_state and the last[] arrays");
   const int l1 = (n1 + 3) & ~3, l2 = (n2 + 3) & ~3;      // row strides of a1 / gh1 and a2 / gh2 (padded to 16 B: include/binrec.h)
   const float p = train ? s->dropout : 0.f;
+  const int64_t krows = s->keep_rows > 0 ? s->keep_rows : B;   // rows the keep-bit planes are laid out for
   const double bt = (double)(s->batch_total > 0 ? s->batch_total : B);
   const float inv_b = (float)(1.0 / bt);
   const double bt_bn = s->bn_local ? (double)B : bt;       // rows behind the BatchNorm sums
@@ -170,9 +174,23 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   uint32_t *keep0 = nullptr, *keep1 = nullptr, *keep2 = nullptr;
   if (p > 0.f) {
     BR_CHECK_ARG(s->keep_bits != nullptr, "brNeumfStepRun: dropout needs brNeumfStep.keep_bits");
-    keep0 = s->keep_bits; keep1 = keep0 + brDropoutKeepWords(B, 2 * D); keep2 = keep1 + brDropoutKeepWords(B, n1);
+    BR_CHECK_ARG(s->keep_rows == 0 || s->keep_rows >= B, "brNeumfStepRun: keep_rows < batch");
+    keep0 = s->keep_bits; keep1 = keep0 + brDropoutKeepWords(krows, 2 * D); keep2 = keep1 + brDropoutKeepWords(krows, n1);
   }
-  if ((ph & BR_PH_FWD1) && p > 0.f) {
+  // dedup sorts on the aux stream, forked right behind the step-counter launch: they depend only on the ids and then run beside the
+  // embedding lookup (an HBM-latency-bound gather without LDS).  Beside the first dense layer they cost it ~20 us: its one-wave grid
+  // had to wait for the 16 CUs the sort workgroups (64 KB of LDS each) were holding.
+  if ((ph & BR_PH_FWD1) && aux_index) {
+    if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
+    hipStream_t as = (hipStream_t)s->aux_stream;
+    (void)hipEventRecord(g_fork, hs);                 // the previous step's readers of the index buffers are done
+    (void)hipStreamWaitEvent(as, g_fork, 0);
+    const int rc = brRowIndexBuildPair(s->users, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes,
+                                       s->items, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, s->id_type, B, s->aux_stream);
+    if (rc != BR_OK) return rc;
+    (void)hipEventRecord(g_join, as);
+  }
+  if ((ph & BR_PH_FWD1) && p > 0.f && !(train && s->keep_ready)) {
     const uint32_t sites[3] = {0, 1, 2};
     const int widths[3] = {2 * D, n1, n2};
     uint32_t* const outs[3] = {keep0, keep1, keep2};
@@ -190,16 +208,6 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     else if (ph & BR_PH_EMBED)   /* deferred + inference: the host flushed the tables (brAdamFlush) first */
       RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForward(s->user_tab, s->item_tab, s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows,
                               s->users, s->items, s->id_type, D, B, s->item_first, s->x0, s->dot, s->err_flag, stream));
-    if (aux_index) {
-      if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
-      hipStream_t as = (hipStream_t)s->aux_stream;
-      (void)hipEventRecord(g_fork, hs);                 // the previous step's readers of the index buffers are done
-      (void)hipStreamWaitEvent(as, g_fork, 0);
-      const int rc = brRowIndexBuildPair(s->users, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes,
-                                         s->items, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, s->id_type, B, s->aux_stream);
-      if (rc != BR_OK) return rc;
-      (void)hipEventRecord(g_join, as);
-    }
     RUN(BR_TAG_FWD_L1, brDenseForward(s->x0, 2 * D, th + oW1, th + ob1, s->a1, l1, B, 2 * D, n1, s->act, nullptr, nullptr, nullptr, p, keep0,
                        train ? stats1 : nullptr, stream));
   }
@@ -263,6 +271,21 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     (void)hipStreamWaitEvent(hs, g_join, 0);
     joined = true;
   }
+  // next step's dropout planes on the aux stream beside the Adam-rows kernel (the planes' last readers - this step's backward -
+  // are behind us on the launch stream; the dedup sorts on the aux stream were joined above)
+  const bool prefetch = train && p > 0.f && s->keep_prefetch && s->aux_stream && (ph & BR_PH_ROWS_USER);
+  if (prefetch) {
+    if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
+    hipStream_t as = (hipStream_t)s->aux_stream;
+    (void)hipEventRecord(g_kfork, hs);
+    (void)hipStreamWaitEvent(as, g_kfork, 0);
+    const uint32_t sites[3] = {0, 1, 2};
+    const int widths[3] = {2 * D, n1, n2};
+    uint32_t* const outs[3] = {keep0, keep1, keep2};
+    const int rc = br::dropout_keep_bits_ahead(p, s->seed, (uint32_t)s->step, 1, s->row0, krows, 3, sites, widths, outs, s->aux_stream);
+    if (rc != BR_OK) return rc;
+    (void)hipEventRecord(g_kjoin, as);
+  }
   {
     uint8_t* um = s->adam_dense == 1 ? s->user_mark : nullptr;
     uint8_t* im = s->adam_dense == 1 ? s->item_mark : nullptr;
@@ -297,6 +320,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     if ((ph & BR_PH_SWEEP_ITEM) && s->adam_dense == 1)
       RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
   }
+  if (prefetch) (void)hipStreamWaitEvent(hs, g_kjoin, 0);
   if ((ph & BR_PH_OPT_DENSE) && fused_final) {
     const float* const rs[3] = {slabs1, slabs2, slabs_t};
     const int rn[3] = {sp.ns1, sp.ns2, sp.ns_t};

@@ -49,6 +49,7 @@ struct DropoutCfg {
   uint32_t thr;      // 0 => dropout off
   float inv_keep;    // 1/(1-p)
   const uint32_t* step_ptr;   // non-null: the step counter lives in device memory (hipGraph replays)
+  uint32_t step_add;          // added to the resolved counter (keep-bit planes prefetched for the next step)
 };
 
 __host__ inline DropoutCfg make_dropout(float p, uint64_t seed, uint32_t step, uint32_t site) {
@@ -60,12 +61,14 @@ __host__ inline DropoutCfg make_dropout(float p, uint64_t seed, uint32_t step, u
   c.thr = p > 0.f ? dropout_threshold(p) : 0u;
   c.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   c.step_ptr = nullptr;
+  c.step_add = 0;
   return c;
 }
 
 // kernels call this once on their by-value copy
 __device__ __forceinline__ void dropout_resolve(DropoutCfg& c) {
   if (c.step_ptr) c.step = *c.step_ptr;
+  c.step += c.step_add;
 }
 
 // keep-bits (bit i = column 8*c8 + i kept) of the 8 columns of chunk c8 of global row r

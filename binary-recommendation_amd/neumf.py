@@ -222,6 +222,10 @@ class NeuMFEngine:
         self.nsh = ops.head_slabs(B)
         self.hslabs = f(self.nsh * (n3 + 2))
         self.keep_bits = torch.empty(sum(ops.dropout_keep_words(B, k) for k in (2 * D, n1, n2)), dtype=torch.int32, device=dev)
+        self._keep_widths = (2 * D, n1, n2)
+        o1, o2 = ops.dropout_keep_words(B, 2 * D), ops.dropout_keep_words(B, 2 * D) + ops.dropout_keep_words(B, n1)
+        self._keep_planes = [self.keep_bits[:o1], self.keep_bits[o1:o2], self.keep_bits[o2:]]
+        self._keep_for = None                  # (step, row0) whose masks the planes hold (a training step prefetches the next one's)
         self.err = ops.new_err_flag(dev)
         self._alloc_sparse(B)
         self._build_step_struct()
@@ -298,6 +302,11 @@ class NeuMFEngine:
         st.labels = labels.data_ptr() if labels is not None else None
         st.training, st.step = int(training), self.t
         st.alpha_t = ops.adam_alpha(self.cfg.lr, max(self.t, 1), self.cfg.beta1, self.cfg.beta2)
+        # dropout planes: laid out for max_batch rows; a single-process training step prefetches the next step's planes beside its
+        # Adam-rows kernel (brNeumfStep.keep_prefetch), and this step skips the generation if it is the one they were made for
+        st.keep_rows = self.max_batch
+        st.keep_prefetch = 1 if (training and self.dist is None and st.aux_stream) else 0
+        st.keep_ready = 1 if (training and self._keep_for == (self.t, row0)) else 0
 
     def _alloc_sparse(self, B):
         dev = self.device
@@ -348,6 +357,7 @@ class NeuMFEngine:
         self._set_batch(users, items, labels, B, True, row0, batch_total)
         if self.dist is None:
             self._run(PH["ALL"])
+            self._keep_for = (self.t + 1, row0) if self.step_struct.keep_prefetch and cfg.dropout > 0 else None
             return
         d, sync = self.dist, cfg.sync_bn
         emb = 0 if self.sharded else PH["EMBED"]
@@ -419,6 +429,7 @@ class NeuMFEngine:
         self.msums.copy_(keep_sums)
         del keep
         self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, 0, B)
+        st.keep_ready = 1 if st.keep_prefetch else 0      # replays find the planes the previous step (or _replay itself) left
         if eager_phases:
             order = self.PHASE_ORDER
             idx = sorted(order.index(n) for n in eager_phases)
@@ -442,6 +453,7 @@ class NeuMFEngine:
         parts = [ph for ph, _ in parts]
         # the capture itself executes nothing, but the dry run above advanced the device step counter
         self._sync_step_state()
+        self._keep_for = None                 # the dry run above left another step's planes
         self._graph = {"batch": B, "parts": parts, "graphs": graphs}
 
     def disable_graph(self):
@@ -460,12 +472,20 @@ class NeuMFEngine:
                                                 items.data_ptr(), labels.data_ptr(), self.step_struct.id_type, users.shape[0], ops._stream()),
                        "brStageBatch")
         gr = self._graph
+        cfg = self.cfg
+        prefetching = cfg.dropout > 0 and self.step_struct.aux_stream
+        if prefetching and self._keep_for != (self.t, 0):
+            # first replay (or the previous step ran another path): the graph expects this step's planes to be there
+            ops.dropout_keep_bits(cfg.dropout, cfg.seed, self.t, 0, self.max_batch, (0, 1, 2), self._keep_widths, self._keep_planes)
+            self._keep_for = (self.t, 0)
         for ph, g in zip(gr["parts"], gr["graphs"]):
             if g is None:
                 self._set_batch(self.in_users, self.in_items, self.in_labels, gr["batch"], True, 0, gr["batch"])
+                self.step_struct.keep_ready = 1 if prefetching else 0
                 self._run(ph)
             else:
                 g.replay()
+        self._keep_for = (self.t + 1, 0) if prefetching else None
 
     def row_grad_views(self, B):
         """name -> (tensor, row stride): the MLP halves are views of dx0, the MF halves of g_user / g_item.

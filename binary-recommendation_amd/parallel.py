@@ -22,18 +22,21 @@ import torch.distributed as dist
 class DistCtx:
     """Thin wrapper over a torch.distributed process group ("nccl" == RCCL on ROCm)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force_collectives: bool = False):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        # a 1-rank group normally short-cuts every collective to a local copy; force_collectives issues them anyway
+        # (rehearsal of the RCCL call paths on a one-GPU box: tests/test_gpu_nccl_world1.py, bench.py BR_BENCH_FORCE_SHARDED)
+        self.local = self.world == 1 and not force_collectives
 
     def _stage(self, t):
         # gloo has no device-side collectives for every op: stage through the host there
         return self.backend == "gloo" and t.is_cuda
 
     def all_reduce_sum(self, t: torch.Tensor):
-        if self.world == 1:
+        if self.local:
             return t
         if self._stage(t):
             c = t.cpu()
@@ -45,7 +48,7 @@ class DistCtx:
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits):
         """Row-wise all_to_all_single (splits count rows of dim 0)."""
-        if self.world == 1:
+        if self.local:
             out.copy_(inp)
             return out
         if self._stage(inp):
@@ -58,7 +61,7 @@ class DistCtx:
 
     def all_gather_rows(self, inp: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self.world * inp.shape[0],) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
-        if self.world == 1:
+        if self.local:
             out.copy_(inp)
         elif self._stage(inp):
             co = torch.empty(out.shape, dtype=out.dtype)
@@ -69,7 +72,7 @@ class DistCtx:
         return out
 
     def barrier(self):
-        if self.world > 1:
+        if not self.local:
             dist.barrier(group=self.group)
 
 
@@ -148,7 +151,7 @@ class ShardExchange:
         plans = (self,) + others
         S = len(plans)
         sc = torch.stack([p.send_counts_t for p in plans]).to(torch.int64)          # (S, W)
-        if W > 1:
+        if not ctx.local:
             # peer-major layout (inp[d*S + s] = sc[s][d]) so ONE all_to_all moves every stream's count
             out = torch.empty(W * S, dtype=torch.int64, device=sc.device)
             ctx.all_to_all(out, sc.t().contiguous().view(-1), [S] * W, [S] * W)

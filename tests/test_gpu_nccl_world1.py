@@ -1,0 +1,99 @@
+"""-m gpu: the RCCL ("nccl") branches of parallel.DistCtx and the row-sharded engines on a 1-rank group with every collective
+really issued (force_collectives) - device tensors go straight into all_reduce / all_to_all_single / all_gather_into_tensor, no
+host staging.  The GPU box has one card, so this is the only way these call paths run before the 8-GPU bench; results must
+equal the single-GPU engine's bit for bit (one rank owns every row)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from importlib import import_module
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        par, neumf, bpr, tt = (import_module("binary-recommendation_amd." + m) for m in ("parallel", "neumf", "bpr", "two_tower"))
+        ctx = par.DistCtx(force_collectives=True)
+        assert ctx.backend == "nccl" and not ctx.local
+        x = torch.arange(12, dtype=torch.float32, device=dev).view(4, 3)
+        assert torch.equal(ctx.all_reduce_sum(x.clone()), x)
+        out = torch.empty_like(x)
+        assert torch.equal(ctx.all_to_all(out, x, [4], [4]), x)
+        assert torch.equal(ctx.all_gather_rows(x), x)
+        ids = torch.tensor([5, 3, 5, 0], dtype=torch.int32, device=dev)
+        xch = par.ShardExchange(ctx).plan(ids)
+        xch.exchange_counts()
+        assert xch.send_counts == [4] and xch.recv_counts == [4] and torch.equal(xch.send_ids()[xch.inv.long()], ids)
+        ctx.barrier()
+        # NeuMF: sharded engine (deferred dense Adam, per-replica BatchNorm) == single-GPU engine
+        U, I, B = 300, 200, 256
+        g = torch.Generator().manual_seed(3)
+        steps = [(torch.randint(0, U, (B,), generator=g).int().to(dev), torch.randint(0, I, (B,), generator=g).int().to(dev),
+                  (torch.rand(B, generator=g) < 0.25).float().to(dev)) for _ in range(3)]
+        for sync_bn in (False, True):
+            cfg = neumf.NeuMFConfig(variant="A", dim=16, seed=11, sync_bn=sync_bn)
+            single = neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=2)
+            sh = par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, full_tables={k: single.tables[k].clone() for k in neumf.TABLES})
+            sh.theta.buf.copy_(single.theta.buf)
+            for u, i, y in steps:
+                single.train_step(u, i, y)
+                sh.train_step(u, i, y)
+            single.flush(); sh.flush()
+            travel = 3 * cfg.lr        # Adam's first steps are sign-like: elements whose gradient is ~0 may move differently
+            for k in neumf.TABLES:
+                a, b = sh.tables[k].cpu().numpy()[: single.tables[k].shape[0]], single.tables[k].cpu().numpy()
+                np.testing.assert_allclose(a, b, rtol=1e-5, atol=5e-3 * travel, err_msg=k)
+                assert np.median(np.abs(a - b)) <= 1e-7, k
+            np.testing.assert_allclose(sh.theta.buf.cpu().numpy(), single.theta.buf.cpu().numpy(), rtol=1e-5, atol=2e-2 * travel)
+            np.testing.assert_allclose(sh.predict(steps[0][0], steps[0][1]).cpu().numpy(), single.predict(steps[0][0], steps[0][1]).cpu().numpy(), rtol=1e-3, atol=1e-4)
+        # BPR and TwoTower sharded steps on the same group
+        eb = par.make_sharded_bpr(bpr.BPREngine)(U, I, 16, dev, B, ctx)
+        es = bpr.BPREngine(U, I, 16, dev, B)
+        es.user.copy_(eb.user[:U]); es.item.copy_(eb.item[:I])
+        n = torch.randint(0, I, (B,), generator=g).int().to(dev)
+        eb.train_step(steps[0][0], steps[0][1], n); es.train_step(steps[0][0], steps[0][1], n)
+        np.testing.assert_allclose(eb.user[:U].cpu().numpy(), es.user.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(eb.predict_scores(steps[1][0][:9]).cpu().numpy(), es.predict_scores(steps[1][0][:9]).cpu().numpy(), rtol=1e-6, atol=1e-7)
+        et = par.make_sharded_two_tower(tt.TwoTowerEngine)(24, I, U, 16, dev, B, ctx)
+        e1 = tt.TwoTowerEngine(24, I, U, 16, dev, B)
+        e1.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in et.state_dict().items()})
+        uu, ii = steps[2][0] + 2, steps[2][1] + 2
+        et.train_step(uu, ii); e1.train_step(uu, ii)
+        np.testing.assert_allclose(et.user_emb.cpu().numpy()[: U + 2], e1.user_emb.cpu().numpy(), rtol=1e-5, atol=2e-4)
+        la, lb = et.pop_loss(), e1.pop_loss()
+        assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+        torch.cuda.synchronize()
+        q.put("ok")
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put("FAIL: " + traceback.format_exc()[-2500:])
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def test_rccl_one_rank_group(dev):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    p = ctxm.Process(target=_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res == "ok", res
