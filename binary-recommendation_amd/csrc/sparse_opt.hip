@@ -854,6 +854,92 @@ __global__ __launch_bounds__(256) void shard_finish_kernel(ShardFinishJobs jobs,
   }
 }
 
+// ---- fixed-capacity form of the exchange plan: every peer gets exactly `cap` slots per stream, so the all-to-alls have equal, static
+// splits and no row count ever crosses to the host.  Slot t = d * cap + k holds the k-th row for owner d (bucket order), pad slots
+// hold the owner's spare row (local index = its row count: the tables of a padded engine carry one extra row whose gradient is always 0).
+struct ShardPadJob {
+  const void* sorted_dest; const int32_t* order; const void* send_local; const int64_t* counts;
+  void* send_pad; int32_t* slot; int32_t* bpos; int64_t total_rows;
+};
+struct ShardPadJobs { ShardPadJob j[2]; };
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void shard_pad_kernel(ShardPadJobs jobs, int64_t n, int world, int64_t cap, int* __restrict__ overflow) {
+  const ShardPadJob& jb = jobs.j[blockIdx.y];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) {                                        // bucket position t -> its slot
+    const int64_t d = (int64_t)((const IdT*)jb.sorted_dest)[t];
+    int64_t off = 0;
+    for (int64_t q = 0; q < d; ++q) off += jb.counts[q];
+    int64_t k = t - off;
+    if (k >= cap) { atomicOr(overflow, BR_ERRFLAG_CAPACITY); k = cap - 1; }     // reported by the host's next flag check
+    const int64_t sl = d * cap + k;
+    const int32_t b = jb.order[t];
+    jb.slot[b] = (int32_t)sl;
+    if (t - off < cap) { ((IdT*)jb.send_pad)[sl] = ((const IdT*)jb.send_local)[t]; jb.bpos[sl] = b; }
+  }
+  if (t < (int64_t)world * cap) {                     // pad slots
+    const int64_t d = t / cap, k = t - d * cap;
+    if (k >= jb.counts[d]) {
+      const int64_t spare = jb.total_rows > d ? (jb.total_rows - d + world - 1) / world : 0;   // rows owner d holds = index of its spare row
+      ((IdT*)jb.send_pad)[t] = (IdT)spare;
+      jb.bpos[t] = -1;
+    }
+  }
+}
+
+extern "C" int brShardPadPair(const void* sorted_dest_a, const void* sorted_dest_b, const int32_t* order_a, const int32_t* order_b,
+                              const void* send_local_a, const void* send_local_b, const int64_t* counts_a, const int64_t* counts_b, int id_type,
+                              int64_t n, int world, int64_t cap, int64_t total_rows_a, int64_t total_rows_b, void* send_pad_a, void* send_pad_b,
+                              int32_t* slot_a, int32_t* slot_b, int32_t* bpos_a, int32_t* bpos_b, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brShardPadPair: bad id_type");
+  BR_CHECK_ARG(world >= 1 && world <= 256 && n >= 0 && cap >= 1 && err_flag, "brShardPadPair: bad world / n / cap / flag");
+  BR_CHECK_ARG(sorted_dest_a && order_a && send_local_a && counts_a && send_pad_a && slot_a && bpos_a, "brShardPadPair: null pointer (stream a)");
+  const int n_jobs = sorted_dest_b ? 2 : 1;
+  BR_CHECK_ARG(!sorted_dest_b || (order_b && send_local_b && counts_b && send_pad_b && slot_b && bpos_b), "brShardPadPair: null pointer (stream b)");
+  ShardPadJobs J;
+  J.j[0] = ShardPadJob{sorted_dest_a, order_a, send_local_a, counts_a, send_pad_a, slot_a, bpos_a, total_rows_a};
+  J.j[1] = sorted_dest_b ? ShardPadJob{sorted_dest_b, order_b, send_local_b, counts_b, send_pad_b, slot_b, bpos_b, total_rows_b} : J.j[0];
+  const int64_t m = n > (int64_t)world * cap ? n : (int64_t)world * cap;
+  const dim3 g((unsigned)ceil_div(m, 256), (unsigned)n_jobs);
+  if (id_type == BR_IDS_I32) shard_pad_kernel<int32_t><<<g, 256, 0, (hipStream_t)stream>>>(J, n, world, cap, err_flag);
+  else shard_pad_kernel<int64_t><<<g, 256, 0, (hipStream_t)stream>>>(J, n, world, cap, err_flag);
+  BR_CHECK_LAUNCH("brShardPadPair");
+  return BR_OK;
+}
+
+// dst[t] = bpos[t] >= 0 ? src[bpos[t]] : 0 for one or two (src, bpos, dst) sets of equal shape: per-pair rows -> padded send slots
+struct PadRowsJob { const float* src; int64_t ld; const int32_t* bpos; float* dst; };
+struct PadRowsJobs { PadRowsJob j[2]; };
+__global__ __launch_bounds__(256) void rows_to_slots_kernel(PadRowsJobs jobs, int64_t n_slots, int dim) {
+  const PadRowsJob& jb = jobs.j[blockIdx.y];
+  const int q4 = dim >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_slots * q4) return;
+  const int64_t t = i / q4;
+  const int c = (int)(i - t * q4) << 2;
+  const int32_t b = jb.bpos[t];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b >= 0) v = *reinterpret_cast<const float4*>(jb.src + (int64_t)b * jb.ld + c);
+  *reinterpret_cast<float4*>(jb.dst + t * dim + c) = v;
+}
+
+extern "C" int brRowsToSlotsPair(const float* src_a, const float* src_b, int64_t ld, const int32_t* bpos_a, const int32_t* bpos_b, float* dst_a,
+                                 float* dst_b, int64_t n_slots, int dim, brStream stream) {
+  BR_CHECK_ARG(src_a && bpos_a && dst_a && n_slots >= 0 && dim >= 4 && dim % 4 == 0 && ld >= dim && ld % 4 == 0, "brRowsToSlotsPair: bad args (dim, ld multiples of 4)");
+  BR_CHECK_ARG(((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(dst_a) | reinterpret_cast<uintptr_t>(src_b) | reinterpret_cast<uintptr_t>(dst_b)) & 15) == 0,
+               "brRowsToSlotsPair: rows must be 16-byte aligned");
+  BR_CHECK_ARG(!src_b || (bpos_b && dst_b), "brRowsToSlotsPair: null pointer (set b)");
+  if (n_slots == 0) return BR_OK;
+  PadRowsJobs J;
+  J.j[0] = PadRowsJob{src_a, ld, bpos_a, dst_a};
+  J.j[1] = src_b ? PadRowsJob{src_b, ld, bpos_b, dst_b} : J.j[0];
+  const dim3 g((unsigned)ceil_div(n_slots * (dim >> 2), 256), src_b ? 2u : 1u);
+  rows_to_slots_kernel<<<g, 256, 0, (hipStream_t)stream>>>(J, n_slots, dim);
+  BR_CHECK_LAUNCH("brRowsToSlotsPair");
+  return BR_OK;
+}
+
 extern "C" int brShardPlanPair(const void* ids_a, const void* ids_b, int id_type, int64_t n, int world, void* dest_a, void* dest_b,
                                void* sorted_dest_a, void* sorted_dest_b, int32_t* order_a, int32_t* order_b, void* ws_a, void* ws_b,
                                int64_t ws_bytes, int32_t* inv_a, int32_t* inv_b, void* send_local_a, void* send_local_b,

@@ -65,8 +65,12 @@ def new_err_flag(device) -> torch.Tensor:
 
 def raise_if_flag(flag: torch.Tensor, what="embedding id"):
     """Host sync. Turns the device flag into the IndexError TF-CPU would raise [TF-sem]."""
-    if int(flag.item()) != 0:
+    v = int(flag.item())
+    if v != 0:
         flag.zero_()
+        if v & 2:      # BR_ERRFLAG_CAPACITY (brShardPadPair)
+            raise RuntimeError("row-sharded exchange: more rows for one owner than the fixed per-peer capacity; raise exchange_capacity "
+                               "(ids this skewed need > 1.25 x batch / world slots) or use exchange='exact'")
         raise IndexError(f"{what} out of range")
 
 

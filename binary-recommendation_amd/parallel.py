@@ -59,6 +59,18 @@ class DistCtx:
             dist.all_to_all_single(out, inp.contiguous(), list(out_splits), list(in_splits), group=self.group)
         return out
 
+    def all_to_all_equal(self, out: torch.Tensor, inp: torch.Tensor):
+        """all_to_all_single with equal, static splits (dim 0 of both is a multiple of the world size): no split lists, no counts."""
+        if self.local:
+            out.copy_(inp)
+        elif self._stage(inp):
+            co = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(co, inp.cpu(), group=self.group)
+            out.copy_(co)
+        else:
+            dist.all_to_all_single(out, inp, group=self.group)
+        return out
+
     def all_gather_rows(self, inp: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self.world * inp.shape[0],) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
         if self.local:
@@ -182,6 +194,72 @@ class ShardExchange:
         return self.ctx.all_to_all(out, grads_bucket_order, self.recv_counts, self.send_counts)
 
 
+class PaddedExchange:
+    """Both id streams of a NeuMF step with a FIXED number of slots per peer (brShardPadPair): the three all-to-alls per stream
+    have equal static splits, every buffer is allocated once, and nothing about the step is read back by the host - the step's
+    launches and collectives are enqueued without a sync (the exact exchange above needs the per-peer row counts on the host
+    before it can post its first all-to-all).  Pad slots carry the owner's spare table row (gradient 0).  More rows for one owner
+    than `cap` sets a device flag that the engine's check_ids() turns into an error (uniform ids at batch 65 536 / 8 ranks sit
+    20 sigma below the default 1.25 x batch / world; ids as skewed as Zipf(1.05) need a larger factor or the exact exchange)."""
+
+    def __init__(self, ctx: DistCtx, max_batch: int, id_dtype, device, total_rows, dim: int, factor: float = 1.25):
+        from . import _lib, ops
+        W = ctx.world
+        self.ctx, self.W, self.dim, self.id_dtype, self.total_rows = ctx, W, int(dim), id_dtype, tuple(int(r) for r in total_rows)
+        cap = max_batch if W == 1 else min(max_batch, (int(max_batch / W * factor) + 64) // 64 * 64)
+        self.cap, self.n_slots = cap, W * cap
+        self.id_type = ops.I64 if id_dtype == torch.int64 else ops.I32
+        e = lambda n, dt: torch.empty(n, dtype=dt, device=device)
+        B, S = max_batch, self.n_slots
+        self.dest, self.sdest, self.send = [e(B, id_dtype) for _ in range(2)], [e(B, id_dtype) for _ in range(2)], [e(B, id_dtype) for _ in range(2)]
+        self.order, self.inv = [e(B, torch.int32) for _ in range(2)], [e(B, torch.int32) for _ in range(2)]
+        self.counts = [torch.zeros(W, dtype=torch.int64, device=device) for _ in range(2)]
+        self.ws_bytes = int(_lib.load().brRowIndexWorkspaceBytes(B, self.id_type))
+        self.ws = [e(self.ws_bytes, torch.uint8) for _ in range(2)]
+        self.send_pad, self.recv_ids = [e(S, id_dtype) for _ in range(2)], [e(S, id_dtype) for _ in range(2)]
+        self.slot, self.bpos = [e(B, torch.int32) for _ in range(2)], [e(S, torch.int32) for _ in range(2)]
+        f = lambda: [torch.empty(S, self.dim, dtype=torch.float32, device=device) for _ in range(2)]
+        self.served, self.rows, self.gpad, self.grecv = f(), f(), f(), f()
+
+    def plan(self, ids_a, ids_b, err_flag):
+        from . import _lib, ops
+        n = ids_a.shape[0]
+        if ids_b.shape[0] != n or n > self.dest[0].shape[0]:
+            raise ValueError("PaddedExchange.plan: both streams must have the same length <= max_batch")
+        P = lambda t: t.data_ptr()
+        lib = _lib.load()
+        _lib.check(lib.brShardPlanPair(P(ids_a), P(ids_b), self.id_type, n, self.W, P(self.dest[0]), P(self.dest[1]), P(self.sdest[0]), P(self.sdest[1]),
+                                       P(self.order[0]), P(self.order[1]), P(self.ws[0]), P(self.ws[1]), self.ws_bytes, P(self.inv[0]), P(self.inv[1]),
+                                       P(self.send[0]), P(self.send[1]), P(self.counts[0]), P(self.counts[1]), ops._stream()), "brShardPlanPair")
+        _lib.check(lib.brShardPadPair(P(self.sdest[0]), P(self.sdest[1]), P(self.order[0]), P(self.order[1]), P(self.send[0]), P(self.send[1]),
+                                      P(self.counts[0]), P(self.counts[1]), self.id_type, n, self.W, self.cap, self.total_rows[0], self.total_rows[1],
+                                      P(self.send_pad[0]), P(self.send_pad[1]), P(self.slot[0]), P(self.slot[1]), P(self.bpos[0]), P(self.bpos[1]),
+                                      P(err_flag), ops._stream()), "brShardPadPair")
+        self.n = n
+        return self
+
+    def send_ids(self):
+        """all-to-all #1 (per stream): padded local row ids -> the ids this rank serves, n_slots each."""
+        for s in range(2):
+            self.ctx.all_to_all_equal(self.recv_ids[s], self.send_pad[s])
+        return self.recv_ids
+
+    def return_rows(self):
+        """all-to-all #2: self.served (filled by the owner-side gather) -> self.rows in the requester's slot order."""
+        for s in range(2):
+            self.ctx.all_to_all_equal(self.rows[s], self.served[s])
+        return self.rows
+
+    def send_row_grads(self, g_a, g_b):
+        """per-pair row gradients (n x dim, batch order) -> padded slots (pad = 0) -> all-to-all #3 -> aligned with recv_ids."""
+        from . import _lib, ops
+        _lib.check(_lib.load().brRowsToSlotsPair(g_a.data_ptr(), g_b.data_ptr(), g_a.stride(0), self.bpos[0].data_ptr(), self.bpos[1].data_ptr(),
+                                                 self.gpad[0].data_ptr(), self.gpad[1].data_ptr(), self.n_slots, self.dim, ops._stream()), "brRowsToSlotsPair")
+        for s in range(2):
+            self.ctx.all_to_all_equal(self.grecv[s], self.gpad[s])
+        return self.grecv
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Checkpoint / restore of row-sharded engines.  The reference writes ONE SavedModel: the chief to
 # checkpoints/<model>/cp, every other worker to a temporary cp/workertemp_<id> that it deletes again, because all its variables
@@ -214,8 +292,20 @@ def load_sharded(engine, path, rank: int, world: int, global_rows: dict):
     with open(path + ".meta.json") as f:
         meta = json.load(f)
     W0, keys = int(meta["world"]), set(meta["sharded_keys"])
+
+    def fit(sd):
+        """row-sharded entries cut / zero-padded to the engine's row count (an engine with the padded exchange has a spare row)"""
+        have = engine.state_dict()
+        for k in keys:
+            want = have[k].shape[0]
+            if sd[k].shape[0] > want:
+                sd[k] = sd[k][:want]
+            elif sd[k].shape[0] < want:
+                sd[k] = torch.cat([sd[k], torch.zeros((want - sd[k].shape[0],) + tuple(sd[k].shape[1:]), dtype=sd[k].dtype)])
+        return sd
+
     if W0 == world:
-        engine.load_state_dict(torch.load(_shard_file(path, rank, world), map_location="cpu", weights_only=True))
+        engine.load_state_dict(fit(torch.load(_shard_file(path, rank, world), map_location="cpu", weights_only=True)))
         return
     shards = [torch.load(_shard_file(path, r, W0), map_location="cpu", weights_only=True) for r in range(W0)]
     sd = {}
@@ -231,7 +321,7 @@ def load_sharded(engine, path, rank: int, world: int, global_rows: dict):
                 full[r::W0] = shards[r][k][:n]
         mine = full[rank::world]
         sd[k] = mine if mine.shape[0] else torch.zeros((1,) + tuple(v.shape[1:]), dtype=v.dtype)
-    engine.load_state_dict(sd)
+    engine.load_state_dict(fit(sd))
 
 
 def make_sharded_engine(base_cls):
@@ -246,12 +336,24 @@ def make_sharded_engine(base_cls):
         def __init__(self, cfg, num_user_rows, num_item_rows, device, max_batch, ctx: DistCtx, **kw):
             self.ctx = ctx
             self.full_tables = kw.pop("full_tables", None)   # tests: {name: full (rows, D) tensor} to slice
+            # "padded" (default): fixed per-peer capacity, no host sync in the step (PaddedExchange); "exact": row counts over the host
+            self.exchange = kw.pop("exchange", "padded")
+            self.exchange_capacity = float(kw.pop("exchange_capacity", 1.25))
+            if self.exchange not in ("padded", "exact"):
+                raise ValueError("exchange must be 'padded' or 'exact'")
             super().__init__(cfg, num_user_rows, num_item_rows, device, max_batch, dist=ctx, **kw)
             self.xu, self.xi = ShardExchange(ctx), ShardExchange(ctx)
+            if self.exchange == "padded":
+                self.px = PaddedExchange(ctx, max_batch, self.id_dtype, self.device, (num_user_rows, num_item_rows), 2 * cfg.dim, self.exchange_capacity)
+                self._grow_index(self.px.n_slots)
+
+        def owned_rows(self, name):
+            total = self.num_user_rows if name.startswith("user") else self.num_item_rows
+            return shard_rows(total, self.ctx.rank, self.ctx.world)
 
         def local_rows(self, name):
-            total = self.num_user_rows if name.startswith("user") else self.num_item_rows
-            return max(1, shard_rows(total, self.ctx.rank, self.ctx.world))
+            """rows of this rank's table tensors: the rows it owns (+ the spare row the pad slots of the padded exchange point at)"""
+            return max(1, self.owned_rows(name)) + (1 if self.exchange == "padded" else 0)
 
         def _init_tables(self, g, init_seed):
             if self.full_tables is not None:     # tests: slice the rows this rank owns out of global tables
@@ -260,7 +362,10 @@ def make_sharded_engine(base_cls):
                 for stream in ("user", "item"):
                     full = torch.cat([self.full_tables[stream + "_mlp"], self.full_tables[stream + "_mf"]], dim=1)
                     t = full[self.ctx.rank::self.ctx.world].contiguous().to(self.device)
-                    self.fused[stream] = t if t.shape[0] else torch.zeros(1, 2 * D, device=self.device)
+                    t = t if t.shape[0] else torch.zeros(1, 2 * D, device=self.device)
+                    if self.exchange == "padded":
+                        t = torch.cat([t, torch.zeros(1, 2 * D, device=self.device)])
+                    self.fused[stream] = t
                 self._make_views()
                 return
             super()._init_tables(g, init_seed + 104729 * self.ctx.rank)
@@ -285,6 +390,18 @@ def make_sharded_engine(base_cls):
 
         def _embed_forward(self, users, items, B):
             D = self.cfg.dim
+            if self.exchange == "padded":
+                x = self.px.plan(users, items, self.err)
+                ru, ri = x.send_ids()                              # all-to-all #1
+                self._serve_rows("user", ru, out=x.served[0])      # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64)
+                self._serve_rows("item", ri, out=x.served[1])
+                self.r_user, self.r_item = x.return_rows()         # all-to-all #2
+                self.pos_u, self.pos_i = x.slot[0][:B], x.slot[1][:B]
+                if self.id_dtype != torch.int32:
+                    self.pos_u, self.pos_i = self.pos_u.to(self.id_dtype), self.pos_i.to(self.id_dtype)
+                ops.neumf_embed_forward(self.r_user[:, :D], self.r_item[:, :D], self.r_user[:, D:], self.r_item[:, D:], self.pos_u,
+                                        self.pos_i, self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
+                return
             xu, xi = ShardExchange.plan_pair(self.xu, users, self.xi, items)
             xu.exchange_counts(xi)                     # the step's one host sync (variable split sizes)
             ru, ri = xu.send_ids(), xi.send_ids()      # all-to-all #1
@@ -324,13 +441,13 @@ def make_sharded_engine(base_cls):
             self.sync_moving_stats()
             return super()._infer(users, items, labels, n)
 
-        def _serve_rows(self, stream, local_ids):
+        def _serve_rows(self, stream, local_ids, out=None):
             """owner side of the lookup: rows of this rank's shard for the ids its peers asked for."""
             if self.deferred:      # rows as of the previous step, replayed in registers (binrec.h "Deferred dense Adam")
                 cfg = self.cfg
                 return ops.gather_rows_deferred(self.fused[stream], self.fused_m[stream], self.fused_v[stream], self.last[stream], local_ids,
-                                                self.step_state, cfg.beta1, cfg.beta2, cfg.adam_eps, err_flag=self.err)
-            return ops.gather_rows([self.fused[stream]], [local_ids], err_flag=self.err)[0]
+                                                self.step_state, cfg.beta1, cfg.beta2, cfg.adam_eps, out=out, err_flag=self.err)
+            return ops.gather_rows([self.fused[stream]], [local_ids], None if out is None else [out], err_flag=self.err)[0]
 
         def _embed_backward_apply(self, users, items, B):
             cfg, D = self.cfg, self.cfg.dim
@@ -338,6 +455,13 @@ def make_sharded_engine(base_cls):
             # fused per-pair row gradients [mlp | mf] (the MLP halves are copied out of dx0 here)
             ops.neumf_embed_backward(self.r_user[:, D:], self.r_item[:, D:], self.pos_u, self.pos_i, cfg.item_first,
                                      self.dx0[:B], self.ddot[:B], gu[:, D:], gi[:, D:], gu[:, :D], gi[:, :D])
+            if self.exchange == "padded":
+                x = self.px
+                ou, oi = x.send_row_grads(gu, gi)                  # batch order -> padded slots -> all-to-all #3
+                self.user_index.build(x.recv_ids[0], self.local_rows("user_mf"))
+                self.item_index.build(x.recv_ids[1], self.local_rows("item_mf"))
+                self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
+                return
             xu, xi = self.xu, self.xi
             # batch order -> bucket order, then all-to-all #3 to the owners
             bu = ops.gather_rows([gu], [xu.order.to(self.id_dtype)])[0]

@@ -115,6 +115,21 @@ int brShardPlanPair(const void* ids_a, const void* ids_b, int id_type, int64_t n
                     void* sorted_dest_a, void* sorted_dest_b, int32_t* order_a, int32_t* order_b, void* ws_a, void* ws_b,
                     int64_t ws_bytes, int32_t* inv_a, int32_t* inv_b, void* send_local_a, void* send_local_b,
                     int64_t* counts_a, int64_t* counts_b, brStream stream);
+/* Fixed-capacity form of that plan: every owner gets exactly `cap` slots per stream (slot d*cap + k = the k-th row for owner d in
+ * bucket order), so the three all-to-alls of a step have equal, static splits and no row count crosses to the host.
+ * send_pad[world*cap]: local row ids, pad slots hold the owner's SPARE row (local index = the owner's row count; a padded engine
+ * allocates one row more per table, its gradient is always 0); slot[n]: batch position -> slot; bpos[world*cap]: slot -> batch
+ * position or -1.  More than `cap` rows for one owner sets bit BR_ERRFLAG_CAPACITY in *err_flag (the surplus rows collide in the
+ * owner's last slot: the step's result is then wrong and the host must raise). */
+enum { BR_ERRFLAG_RANGE = 1, BR_ERRFLAG_CAPACITY = 2 };
+int brShardPadPair(const void* sorted_dest_a, const void* sorted_dest_b, const int32_t* order_a, const int32_t* order_b,
+                   const void* send_local_a, const void* send_local_b, const int64_t* counts_a, const int64_t* counts_b, int id_type,
+                   int64_t n, int world, int64_t cap, int64_t total_rows_a, int64_t total_rows_b, void* send_pad_a, void* send_pad_b,
+                   int32_t* slot_a, int32_t* slot_b, int32_t* bpos_a, int32_t* bpos_b, int* err_flag, brStream stream);
+/* dst[t] = bpos[t] >= 0 ? src[bpos[t]] : 0 (n_slots rows of dim floats; src rows at stride ld): per-pair rows -> padded send slots,
+ * for one or two sets of equal shape (set b NULL: one). */
+int brRowsToSlotsPair(const float* src_a, const float* src_b, int64_t ld, const int32_t* bpos_a, const int32_t* bpos_b, float* dst_a,
+                      float* dst_b, int64_t n_slots, int dim, brStream stream);
 /* The ordered duplicate sum and its scratch.  Every kernel that sums a segment (brSegmentSumRows, brAdamRowsSorted*,
  * brAdagradRowsSorted) takes an optional `seg_ws` of brSegmentScratchFloats(n, dim) floats (16-byte aligned):
  *   seg_ws == NULL: the segment head adds its duplicates one by one in ascending batch position = a sequential fp32
