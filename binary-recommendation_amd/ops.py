@@ -211,6 +211,18 @@ class RowIndex:
         return self
 
 
+def row_index_build_pair(idx_a: RowIndex, ids_a, upper_a: int, idx_b: RowIndex, ids_b, upper_b: int):
+    """both dedup indexes of a step in shared launches (brRowIndexBuildPair); ids of equal length and type."""
+    ta, ty = _ids(ids_a, "ids_a"); tb, tyb = _ids(ids_b, "ids_b")
+    n = ta.shape[0]
+    if ty != tyb or tb.shape[0] != n or ty != idx_a.id_type or ty != idx_b.id_type or n > min(idx_a.capacity, idx_b.capacity):
+        raise ValueError("row_index_build_pair: dtype / length / capacity mismatch")
+    idx_a.n = idx_b.n = n
+    check(_lib.load().brRowIndexBuildPair(ta.data_ptr(), int(upper_a), idx_a.sorted_ids.data_ptr(), idx_a.sorted_pos.data_ptr(), idx_a.ws.data_ptr(), idx_a.ws_bytes,
+                                          tb.data_ptr(), int(upper_b), idx_b.sorted_ids.data_ptr(), idx_b.sorted_pos.data_ptr(), idx_b.ws.data_ptr(), idx_b.ws_bytes,
+                                          ty, n, _stream()), "brRowIndexBuildPair")
+
+
 def segment_sum_rows(index: RowIndex, row_grads, dim=None, ldg=None, out=None, head_flag=None, two_level=True):
     dim = row_grads.shape[1] if dim is None else dim
     ldg = row_grads.stride(0) if ldg is None else ldg

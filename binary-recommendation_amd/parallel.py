@@ -393,6 +393,16 @@ def make_sharded_engine(base_cls):
             if self.exchange == "padded":
                 x = self.px.plan(users, items, self.err)
                 ru, ri = x.send_ids()                              # all-to-all #1
+                # the owner-side dedup indexes depend only on the ids just received: both in shared launches on a side stream,
+                # beside the lookup / MLP, joined before the Adam-rows kernels
+                main = torch.cuda.current_stream(self.device)
+                if getattr(self, "_side", None) is None:
+                    self._side, self._ev_ids, self._ev_index = torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event()
+                self._ev_ids.record(main)
+                self._side.wait_event(self._ev_ids)
+                with torch.cuda.stream(self._side):
+                    ops.row_index_build_pair(self.user_index, ru, self.local_rows("user_mf"), self.item_index, ri, self.local_rows("item_mf"))
+                    self._ev_index.record(self._side)
                 self._serve_rows("user", ru, out=x.served[0])      # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64)
                 self._serve_rows("item", ri, out=x.served[1])
                 self.r_user, self.r_item = x.return_rows()         # all-to-all #2
@@ -458,8 +468,7 @@ def make_sharded_engine(base_cls):
             if self.exchange == "padded":
                 x = self.px
                 ou, oi = x.send_row_grads(gu, gi)                  # batch order -> padded slots -> all-to-all #3
-                self.user_index.build(x.recv_ids[0], self.local_rows("user_mf"))
-                self.item_index.build(x.recv_ids[1], self.local_rows("item_mf"))
+                torch.cuda.current_stream(self.device).wait_event(self._ev_index)
                 self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
                 return
             xu, xi = self.xu, self.xi
