@@ -2,6 +2,7 @@
 // brDenseBackward in mlp.hip) and the MFMA tail (tail_mfma.hip, called from brNeumfTailFused in tail.hip).
 #pragma once
 #include "common.h"
+#include "philox.h"
 
 namespace br {
 
@@ -21,8 +22,21 @@ struct BwdArgs {
 };
 
 // dense_fwd.hip: brDropoutKeepBits for the step (resolved step counter + step_add)
+int make_keep_args(KeepArgs& a, float drop_p, uint64_t seed, uint32_t step, uint32_t step_add, int64_t row0, int64_t batch, int n_sites,
+                   const uint32_t* sites, const int* widths, uint32_t* const* out);
 int dropout_keep_bits_ahead(float drop_p, uint64_t seed, uint32_t step, uint32_t step_add, int64_t row0, int64_t batch, int n_sites,
                             const uint32_t* sites, const int* widths, uint32_t* const* out, brStream stream);
+
+// sparse_opt.hip: brAdamRowsSortedPair whose grid also fills the keep-bit planes described by *keep (NULL: plain)
+struct AdamPairCall {
+  float *table_a, *m_a, *v_a; int64_t rows_a; const void* sorted_ids_a; const int32_t* sorted_pos_a; const float* grads_a; int64_t ldg_a;
+  const float* grads_hi_a; int64_t ldg_hi_a; uint8_t* mark_a; int32_t* last_a;
+  float *table_b, *m_b, *v_b; int64_t rows_b; const void* sorted_ids_b; const int32_t* sorted_pos_b; const float* grads_b; int64_t ldg_b;
+  const float* grads_hi_b; int64_t ldg_hi_b; uint8_t* mark_b; int32_t* last_b;
+  int dim, id_type; int64_t n; int split; const float* hi_scale; const void* step_state; double alpha_t, beta1, beta2, eps;
+  float *seg_ws_a, *seg_ws_b;
+};
+int adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream);
 
 int dense_backward_fused(const BwdArgs& a, hipStream_t s);    // BR_ERR_UNSUPPORTED when the LDS image does not fit
 int dense_bwd_fused_grid(int64_t batch);                      // workgroups = slabs written

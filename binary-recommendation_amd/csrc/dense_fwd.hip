@@ -22,6 +22,7 @@
 //   (uint32 [rows][ceil(K/32)]: 2.3 MB for the three sites of the NeuMF tower at batch 65 536) instead of being
 //   regenerated inside the forward, the dx and the dW kernel of each layer (~120 VALU per 8 elements, three times).
 #include "common.h"
+#include <stdlib.h>
 #include "philox.h"
 #include "dense.h"
 
@@ -29,8 +30,6 @@ namespace br {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kFwdThreads = 1024;
-constexpr int kFwdWaves = kFwdThreads / 64;
 constexpr int kRep = BR_STAT_REPLICAS;
 
 // In-kernel stamps of the diagnostic build (tools/diag/: this file compiled with -DBR_STAMPS into a test binary of its
@@ -70,54 +69,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // ------------------------------------------------------------------------------ keep-bit planes
-struct KeepSite { uint32_t* out; int K, kw; uint32_t site; };
-struct KeepArgs {
-  KeepSite s[3];
-  int n_sites;
-  DropoutCfg drop;      // key, step (or step_ptr), threshold
-  int64_t row0, batch;
-};
-
-// one thread per (row, 32-column word): its 4 Philox calls (one per 8-column chunk) run INTERLEAVED, round by round - a
-// Philox round is two dependent 32x32->64 multiplies (v_mad_u64_u32, quarter rate), so four independent chains per lane
-// are what keeps the multiplier busy (one chain at a time behind per-chunk branches measured 9.6 us for the 128-column
-// plane of 65 536 rows) - then one coalesced store.  Chunks past K produce bits that nobody reads.
+// (KeepSite / KeepArgs / keep_bits_block: philox.h - the optimizer launch can carry the planes of the next step in its own grid)
 __global__ __launch_bounds__(256) void keep_bits_kernel(KeepArgs a) {
   dropout_resolve(a.drop);
-  const KeepSite s = blockIdx.y == 0 ? a.s[0] : (blockIdx.y == 1 ? a.s[1] : a.s[2]);    // (a runtime index would copy the struct to scratch)
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.batch * s.kw) return;
-  const int64_t r = idx / s.kw;
-  const uint32_t w = (uint32_t)(idx - r * s.kw);
-  uint32_t c0[4], c1[4], c2[4], c3[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { c0[c] = (uint32_t)(a.row0 + r); c1[c] = 4 * w + c; c2[c] = s.site; c3[c] = a.drop.step; }
-  uint32_t k0 = a.drop.k0, k1 = a.drop.k1;
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      // 32x32 -> hi / lo as v_mul_hi_u32 + v_mul_lo_u32: the 64-bit product form compiles to v_mad_u64_u32, which measured
-      // ~78 cycles per wave instruction on gfx950 (27 us for the three planes of a step)
-      const uint32_t h0 = __umulhi(0xD2511F53u, c0[c]), l0 = 0xD2511F53u * c0[c];
-      const uint32_t h1 = __umulhi(0xCD9E8D57u, c2[c]), l1 = 0xCD9E8D57u * c2[c];
-      const uint32_t n0 = h1 ^ c1[c] ^ k0, n2 = h0 ^ c3[c] ^ k1;
-      c0[c] = n0; c1[c] = l1; c2[c] = n2; c3[c] = l0;
-    }
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  const uint32_t thr = a.drop.thr;
-  uint32_t word = 0;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const uint32_t d[4] = {c0[c], c1[c], c2[c], c3[c]};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      word |= ((d[e] & 0xFFFFu) >= thr ? 1u : 0u) << (8 * c + 2 * e);
-      word |= ((d[e] >> 16) >= thr ? 1u : 0u) << (8 * c + 2 * e + 1);
-    }
-  }
-  s.out[idx] = word;
+  keep_bits_block(a, (int)blockIdx.y, (int64_t)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -226,15 +181,71 @@ __device__ __forceinline__ void fwd_epilogue(const f32x4& acc, const FwdArgs& a,
   }
 }
 
-template <int NT, int KJ, bool VEC>
-__global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs a) {
+// the same for up to 4 n-tiles at once (WPS == 2: the VGPR budget allows it): every tile has its own patch, so the 16 activations,
+// the patch writes, the patch reads and the stores of a pass each go out back to back instead of tile by tile
+template <bool VEC, int WN, int NT>
+__device__ __forceinline__ void fwd_epilogue_multi(const f32x4 (&acc)[4], const FwdArgs& a, float* patch4, float* yrow, int64_t rbase, int nt0, int c16, int g,
+                                                   const int (&vmask)[4], bool row_ok, const float* bs, int sigmask, float floor_, float (&ssum)[NT], float (&ssq)[NT]) {
+#pragma unroll
+  for (int w = 0; w < WN; ++w) {
+    const int nt = nt0 + w, n = nt * 16 + c16;
+    const bool last = nt * 16 + 16 > a.N;
+    const int cmask = (!last || n < a.N) ? -1 : 0;
+    const float bv = bs[n];
+    float* patch = patch4 + w * 16 * kPatchLd;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float z = fmaf(acc[w][r], a.inv_keep, bv);
+      if (a.yin) z += a.yin[(rbase + (vmask[r] ? 4 * g + r : 0)) * a.ldy + (cmask ? n : 0)];      // wave-uniform: split-K second half
+      const float v = __int_as_float(__float_as_int(act_fwd(z, sigmask, floor_)) & vmask[r] & cmask);
+      ssum[nt] += v;
+      ssq[nt] = fmaf(v, v, ssq[nt]);
+      patch[(4 * g + r) * kPatchLd + c16] = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // (named values, not an array: hipcc kept a float4 o[WN] behind the lane-conditional stores in scratch)
+  const float* pr = patch4 + c16 * kPatchLd + 4 * g;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 o0 = *reinterpret_cast<const float4*>(pr);
+  const float4 o1 = WN > 1 ? *reinterpret_cast<const float4*>(pr + 1 * 16 * kPatchLd) : z4;
+  const float4 o2 = WN > 2 ? *reinterpret_cast<const float4*>(pr + 2 * 16 * kPatchLd) : z4;
+  const float4 o3 = WN > 3 ? *reinterpret_cast<const float4*>(pr + 3 * 16 * kPatchLd) : z4;
+  auto put = [&](const float4& o, int w) {
+    const int nt = nt0 + w, n0 = nt * 16 + 4 * g;
+    float* dst = yrow + nt * 16;
+    if (VEC) {                                              // rows are padded to 4 floats: a group that starts inside N is stored whole
+      if (n0 < a.N) *reinterpret_cast<float4*>(dst) = o;
+    } else {
+      if (n0 + 0 < a.N) dst[0] = o.x;
+      if (n0 + 1 < a.N) dst[1] = o.y;
+      if (n0 + 2 < a.N) dst[2] = o.z;
+      if (n0 + 3 < a.N) dst[3] = o.w;
+    }
+  };
+  if (row_ok) {
+    put(o0, 0);
+    if (WN > 1) put(o1, 1);
+    if (WN > 2) put(o2, 2);
+    if (WN > 3) put(o3, 3);
+  }
+}
+
+// WPS = waves per SIMD: 4 (one 16-row tile per wave at batch 65 536: every wave of the chip loads, multiplies and stores at the
+// same time, the matrix pipe idles through the two memory phases) or 2 (half the waves, two tiles each, the second tile's loads
+// issued before the first tile's MFMA passes and the first tile's stores behind them: the memory phases of one tile overlap the
+// MFMA phase of the other)
+template <int NT, int KJ, bool VEC, int WPS>
+__global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kFwdThreads = 256 * WPS, kFwdWaves = 4 * WPS;
   constexpr int Np = NT * 16, Kp = KJ * 16, KWJ = (KJ + 1) / 2;
   float* Ws = smem;                                     // [KJ][4][Np][4]
   float* ssb = Ws + Kp * Np;                            // [scale Kp | shift Kp]
   float* bs = ssb + 2 * Kp;                             // [bias Np]
   float* patches = bs + Np;                             // [waves][16][kPatchLd]
-  float* redw = patches + kFwdWaves * 16 * kPatchLd;    // [waves][2][Np] per-wave column sums
+  constexpr int kPatchesPerWave = WPS == 2 ? 4 : 1;
+  float* redw = patches + kFwdWaves * kPatchesPerWave * 16 * kPatchLd;    // [waves][2][Np] per-wave column sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const int K = a.K, N = a.N;
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs
     const int slot = __builtin_amdgcn_readfirstlane(wave >> 2);
     if (slot == 0) __builtin_amdgcn_s_setprio(3);
     else if (slot == 1) __builtin_amdgcn_s_setprio(2);
-    else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+    else if (slot == 2) __builtin_amdgcn_s_setprio(1);     // (WPS == 2: slots 0 and 1 only)
   }
 
   BR_STAMP_DECL;
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs
   __syncthreads();
   BR_STAMP(3);
 
-  float* patch = patches + wave * 16 * kPatchLd;
+  float* patch = patches + wave * kPatchesPerWave * 16 * kPatchLd;
   float ssum[NT], ssq[NT];             // this lane's column sums of y, y^2 (column nt*16+c16, its 4 rows of every tile)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
@@ -345,6 +356,11 @@ __global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs
     for (int r = 0; r < 4; ++r) vmask[r] = (4 * g + r < rows_left16) ? -1 : 0;
     const bool row_ok = c16 < rows_left16;
     float* yrow = a.y + (rbase + (row_ok ? c16 : 0)) * a.ldy + 4 * g;      // row layout: &y[rbase + c16][4g]
+    // WPS == 2: the next tile's operands are requested now and fly during this tile's MFMA passes and epilogue
+    float4 avn[WPS == 2 ? KJ : 1];
+    uint32_t kbn[WPS == 2 ? KWJ : 1];
+    const bool has_next = tile + tstride < n_tiles;                        // wave-uniform
+    if (WPS == 2 && has_next) fwd_load_tile<KJ, VEC>(reinterpret_cast<float4 (&)[KJ]>(avn), reinterpret_cast<uint32_t (&)[KWJ]>(kbn), a, tile + tstride, c16, g);
     // ---- MFMA in passes of <= 4 n-tiles: 4 independent accumulator chains, each revisited every 4th MFMA ----
 #pragma unroll
     for (int nt0 = 0; nt0 < NT; nt0 += 4) {
@@ -373,18 +389,31 @@ __global__ __launch_bounds__(kFwdThreads, 4) void dense_fwd_kernel(const FwdArgs
         __builtin_amdgcn_sched_barrier(0);
       }
       BR_STAMP(5 + 2 * (nt0 / 4));       // pass MFMAs issued
+      if (WPS == 2) {
+        if (Wn == 4) fwd_epilogue_multi<VEC, 4, NT>(acc, a, patch, yrow, rbase, nt0, c16, g, vmask, row_ok, bs, sigmask, floor_, ssum, ssq);
+        else if (Wn == 3) fwd_epilogue_multi<VEC, 3, NT>(acc, a, patch, yrow, rbase, nt0, c16, g, vmask, row_ok, bs, sigmask, floor_, ssum, ssq);
+        else if (Wn == 2) fwd_epilogue_multi<VEC, 2, NT>(acc, a, patch, yrow, rbase, nt0, c16, g, vmask, row_ok, bs, sigmask, floor_, ssum, ssq);
+        else fwd_epilogue_multi<VEC, 1, NT>(acc, a, patch, yrow, rbase, nt0, c16, g, vmask, row_ok, bs, sigmask, floor_, ssum, ssq);
+      } else
 #pragma unroll
       for (int w = 0; w < WMAX; ++w) {
         if (w < Wn) {
           const float bv = bs[(nt0 + w) * 16 + c16];
           fwd_epilogue<VEC>(acc[w], a, patch, yrow, rbase, nt0 + w, c16, g, vmask, row_ok, bv, sigmask, floor_, ssum[nt0 + w], ssq[nt0 + w]);
-          __builtin_amdgcn_sched_barrier(0);      // one n-tile at a time: interleaved, the four epilogues' temporaries spill
+          if (WPS == 4) __builtin_amdgcn_sched_barrier(0);      // one n-tile at a time: interleaved, the four epilogues' temporaries spill at 128 VGPRs
         }
       }
       BR_STAMP(6 + 2 * (nt0 / 4));       // pass epilogue issued
     }
     tile += tstride;
-    if (tile < n_tiles) fwd_load_tile<KJ, VEC>(av, kb, a, tile, c16, g);
+    if (WPS == 2) {
+      if (has_next) {
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) av[j] = avn[j];
+#pragma unroll
+        for (int w = 0; w < KWJ; ++w) kb[w] = kbn[w];
+      }
+    } else if (tile < n_tiles) fwd_load_tile<KJ, VEC>(av, kb, a, tile, c16, g);
   }
 
   if (a.stats) {      // lane -> wave (the 4 row groups) -> per-wave LDS partials -> workgroup sum in double -> one global atomic per column
@@ -427,55 +456,77 @@ extern "C" int brDropoutKeepBits(float drop_p, uint64_t seed, uint32_t step, int
 }
 
 // step_add: masks of step (resolved counter + step_add) - the step driver prefetches the next step's planes
-int br::dropout_keep_bits_ahead(float drop_p, uint64_t seed, uint32_t step, uint32_t step_add, int64_t row0, int64_t batch, int n_sites,
-                                const uint32_t* sites, const int* widths, uint32_t* const* out, brStream stream) {
+int br::make_keep_args(KeepArgs& a, float drop_p, uint64_t seed, uint32_t step, uint32_t step_add, int64_t row0, int64_t batch, int n_sites,
+                       const uint32_t* sites, const int* widths, uint32_t* const* out) {
   BR_CHECK_ARG(n_sites >= 1 && n_sites <= 3 && sites && widths && out && batch >= 0, "brDropoutKeepBits: bad args (1..3 sites)");
   BR_CHECK_ARG(drop_p > 0.f && drop_p < 1.f, "brDropoutKeepBits: drop_p must be in (0,1)");
-  if (batch == 0) return BR_OK;
-  KeepArgs a;
   a.n_sites = n_sites;
-  int kwmax = 0;
   for (int i = 0; i < 3; ++i) {
     const int j = i < n_sites ? i : 0;
     BR_CHECK_ARG(widths[j] >= 1 && out[j], "brDropoutKeepBits: bad site %d", j);
     a.s[i].out = out[j]; a.s[i].K = widths[j]; a.s[i].kw = (widths[j] + 31) / 32; a.s[i].site = sites[j];
-    if (a.s[i].kw > kwmax) kwmax = a.s[i].kw;
   }
   a.drop = make_dropout(drop_p, seed, step, 0);
   if (const StepStateDev* ss = current_step_state()) a.drop.step_ptr = &ss->step;
   a.drop.step_add = step_add;
   a.row0 = row0; a.batch = batch;
+  return BR_OK;
+}
+
+int br::dropout_keep_bits_ahead(float drop_p, uint64_t seed, uint32_t step, uint32_t step_add, int64_t row0, int64_t batch, int n_sites,
+                                const uint32_t* sites, const int* widths, uint32_t* const* out, brStream stream) {
+  KeepArgs a;
+  const int rc = make_keep_args(a, drop_p, seed, step, step_add, row0, batch, n_sites, sites, widths, out);
+  if (rc != BR_OK) return rc;
+  if (batch == 0) return BR_OK;
+  int kwmax = 0;
+  for (int i = 0; i < n_sites; ++i) kwmax = a.s[i].kw > kwmax ? a.s[i].kw : kwmax;
   const dim3 grid((unsigned)ceil_div(batch * kwmax, 256), (unsigned)n_sites);
   keep_bits_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   BR_CHECK_LAUNCH("brDropoutKeepBits");
   return BR_OK;
 }
 
-template <int NT, int KJ, bool VEC>
+template <int NT, int KJ, bool VEC, int WPS>
 static void launch_fwd_v(unsigned grid, size_t shmem, hipStream_t s, const FwdArgs& a) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ, VEC, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     attr_set = true;
   }
-  dense_fwd_kernel<NT, KJ, VEC><<<grid, kFwdThreads, shmem, s>>>(a);
+  dense_fwd_kernel<NT, KJ, VEC, WPS><<<grid, 256 * WPS, shmem, s>>>(a);
 }
+// waves per SIMD of a forward launch: 2 (two tiles per wave, software-pipelined) once every wave of a one-workgroup-per-CU grid would
+// get two tiles anyway, else 4 (one tile per wave, more waves to hide latency); BR_FWD_WPS=2|4 forces one (experiments)
+static int fwd_wps(int64_t batch, bool vec, int KJ) {
+  static const int forced = [] { const char* e = getenv("BR_FWD_WPS"); return e ? atoi(e) : 0; }();
+  if (!vec) return 4;
+  if (forced == 2 || forced == 4) return forced;
+  // measured at batch 65 536: 128 x 100 36.2 -> 33.8 us with two pipelined tiles per wave, 100 x 50 23.0 -> 23.9 us (its loads are
+  // short: the extra waves hide more than the prefetch does)
+  return (KJ >= 8 && ceil_div(batch, (int64_t)16) >= (int64_t)2 * 256 * 8) ? 2 : 4;
+}
+
 template <int NT, int KJ>
-static void launch_fwd(unsigned grid, size_t shmem, hipStream_t s, const FwdArgs& a) {
+static void launch_fwd(size_t shmem_words_fixed, int Np, hipStream_t s, const FwdArgs& a) {
   // VEC: 16-B accesses on both sides: x rows / y rows 16-B aligned with row strides that are multiples of 4 floats (rows of K
   // or N floats are then padded to 4, and a 16-B access that starts inside a row stays inside its allocation)
   const bool vec = (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
                    (a.yin == nullptr || a.K % 4 == 0);
-  if (vec) launch_fwd_v<NT, KJ, true>(grid, shmem, s, a);
-  else launch_fwd_v<NT, KJ, false>(grid, shmem, s, a);
+  const int wps = fwd_wps(a.batch, vec, KJ);
+  const int waves = 4 * wps;
+  const size_t shmem = (shmem_words_fixed + (size_t)waves * (wps == 2 ? 4 : 1) * 16 * kPatchLd + (size_t)waves * 2 * Np) * sizeof(float);
+  const int64_t wgs = ceil_div(ceil_div(a.batch, (int64_t)16), (int64_t)waves);
+  const unsigned grid = (unsigned)(wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs));      // one workgroup per CU
+  if (vec && wps == 2) launch_fwd_v<NT, KJ, true, 2>(grid, shmem, s, a);
+  else if (vec) launch_fwd_v<NT, KJ, true, 4>(grid, shmem, s, a);
+  else launch_fwd_v<NT, KJ, false, 4>(grid, shmem, s, a);
 }
 
 static int dense_forward_one(FwdArgs a, hipStream_t s) {
   const int NT = tiles16(a.N), KJ = tiles16(a.K), Kp = KJ * 16, Np = NT * 16;
-  const size_t shmem = ((size_t)Kp * Np + 2 * (size_t)Kp + (size_t)Np + (size_t)kFwdWaves * 16 * kPatchLd + (size_t)kFwdWaves * 2 * Np) * sizeof(float);
-  int64_t wgs = ceil_div(ceil_div(a.batch, 16), kFwdWaves);
-  const unsigned grid = (unsigned)(wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs));      // one workgroup per CU
-#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(grid, shmem, s, a); break;
+  const size_t fixed = (size_t)Kp * Np + 2 * (size_t)Kp + (size_t)Np;           // W image, affine, bias (floats); + per-wave patches / sums
+#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(fixed, Np, s, a); break;
 #define BR_FWD(NTv)                                                                                        \
   case NTv:                                                                                                \
     switch (KJ) { BR_FWD_KJ(NTv, 1) BR_FWD_KJ(NTv, 2) BR_FWD_KJ(NTv, 3) BR_FWD_KJ(NTv, 4) BR_FWD_KJ(NTv, 5) \

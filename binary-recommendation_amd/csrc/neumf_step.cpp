@@ -271,20 +271,29 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     (void)hipStreamWaitEvent(hs, g_join, 0);
     joined = true;
   }
-  // next step's dropout planes on the aux stream beside the Adam-rows kernel (the planes' last readers - this step's backward -
-  // are behind us on the launch stream; the dedup sorts on the aux stream were joined above)
-  const bool prefetch = train && p > 0.f && s->keep_prefetch && s->aux_stream && (ph & BR_PH_ROWS_USER);
-  if (prefetch) {
-    if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
-    hipStream_t as = (hipStream_t)s->aux_stream;
-    (void)hipEventRecord(g_kfork, hs);
-    (void)hipStreamWaitEvent(as, g_kfork, 0);
+  // next step's dropout planes beside the Adam-rows kernel (Philox is ALU-bound, the optimizer HBM-bound; the planes' last readers -
+  // this step's backward - are behind us on the launch stream): inside the pair launch's own grid when there is one, else as a
+  // launch on the aux stream (the dedup sorts there were joined above)
+  const bool prefetch = train && p > 0.f && s->keep_prefetch && (ph & BR_PH_ROWS_USER);
+  const bool prefetch_fused = prefetch && (ph & BR_PH_ROWS_ITEM);
+  const bool prefetch_aux = prefetch && !prefetch_fused && s->aux_stream;
+  br::KeepArgs next_keep;
+  if (prefetch_fused || prefetch_aux) {
     const uint32_t sites[3] = {0, 1, 2};
     const int widths[3] = {2 * D, n1, n2};
     uint32_t* const outs[3] = {keep0, keep1, keep2};
-    const int rc = br::dropout_keep_bits_ahead(p, s->seed, (uint32_t)s->step, 1, s->row0, krows, 3, sites, widths, outs, s->aux_stream);
-    if (rc != BR_OK) return rc;
-    (void)hipEventRecord(g_kjoin, as);
+    if (prefetch_fused) {
+      const int rc = br::make_keep_args(next_keep, p, s->seed, (uint32_t)s->step, 1, s->row0, krows, 3, sites, widths, outs);
+      if (rc != BR_OK) return rc;
+    } else {
+      if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
+      hipStream_t as = (hipStream_t)s->aux_stream;
+      (void)hipEventRecord(g_kfork, hs);
+      (void)hipStreamWaitEvent(as, g_kfork, 0);
+      const int rc = br::dropout_keep_bits_ahead(p, s->seed, (uint32_t)s->step, 1, s->row0, krows, 3, sites, widths, outs, s->aux_stream);
+      if (rc != BR_OK) return rc;
+      (void)hipEventRecord(g_kjoin, as);
+    }
   }
   {
     uint8_t* um = s->adam_dense == 1 ? s->user_mark : nullptr;
@@ -294,12 +303,13 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       // the two fused tables in one launch (they share dim, batch, split): the sweeps of adam_dense == 1 follow.
       // deferred + EMBED: g_user / g_item still hold the stashed MF rows, so each table reads the PARTNER's stash times ddot
       const bool fuse_mf = deferred && (ph & BR_PH_EMBED) && (ph & BR_PH_OPT_TABLES);
-      RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedPair(
-              s->user_tab, s->user_m, s->user_v, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->dx0 + uoff, 2 * D, (fuse_mf ? s->g_item : s->g_user) + D, 2 * D, um,
-              deferred ? s->user_last : nullptr,
-              s->item_tab, s->item_m, s->item_v, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->dx0 + ioff, 2 * D, (fuse_mf ? s->g_user : s->g_item) + D, 2 * D, im,
-              deferred ? s->item_last : nullptr, 2 * D, s->id_type, B, D, fuse_mf ? s->ddot : nullptr, s->step_state, s->alpha_t, s->beta1, s->beta2, s->adam_eps,
-              s->u_seg_ws, s->i_seg_ws, stream));
+      const br::AdamPairCall pc{
+          s->user_tab, s->user_m, s->user_v, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->dx0 + uoff, 2 * D, (fuse_mf ? s->g_item : s->g_user) + D, 2 * D, um,
+          deferred ? s->user_last : nullptr,
+          s->item_tab, s->item_m, s->item_v, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->dx0 + ioff, 2 * D, (fuse_mf ? s->g_user : s->g_item) + D, 2 * D, im,
+          deferred ? s->item_last : nullptr, 2 * D, s->id_type, B, D, fuse_mf ? s->ddot : nullptr, s->step_state, s->alpha_t, s->beta1, s->beta2, s->adam_eps,
+          s->u_seg_ws, s->i_seg_ws};
+      RUN(BR_TAG_ADAM_ROWS_USER, br::adam_rows_pair_keep(pc, prefetch_fused ? &next_keep : nullptr, stream));
     } else if ((ph & BR_PH_ROWS_USER) && deferred) {
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type,
                            s->u_sorted_pos, B, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, s->u_seg_ws, stream));
@@ -320,7 +330,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     if ((ph & BR_PH_SWEEP_ITEM) && s->adam_dense == 1)
       RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
   }
-  if (prefetch) (void)hipStreamWaitEvent(hs, g_kjoin, 0);
+  if (prefetch_aux) (void)hipStreamWaitEvent(hs, g_kjoin, 0);
   if ((ph & BR_PH_OPT_DENSE) && fused_final) {
     const float* const rs[3] = {slabs1, slabs2, slabs_t};
     const int rn[3] = {sp.ns1, sp.ns2, sp.ns_t};

@@ -91,4 +91,66 @@ __device__ __forceinline__ float dropout_scale1(const DropoutCfg& c, int64_t r, 
   return ((dropout_keep8(c, r, col >> 3) >> (col & 7u)) & 1u) ? c.inv_keep : 0.0f;
 }
 
+
+// ---- keep-bit planes (dropout masks materialised once per (step, site): uint32 [rows][ceil(K/32)], bit c of row r) ----
+struct KeepSite { uint32_t* out; int K, kw; uint32_t site; };
+struct KeepArgs {
+  KeepSite s[3];
+  int n_sites;
+  DropoutCfg drop;      // key, step (or step_ptr) (+ step_add), threshold
+  int64_t row0, batch;
+};
+// the planes as extra workgroups of another kernel's grid (horizontal fusion): workgroups [0, blocks[0]) fill site 0, the next
+// blocks[1] site 1, ...; total == 0: nothing fused
+struct KeepFuse { KeepArgs a; int blocks[3]; int total; };
+
+// one thread per (row, 32-column word) of site `si` (256 threads per block): its 4 Philox calls (one per 8-column chunk) run
+// INTERLEAVED, round by round - a Philox round is two dependent 32x32->64 multiplies, so four independent chains per lane are
+// what keeps the multiplier busy (one chain at a time behind per-chunk branches measured 9.6 us for the 128-column plane of
+// 65 536 rows) - then one coalesced store.  Chunks past K produce bits that nobody reads.  `a.drop` must be resolved.
+__device__ __forceinline__ void keep_bits_block(const KeepArgs& a, int si, int64_t block) {
+  const KeepSite s = si == 0 ? a.s[0] : (si == 1 ? a.s[1] : a.s[2]);    // (a runtime index would copy the struct to scratch)
+  const int64_t idx = block * 256 + threadIdx.x;
+  if (idx >= a.batch * s.kw) return;
+  const int64_t r = idx / s.kw;
+  const uint32_t w = (uint32_t)(idx - r * s.kw);
+  uint32_t c0[4], c1[4], c2[4], c3[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { c0[c] = (uint32_t)(a.row0 + r); c1[c] = 4 * w + c; c2[c] = s.site; c3[c] = a.drop.step; }
+  uint32_t k0 = a.drop.k0, k1 = a.drop.k1;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // 32x32 -> hi / lo as v_mul_hi_u32 + v_mul_lo_u32: the 64-bit product form compiles to v_mad_u64_u32, which measured
+      // ~78 cycles per wave instruction on gfx950
+      const uint32_t h0 = __umulhi(0xD2511F53u, c0[c]), l0 = 0xD2511F53u * c0[c];
+      const uint32_t h1 = __umulhi(0xCD9E8D57u, c2[c]), l1 = 0xCD9E8D57u * c2[c];
+      const uint32_t n0 = h1 ^ c1[c] ^ k0, n2 = h0 ^ c3[c] ^ k1;
+      c0[c] = n0; c1[c] = l1; c2[c] = n2; c3[c] = l0;
+    }
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const uint32_t thr = a.drop.thr;
+  uint32_t word = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t d[4] = {c0[c], c1[c], c2[c], c3[c]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      word |= ((d[e] & 0xFFFFu) >= thr ? 1u : 0u) << (8 * c + 2 * e);
+      word |= ((d[e] >> 16) >= thr ? 1u : 0u) << (8 * c + 2 * e + 1);
+    }
+  }
+  s.out[idx] = word;
+}
+
+// a fused grid's workgroup `wg` (0 <= wg < f.total): which site / which block of it
+__device__ __forceinline__ void keep_fuse_block(KeepFuse f, int64_t wg) {
+  dropout_resolve(f.a.drop);
+  if (wg < f.blocks[0]) keep_bits_block(f.a, 0, wg);
+  else if (wg < f.blocks[0] + f.blocks[1]) keep_bits_block(f.a, 1, wg - f.blocks[0]);
+  else keep_bits_block(f.a, 2, wg - f.blocks[0] - f.blocks[1]);
+}
+
 }  // namespace br

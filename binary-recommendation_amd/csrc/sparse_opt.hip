@@ -10,6 +10,7 @@
 #include "common.h"
 #include "rows.h"
 #include "adam_math.h"
+#include "dense.h"
 
 #include <algorithm>
 #include <math.h>
@@ -148,7 +149,22 @@ struct AdamRowsJobs { AdamRowsJob j[2]; };
 
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs, int dim, int chunks, int lpr_log2, int64_t n, int split,
-                                                                AdamHp h, const StepStateDev* __restrict__ ss) {
+                                                                AdamHp h, const StepStateDev* __restrict__ ss, const KeepFuse kf, int keep_x) {
+  // keep_x columns of the grid fill the next step's dropout planes (ALU-bound Philox beside this HBM-bound kernel:
+  // no fork / join around a launch of its own, which costs ~10 us each inside a hipGraph)
+  // every P-th column of the grid (P = columns / keep_x) is a plane column, so the two kinds of work share the CUs from start to end
+  int64_t bx = blockIdx.x;
+  if (keep_x > 0) {
+    const int P = (int)gridDim.x / keep_x;
+    const int q = (int)blockIdx.x / P;
+    if ((int)blockIdx.x - q * P == 0 && q < keep_x) {
+      const int64_t wg = (int64_t)q * gridDim.y + blockIdx.y;
+      if (wg < kf.total) keep_fuse_block(kf, wg);
+      return;
+    }
+    const int before = ((int)blockIdx.x + P - 1) / P;          // plane columns left of this one
+    bx -= before < keep_x ? before : keep_x;
+  }
   const AdamRowsJob& jb = jobs.j[blockIdx.y];
   float* __restrict__ table = jb.table; float* __restrict__ M = jb.M; float* __restrict__ Vv = jb.Vv;
   const int64_t table_rows = jb.table_rows;
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs
   if (last) stage_alpha_ring(ring, ss);      // uniform branch: whole workgroup
   adam_resolve(h);
   const int lpr = 1 << lpr_log2;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tid = bx * blockDim.x + threadIdx.x;
   const int64_t i = tid >> lpr_log2;
   const int lir = (int)(tid & (lpr - 1));
   if (i >= n) return;
@@ -614,7 +630,7 @@ struct AdamRowsArgs {      // one table's host-side arguments
 };
 
 static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_type, int64_t n, int split, double alpha_t, double beta1,
-                            double beta2, double eps, const StepStateDev* ss, brStream stream) {
+                            double beta2, double eps, const StepStateDev* ss, brStream stream, const KeepArgs* keep = nullptr) {
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdamRowsSorted: bad id_type");
   if (n == 0) return BR_OK;
   AdamRowsJobs jobs;
@@ -645,14 +661,24 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     if (rc != BR_OK) return rc;
     probe_split(BR_TAG_SEG_PARTIALS, (hipStream_t)stream);
   }
-  const dim3 grid((unsigned)ceil_div(n, 256 >> g.lpr_log2), (unsigned)n_jobs);
+  KeepFuse kf;
+  kf.total = 0; kf.blocks[0] = kf.blocks[1] = kf.blocks[2] = 0;
+  int keep_x = 0;
+  if (keep && keep->batch > 0) {
+    kf.a = *keep;
+    for (int i = 0; i < keep->n_sites; ++i) { kf.blocks[i] = (int)ceil_div(keep->batch * keep->s[i].kw, (int64_t)256); kf.total += kf.blocks[i]; }
+    keep_x = (int)ceil_div((int64_t)kf.total, (int64_t)n_jobs);
+  } else {
+    kf.a = KeepArgs{};
+  }
+  const dim3 grid((unsigned)(ceil_div(n, 256 >> g.lpr_log2) + keep_x), (unsigned)n_jobs);
   AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
   if (ss) h.alpha_ptr = &ss->alpha_t;
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32)
-    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(jobs, dim, g.chunks, g.lpr_log2, n, split, h, ss)));
+    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(jobs, dim, g.chunks, g.lpr_log2, n, split, h, ss, kf, keep_x)));
   else
-    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(jobs, dim, g.chunks, g.lpr_log2, n, split, h, ss)));
+    BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(jobs, dim, g.chunks, g.lpr_log2, n, split, h, ss, kf, keep_x)));
   BR_CHECK_LAUNCH("brAdamRowsSorted");
   return BR_OK;
 }
@@ -686,6 +712,14 @@ extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int6
   const AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, mark_a, last_a, seg_ws_a, hi_scale},
                              {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, mark_b, last_b, seg_ws_b, hi_scale}};
   return adam_rows_launch(a, 2, dim, id_type, n, split, alpha_t, beta1, beta2, eps, last_a ? (const StepStateDev*)step_state : nullptr, stream);
+}
+
+int br::adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream) {
+  BR_CHECK_ARG((c.last_a == nullptr) == (c.last_b == nullptr) && (c.last_a == nullptr || c.step_state), "brAdamRowsSortedPair: last arrays for both tables (with step_state) or neither");
+  BR_CHECK_ARG(c.grads_hi_a && c.grads_hi_b, "brAdamRowsSortedPair: both gradient halves required");
+  const AdamRowsArgs a[2] = {{c.table_a, c.m_a, c.v_a, c.rows_a, c.sorted_ids_a, c.sorted_pos_a, c.grads_a, c.ldg_a, c.grads_hi_a, c.ldg_hi_a, c.mark_a, c.last_a, c.seg_ws_a, c.hi_scale},
+                             {c.table_b, c.m_b, c.v_b, c.rows_b, c.sorted_ids_b, c.sorted_pos_b, c.grads_b, c.ldg_b, c.grads_hi_b, c.ldg_hi_b, c.mark_b, c.last_b, c.seg_ws_b, c.hi_scale}};
+  return adam_rows_launch(a, 2, c.dim, c.id_type, c.n, c.split, c.alpha_t, c.beta1, c.beta2, c.eps, c.last_a ? (const StepStateDev*)c.step_state : nullptr, stream, keep);
 }
 
 extern "C" int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,

@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   for (auto& v : hh) v = 0.1f * nd(rng);
   float *x, *W, *b, *y, *sc, *sh; uint32_t* keep; double* stats; unsigned long long* st;
   const int64_t nwaves = ((B + 15) / 16 + 7) / 8 * 8;
-  CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&b, N * 4)); CK(hipMalloc(&y, (size_t)B * N * 4));
+  CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&b, N * 4)); CK(hipMalloc(&y, (size_t)B * ((N + 3) & ~3) * 4));
   CK(hipMalloc(&sc, K * 4)); CK(hipMalloc(&sh, K * 4)); CK(hipMalloc(&keep, (size_t)brDropoutKeepWords(B, K) * 4));
   CK(hipMalloc(&stats, 8 * 2 * N * 8)); CK(hipMalloc(&st, (size_t)nwaves * br::kStampSlots * 8));
   CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
@@ -41,10 +41,10 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   // warm the clocks with back-to-back launches, then time and keep the LAST launch's stamps
   const int iters = 200;
-  for (int i = 0; i < 20; ++i) brDenseForward(x, K, W, b, y, N, B, K, N, act, sc, sh, drop, drop > 0.f ? keep : nullptr, stats, nullptr);
+  for (int i = 0; i < 20; ++i) brDenseForward(x, K, W, b, y, (N + 3) & ~3, B, K, N, act, sc, sh, nullptr, drop, drop > 0.f ? keep : nullptr, stats, nullptr);
   CK(hipEventRecord(e0, nullptr));
   for (int i = 0; i < iters; ++i)
-    if (brDenseForward(x, K, W, b, y, N, B, K, N, act, sc, sh, drop, drop > 0.f ? keep : nullptr, stats, nullptr) != 0) { printf("%s\n", brGetLastError()); return 1; }
+    if (brDenseForward(x, K, W, b, y, (N + 3) & ~3, B, K, N, act, sc, sh, nullptr, drop, drop > 0.f ? keep : nullptr, stats, nullptr) != 0) { printf("%s\n", brGetLastError()); return 1; }
   CK(hipEventRecord(e1, nullptr)); CK(hipDeviceSynchronize());
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("{\"K\": %d, \"N\": %d, \"batch\": %lld, \"act\": %d, \"drop\": %.2f, \"us_per_launch\": %.2f,\n", K, N, (long long)B, act, drop, ms * 1e3 / iters);
