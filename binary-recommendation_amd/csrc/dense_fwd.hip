@@ -122,11 +122,8 @@ __device__ __forceinline__ void fwd_load_tile(float4 (&av)[KJ], uint32_t (&kb)[(
 #pragma unroll
     for (int j = 0; j < KJ - 1; ++j) av[j] = *reinterpret_cast<const float4*>(p + 16 * j);
     av[KJ - 1] = *reinterpret_cast<const float4*>(klast < a.K ? p + 16 * (KJ - 1) : p - 4 * g);
-    if (a.K & 3) {         // wave-uniform: the last 16-B group may straddle K (padded rows): what it read past K must not be NaN
-      if (klast + 1 >= a.K) av[KJ - 1].y = 0.f;
-      if (klast + 2 >= a.K) av[KJ - 1].z = 0.f;
-      if (klast + 3 >= a.K) av[KJ - 1].w = 0.f;
-    }
+    // (a last 16-B group that straddles K is cleaned in T(): touching the loaded values here made hipcc wait for every A load
+    //  before it issued the W image's loads)
   } else {
 #pragma unroll
     for (int j = 0; j < KJ - 1; ++j) av[j] = make_float4(p[16 * j], p[16 * j + 1], p[16 * j + 2], p[16 * j + 3]);
@@ -334,6 +331,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
     // ---- T(): BN affine + dropout keep bits, in registers (fenced per 16-column block: left alone the compiler hoists every
     //      block's scale / shift reads and spills) ----
     const bool affine = a.scale || a.bn.stats || 16 * KJ != K;      // the affine also zeroes the columns >= K of the last block
+    if (VEC && (K & 3)) {      // wave-uniform: the last 16-B group may straddle K (padded rows): what it read past K must not be NaN
+      const int klast = 16 * (KJ - 1) + 4 * g;
+      if (klast + 1 >= K) av[KJ - 1].y = 0.f;
+      if (klast + 2 >= K) av[KJ - 1].z = 0.f;
+      if (klast + 3 >= K) av[KJ - 1].w = 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
       if (affine) {
