@@ -57,7 +57,7 @@ struct TailMArgs {
   float *a3, *logit, *prob, *ddot, *gh2;
   int64_t ldgh2;
   double *msums, *bn_sums;
-  float* slabs;
+  float* slabs; int n_slabs;      // slabs beyond the grid are zero-filled by the kernel
 };
 int tail_mfma_grid(int64_t batch);
 void launch_tail_mfma(const TailMArgs& a, int grid, hipStream_t s);

@@ -307,11 +307,7 @@ extern "C" int brNeumfTailFused(const float* a2, int64_t lda2, const float* W3, 
     m.a3 = a3; m.logit = logit; m.prob = prob; m.ddot = ddot; m.gh2 = gh2; m.ldgh2 = ldgh2; m.msums = sums; m.bn_sums = bn_sums; m.slabs = slabs;
     int grid = tail_mfma_grid(batch);
     if (grid > n_slabs) grid = n_slabs;
-    if (grid < n_slabs) {     // the slab count is sized for the 128-row workgroups of the VALU form: unused slabs must read as zeros
-      const int64_t el = brNeumfTailSlabElems(n2, n3);
-      hipError_t e = hipMemsetAsync(slabs + (int64_t)grid * el, 0, sizeof(float) * (size_t)(n_slabs - grid) * (size_t)el, s);
-      if (e != hipSuccess) { set_error("brNeumfTailFused: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
-    }
+    m.n_slabs = n_slabs;
     launch_tail_mfma(m, grid, s);
     BR_CHECK_LAUNCH("brNeumfTailFused(mfma)");
     return BR_OK;

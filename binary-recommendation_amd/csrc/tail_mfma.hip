@@ -35,6 +35,40 @@ __device__ __forceinline__ float keep_bit_t(float x, uint32_t w, uint32_t pos) {
   return __int_as_float(__float_as_int(x) & __builtin_amdgcn_sbfe((int)w, pos, 1u));
 }
 
+// one tile's operands: a2 in the A layout (row c16), raw a2 + keep words + dot / labels of the C-layout rows 4g..4g+3.
+// Issued for the wave's first tile BEFORE the staging (BatchNorm finalize, W images, barrier) so that the tile's HBM latency runs
+// beside the staging's two memory round trips instead of behind them.
+struct TailTile {
+  float4 av[kTmKT];
+  uint32_t ka[2];
+  float xr[4][kTmKT], dv[4], yv[4];
+  uint32_t kc[4][2];
+  int vm[4];
+};
+__device__ __forceinline__ void tail_load_tile(TailTile& t, const TailMArgs& a, int64_t tile, int c16, int g) {
+  const int64_t batch = a.batch, rbase = tile << 4;
+  const int n2 = a.n2;
+  const int64_t arow = rbase + c16 < batch ? rbase + c16 : batch - 1;
+  const float* pa = a.a2 + arow * a.lda2 + 4 * g;
+#pragma unroll
+  for (int j = 0; j < kTmKT; ++j) t.av[j] = *reinterpret_cast<const float4*>(16 * j + 4 * g < n2 ? pa + 16 * j : pa - 4 * g);
+  t.ka[0] = t.ka[1] = 0xFFFFFFFFu;
+  if (a.keep) { t.ka[0] = a.keep[arow * a.kw]; t.ka[1] = a.keep[arow * a.kw + (a.kw > 1 ? 1 : 0)]; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = rbase + 4 * g + r;
+    t.vm[r] = row < batch ? -1 : 0;
+    const int64_t rc = row < batch ? row : batch - 1;
+    const float* px = a.a2 + rc * a.lda2;
+#pragma unroll
+    for (int kt = 0; kt < kTmKT; ++kt) { const int k = kt * 16 + c16; t.xr[r][kt] = px[k < n2 ? k : 0]; }
+    t.kc[r][0] = a.keep ? a.keep[rc * a.kw] : 0xFFFFFFFFu;
+    t.kc[r][1] = a.keep ? a.keep[rc * a.kw + (a.kw > 1 ? 1 : 0)] : 0xFFFFFFFFu;
+    t.dv[r] = a.dot[rc];
+    t.yv[r] = a.labels[rc];
+  }
+}
+
 __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const TailMArgs a) {
   __shared__ __attribute__((aligned(16))) float Wf[4 * 4 * 16 * 4];      // z3 image [j][g][n][4]: W3[16j+4g+s][n]
   __shared__ __attribute__((aligned(16))) float Wb[64 * 16];             // gh2 image [k][n] row-major (n padded to 16)
@@ -53,6 +87,10 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
   const int sigmask = a.act == BR_ACT_SIGMOID ? -1 : 0, relumask = a.act == BR_ACT_RELU ? -1 : 0;
   const float floor_ = a.act == BR_ACT_RELU ? 0.f : -__builtin_inff();
 
+  const int64_t n_tiles = (batch + 15) >> 4;
+  const int64_t tile0 = (int64_t)blockIdx.x * kTmWaves + wave;
+  TailTile tt;
+  if (tile0 < n_tiles) tail_load_tile(tt, a, tile0, c16, g);
   // ---------------- staging ----------------
   for (int t = threadIdx.x; t < 64; t += kTmThreads) {
     float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
@@ -106,33 +144,16 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
   const float b3c = hv[0][c16], w4c = hv[1][c16];
   const float ik = a.inv_keep;
 
-  const int64_t n_tiles = (batch + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * kTmWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kTmWaves) {
+  for (int64_t tile = tile0; tile < n_tiles; tile += (int64_t)gridDim.x * kTmWaves) {
     const int64_t rbase = tile << 4;
-    // ---- loads: a2 in the A layout (row c16), raw a2 + keep words + dot / labels of the C-layout rows 4g..4g+3 ----
-    const int64_t arow = rbase + c16 < batch ? rbase + c16 : batch - 1;
-    const float* pa = a.a2 + arow * a.lda2 + 4 * g;
-    float4 av[kTmKT];
-#pragma unroll
-    for (int j = 0; j < kTmKT; ++j) av[j] = *reinterpret_cast<const float4*>(16 * j + 4 * g < n2 ? pa + 16 * j : pa - 4 * g);
-    uint32_t ka[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (a.keep) { ka[0] = a.keep[arow * a.kw]; ka[1] = a.keep[arow * a.kw + (a.kw > 1 ? 1 : 0)]; }
-    float xr[4][kTmKT], dv[4], yv[4];
-    uint32_t kc[4][2];
-    int vm[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = rbase + 4 * g + r;
-      vm[r] = row < batch ? -1 : 0;
-      const int64_t rc = row < batch ? row : batch - 1;
-      const float* px = a.a2 + rc * a.lda2;
-#pragma unroll
-      for (int kt = 0; kt < kTmKT; ++kt) { const int k = kt * 16 + c16; xr[r][kt] = px[k < n2 ? k : 0]; }
-      kc[r][0] = a.keep ? a.keep[rc * a.kw] : 0xFFFFFFFFu;
-      kc[r][1] = a.keep ? a.keep[rc * a.kw + (a.kw > 1 ? 1 : 0)] : 0xFFFFFFFFu;
-      dv[r] = a.dot[rc];
-      yv[r] = a.labels[rc];
-    }
+    if (tile != tile0) tail_load_tile(tt, a, tile, c16, g);
+    float4 (&av)[kTmKT] = tt.av;
+    uint32_t (&ka)[2] = tt.ka;
+    float (&xr)[4][kTmKT] = tt.xr;
+    float (&dv)[4] = tt.dv;
+    float (&yv)[4] = tt.yv;
+    uint32_t (&kc)[4][2] = tt.kc;
+    int (&vm)[4] = tt.vm;
     // ---- z3 = T(a2)·W3 ----
     f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -258,7 +279,12 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
   }
   __syncthreads();
   // slab of this workgroup: [dW3 (n2 x n3) | db3 (n3) | dW4 (n3 + 1, concat order) | db4]; dW3 carries the 1/(1-p) folded out of T()
-  float* slab = a.slabs + (int64_t)blockIdx.x * ((int64_t)n2 * n3 + 2 * n3 + 2);
+  const int64_t slab_el = (int64_t)n2 * n3 + 2 * n3 + 2;
+  float* slab = a.slabs + (int64_t)blockIdx.x * slab_el;
+  // the caller's slab count is sized for 128-row workgroups: the slabs nobody owns must read as zeros (a memset node of its own
+  // in the step's graph would cost more than these stores)
+  for (int64_t sl = (int64_t)blockIdx.x + gridDim.x; sl < a.n_slabs; sl += gridDim.x)
+    for (int t = threadIdx.x; t < slab_el; t += kTmThreads) a.slabs[sl * slab_el + t] = 0.f;
   for (int t = threadIdx.x; t < 64 * 16; t += kTmThreads) {
     const int k = t >> 4, n = t & 15;
     if (k < n2 && n < n3) {
@@ -296,7 +322,9 @@ __global__ __launch_bounds__(kTmThreads, 2) void neumf_tail_mfma_kernel(const Ta
 
 int tail_mfma_grid(int64_t batch) {
   const int64_t t = ceil_div(ceil_div(batch > 0 ? batch : 1, 16), kTmWaves);
-  return (int)(t < 1 ? 1 : (t > 512 ? 512 : t));
+  // 200+ VGPRs: 2 waves/SIMD = ONE 512-thread workgroup per CU.  A grid of 512 ran as two generations of workgroups, each with its
+  // own staging and its own slab / statistics tail; 256 workgroups loop over two tiles per wave instead
+  return (int)(t < 1 ? 1 : (t > 256 ? 256 : t));
 }
 void launch_tail_mfma(const TailMArgs& a, int grid, hipStream_t s) { neumf_tail_mfma_kernel<<<(unsigned)grid, kTmThreads, 0, s>>>(a); }
 
