@@ -59,52 +59,67 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
   const int sigmask = a.act == BR_ACT_SIGMOID ? -1 : 0, relumask = a.act == BR_ACT_RELU ? -1 : 0;
 
   // ---------------- staging: W image, BN constants ----------------
-  for (int k = threadIdx.x; k < Kp; k += kBwdThreads) {
-    Is[k] = (IBN && k < K) ? a.i_mean[k] : 0.f;
-    Is[Kp + k] = (IBN && k < K) ? a.i_rstd[k] : 0.f;
-    ssb[k] = k < K ? (a.scale ? a.scale[k] : 1.f) : 0.f;
-    ssb[Kp + k] = (a.scale && k < K) ? a.shift[k] : 0.f;
-    red[k] = 0.0; red[Kp + k] = 0.0;
-  }
-  for (int n = threadIdx.x; n < Np; n += kBwdThreads) {
-    float c1 = 1.f, c2 = 0.f, c3 = 0.f, mu = 0.f;
-    if (a.o_mean && n < N) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int r = 0; r < kBwdRep; ++r) { s1 += a.o_sums[(size_t)r * 2 * N + n]; s2 += a.o_sums[(size_t)r * 2 * N + N + n]; }
-      const float rs = a.o_rstd[n];
-      mu = a.o_mean[n];
-      c1 = a.o_gamma[n] * rs;
-      c2 = (float)(s1 * (double)a.inv_batch);
-      c3 = (float)(s2 * (double)a.inv_batch) * rs;
+  // (a lambda that both roles call AFTER they have issued their first tile's loads: in program order ahead of them, the staging's
+  //  three dependent memory round trips - constants, BatchNorm sums, W - ran before the first tile was even requested)
+  auto stage = [&]() {
+    for (int k = threadIdx.x; k < Kp; k += kBwdThreads) {
+      Is[k] = (IBN && k < K) ? a.i_mean[k] : 0.f;
+      Is[Kp + k] = (IBN && k < K) ? a.i_rstd[k] : 0.f;
+      ssb[k] = k < K ? (a.scale ? a.scale[k] : 1.f) : 0.f;
+      ssb[Kp + k] = (a.scale && k < K) ? a.shift[k] : 0.f;
+      red[k] = 0.0; red[Kp + k] = 0.0;
     }
-    // da = c1 * (gy - c2 - (y - mu) * c3)
-    Cs[n] = c1; Cs[Np + n] = c2; Cs[2 * Np + n] = c3; Cs[3 * Np + n] = mu;
-  }
-  {   // W: 4 floats along n per thread (one 16-B load when N % 4 == 0), all issued before the first LDS write
-    constexpr int TOT = Kp * (Np / 4), TR = (TOT + kBwdThreads - 1) / kBwdThreads;
-    float4 wv[TR];
-    const bool n4 = (N & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < TR; ++i) {
-      const int idx = threadIdx.x + i * kBwdThreads;
-      const int idc = idx < TOT ? idx : 0;
-      const int k = idc / (Np / 4), n = (idc - k * (Np / 4)) * 4;
-      const float* wr = a.W + (int64_t)(k < K ? k : 0) * N;
+    for (int n = threadIdx.x; n < Np; n += kBwdThreads) {
+      float c1 = 1.f, c2 = 0.f, c3 = 0.f, mu = 0.f;
+      if (a.o_mean && n < N) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kBwdRep; ++r) { s1 += a.o_sums[(size_t)r * 2 * N + n]; s2 += a.o_sums[(size_t)r * 2 * N + N + n]; }
+        const float rs = a.o_rstd[n];
+        mu = a.o_mean[n];
+        c1 = a.o_gamma[n] * rs;
+        c2 = (float)(s1 * (double)a.inv_batch);
+        c3 = (float)(s2 * (double)a.inv_batch) * rs;
+      }
+      // da = c1 * (gy - c2 - (y - mu) * c3)
+      Cs[n] = c1; Cs[Np + n] = c2; Cs[2 * Np + n] = c3; Cs[3 * Np + n] = mu;
+    }
+    {   // W: 4 floats along n per thread (one 16-B load when N % 4 == 0).  Clamped addresses, no lane conditions around the loads and
+        // the zero padding applied as a bit mask afterwards: with `if (in range) load` per element hipcc built an exec-masked block
+        // with its own s_waitcnt vmcnt(0) around each of the 7 loads - seven memory round trips in a row before the first tile
+      constexpr int TOT = Kp * (Np / 4), TR = (TOT + kBwdThreads - 1) / kBwdThreads;
+      float4 wv[TR];
+      const bool n4 = (N & 3) == 0;
       if (n4) {
-        wv[i] = *reinterpret_cast<const float4*>(wr + (n < N ? n : 0));
-        if (!(k < K && n < N)) wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  #pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const int idx = threadIdx.x + i * kBwdThreads;
+          const int idc = idx < TOT ? idx : 0;
+          const int k = idc / (Np / 4), n = (idc - k * (Np / 4)) * 4;
+          wv[i] = *reinterpret_cast<const float4*>(a.W + (int64_t)(k < K ? k : 0) * N + (n < N ? n : 0));
+        }
       } else {
-        const float t0 = wr[n < N ? n : 0], t1 = wr[n + 1 < N ? n + 1 : 0], t2 = wr[n + 2 < N ? n + 2 : 0], t3 = wr[n + 3 < N ? n + 3 : 0];
-        wv[i] = make_float4((k < K && n < N) ? t0 : 0.f, (k < K && n + 1 < N) ? t1 : 0.f, (k < K && n + 2 < N) ? t2 : 0.f, (k < K && n + 3 < N) ? t3 : 0.f);
+  #pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const int idx = threadIdx.x + i * kBwdThreads;
+          const int idc = idx < TOT ? idx : 0;
+          const int k = idc / (Np / 4), n = (idc - k * (Np / 4)) * 4;
+          const float* wr = a.W + (int64_t)(k < K ? k : 0) * N;
+          wv[i] = make_float4(wr[n < N ? n : 0], wr[n + 1 < N ? n + 1 : 0], wr[n + 2 < N ? n + 2 : 0], wr[n + 3 < N ? n + 3 : 0]);
+        }
+      }
+  #pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int idx = threadIdx.x + i * kBwdThreads;
+        const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
+        const int kin = k < K ? -1 : 0;
+        const int m0 = kin & (n < N ? -1 : 0), m1 = kin & (n + 1 < N ? -1 : 0), m2 = kin & (n + 2 < N ? -1 : 0), m3 = kin & (n + 3 < N ? -1 : 0);
+        const float4 w = make_float4(__int_as_float(__float_as_int(wv[i].x) & m0), __int_as_float(__float_as_int(wv[i].y) & m1),
+                                     __int_as_float(__float_as_int(wv[i].z) & m2), __int_as_float(__float_as_int(wv[i].w) & m3));
+        if (idx < TOT) *reinterpret_cast<float4*>(Ws + k * ldw + n) = w;
       }
     }
-#pragma unroll
-    for (int i = 0; i < TR; ++i) {
-      const int idx = threadIdx.x + i * kBwdThreads;
-      const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
-      if (idx < TOT) *reinterpret_cast<float4*>(Ws + k * ldw + n) = wv[i];
-    }
-  }
+
+  };
 
   if (is_dx) {
     // =========================================== dx waves ===========================================
@@ -125,6 +140,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_gy(tile);
+    stage();
     float isum[KT], isq[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) { isum[kt] = 0.f; isq[kt] = 0.f; }
@@ -269,6 +285,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
     };
     int64_t tile = blockIdx.x;
     if (q_live && tile < n_tiles) load_x(tile);
+    stage();
     f32x4 acc[2][NT];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
