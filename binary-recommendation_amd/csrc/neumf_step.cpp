@@ -275,7 +275,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   // this step's backward - are behind us on the launch stream): inside the pair launch's own grid when there is one, else as a
   // launch on the aux stream (the dedup sorts there were joined above)
   const bool prefetch = train && p > 0.f && s->keep_prefetch && (ph & BR_PH_ROWS_USER);
-  const bool prefetch_fused = prefetch && (ph & BR_PH_ROWS_ITEM);
+  const bool prefetch_fused = prefetch && s->keep_prefetch == 2 && (ph & BR_PH_ROWS_ITEM);
   const bool prefetch_aux = prefetch && !prefetch_fused && s->aux_stream;
   br::KeepArgs next_keep;
   if (prefetch_fused || prefetch_aux) {

@@ -457,11 +457,12 @@ typedef struct brNeumfStep {
   int64_t keep_rows;  /* rows the three planes of keep_bits are laid out for (plane offsets = brDropoutKeepWords(keep_rows, K));
                          0 = the batch of the call */
   int32_t keep_ready; /* 1: keep_bits already holds THIS step's masks (a previous call prefetched them): FWD1 does not generate them */
-  int32_t keep_prefetch;  /* 1 (training, dropout, aux_stream set, single process): the call that holds BR_PH_ROWS_USER also fills keep_bits
-                         with the NEXT step's masks (step + 1, same seed / row0, keep_rows rows) - as extra workgroups of the paired
-                         Adam-rows launch when the call holds BR_PH_ROWS_ITEM too (Philox is ALU-bound, the optimizer HBM-bound), else
-                         as a launch on aux_stream joined before the call returns; the host then sets keep_ready on the next call if
-                         that call's step / row0 are the ones prefetched */
+  int32_t keep_prefetch;  /* 1 or 2 (training, dropout, single process): the call that holds BR_PH_ROWS_USER also fills keep_bits with the
+                         NEXT step's masks (step + 1, same seed / row0, keep_rows rows) beside the Adam-rows kernel (Philox is ALU-bound,
+                         the optimizer HBM-bound): 1 = as a launch on aux_stream (needed), joined before the call returns; 2 = as extra
+                         workgroups of the paired Adam-rows launch when the call holds BR_PH_ROWS_ITEM too (no fork / join - 4 us less
+                         per step inside a hipGraph - but that launch then takes 101 instead of 94 us).  The host sets keep_ready on
+                         the next call if that call's step / row0 are the ones prefetched */
 } brNeumfStep;
 /* step_state: device {uint32 step; float alpha_t; float alpha_hist[BR_ALPHA_RING]}, brStepStateBytes() bytes,
  * zero-initialised (or step / alpha_t set by the host after a reload).
