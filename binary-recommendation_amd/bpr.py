@@ -11,19 +11,29 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 class BPREngine:
+    """optimizer "adam_dense" = Keras' non-lazy sparse Adam (every row of both tables moves every step [TF-sem]); dense_impl
+    "deferred" (default) reaches the untouched rows by per-row replay (include/binrec.h "Deferred dense Adam": the lookup replays a
+    row's missing g = 0 steps in registers, the optimizer launch applies them, flush() brings every row to the current step before
+    anything else reads the tables) instead of sweeping 6 x 4 B per table element per step ("sweep"); bit-equal tables."""
+
+    ALPHA_RING = _lib.parse_enums()["BR_ALPHA_RING"]
+    BETA1, BETA2, EPS = 0.9, 0.999, 1e-7
+
     def __init__(self, num_users: int, num_items: int, num_factor: int, device, max_batch: int, lr: float = 1e-3,
-                 optimizer: str = "adam_dense", id_dtype=torch.int32, init_seed: int = 0):
-        assert optimizer in ("adam_dense", "adam_lazy")
+                 optimizer: str = "adam_dense", id_dtype=torch.int32, init_seed: int = 0, dense_impl: str = "deferred"):
+        assert optimizer in ("adam_dense", "adam_lazy") and dense_impl in ("deferred", "sweep")
         self.device, self.max_batch, self.lr, self.optimizer, self.id_dtype = torch.device(device), int(max_batch), lr, optimizer, id_dtype
         self.dim = int(num_factor)
+        self.deferred = optimizer == "adam_dense" and dense_impl == "deferred"
+        self._stale, self._flush_t = False, 0
         dev = self.device
         self._init_tables(num_users, num_items, init_seed)
-        self.user_m, self.user_v = torch.zeros_like(self.user), torch.zeros_like(self.user)
-        self.item_m, self.item_v = torch.zeros_like(self.item), torch.zeros_like(self.item)
+        self.user_m, self.user_v = torch.zeros_like(self._user), torch.zeros_like(self._user)
+        self.item_m, self.item_v = torch.zeros_like(self._item), torch.zeros_like(self._item)
         B = self.max_batch
         self.g_user = torch.empty(B, self.dim, device=dev)
         self.g_item = torch.empty(2 * B, self.dim, device=dev)
@@ -33,17 +43,61 @@ class BPREngine:
         self.user_index = ops.RowIndex(B, id_dtype, dev)
         self.item_index = ops.RowIndex(2 * B, id_dtype, dev)
         self.err = ops.new_err_flag(dev)
-        if optimizer == "adam_dense":
-            self.user_mark = torch.zeros(self.user.shape[0], dtype=torch.uint8, device=dev)
-            self.item_mark = torch.zeros(self.item.shape[0], dtype=torch.uint8, device=dev)
+        if self.deferred:
+            self.user_last = torch.zeros(self._user.shape[0], dtype=torch.int32, device=dev)
+            self.item_last = torch.zeros(self._item.shape[0], dtype=torch.int32, device=dev)
+            self.step_state = torch.zeros(_lib.load().brStepStateBytes() // 4, dtype=torch.int32, device=dev)
+            _lib.check(_lib.load().brStepStateSet(self.step_state.data_ptr(), 0, lr, self.BETA1, self.BETA2, ops._stream()), "brStepStateSet")
+            self.r_user = torch.empty(B, self.dim, device=dev)            # rows as of the previous step (replayed in registers)
+            self.r_item = torch.empty(2 * B, self.dim, device=dev)
+            self.pos_b = torch.arange(2 * B, device=dev).to(id_dtype)
+        elif optimizer == "adam_dense":
+            self.user_mark = torch.zeros(self._user.shape[0], dtype=torch.uint8, device=dev)
+            self.item_mark = torch.zeros(self._item.shape[0], dtype=torch.uint8, device=dev)
         self.t = 0
         self.n_seen = 0
+
+    # the tables as a caller sees them: flushed (deferred mode) before they are handed out
+    @property
+    def user(self):
+        self.flush()
+        return self._user
+
+    @user.setter
+    def user(self, t):
+        self._user = t
+
+    @property
+    def item(self):
+        self.flush()
+        return self._item
+
+    @item.setter
+    def item(self, t):
+        self._item = t
+
+    def flush(self):
+        """deferred dense Adam: apply the pending g = 0 steps to every row of both tables (brAdamFlush).  No-op otherwise."""
+        if not (self.deferred and self._stale):
+            return
+        lib = _lib.load()
+        for tab, m, v, last in ((self._user, self.user_m, self.user_v, self.user_last), (self._item, self.item_m, self.item_v, self.item_last)):
+            _lib.check(lib.brAdamFlush(tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), tab.shape[0], tab.shape[1], self.step_state.data_ptr(),
+                                       self.BETA1, self.BETA2, self.EPS, ops._stream()), "brAdamFlush")
+        self._stale, self._flush_t = False, self.t
+
+    def _advance(self):
+        """step counter + alpha ring of the device step state (the replay reads each missed step's alpha from the ring)"""
+        if self.t + 1 - self._flush_t >= self.ALPHA_RING - 8:
+            self.flush()
+        self._stale = True
+        _lib.check(_lib.load().brStepStateAdvance(self.step_state.data_ptr(), self.lr, self.BETA1, self.BETA2, None, 0, ops._stream()), "brStepStateAdvance")
 
     def _init_tables(self, num_users, num_items, init_seed):
         """[TF-sem] Keras Embedding init U(-0.05, 0.05).  (A hook: the row-sharded engine allocates only its shard.)"""
         g = torch.Generator(device="cpu").manual_seed(init_seed)
-        self.user = (torch.rand(num_users, self.dim, generator=g) * 0.1 - 0.05).to(self.device)
-        self.item = (torch.rand(num_items, self.dim, generator=g) * 0.1 - 0.05).to(self.device)
+        self._user = (torch.rand(num_users, self.dim, generator=g) * 0.1 - 0.05).to(self.device)
+        self._item = (torch.rand(num_items, self.dim, generator=g) * 0.1 - 0.05).to(self.device)
 
     def train_step(self, users, pos, neg, batch_total: int | None = None):
         """fit step (BPRModel.py:109): users/pos/neg device ids (B,). No host sync."""
@@ -52,25 +106,40 @@ class BPREngine:
             return
         if B > self.max_batch:
             raise ValueError("batch exceeds max_batch")
+        if self.deferred:
+            self._advance()
         self.t += 1
         bt = B if batch_total is None else batch_total
         gi = self.g_item[:2 * B]
-        ops.bpr_forward_backward(self.user, self.item, users, pos, neg, 1.0 / bt, self.loss_slots, self.g_user[:B], gi,
-                                 self.per_triplet[:B], self.err)
         ids2 = self.item_ids[:2 * B]
         ids2[:B].copy_(pos)
         ids2[B:].copy_(neg)
-        self.user_index.build(users, self.user.shape[0])
-        self.item_index.build(ids2, self.item.shape[0])
+        U, I = self._user, self._item
+        if self.deferred:
+            hp = (self.BETA1, self.BETA2, self.EPS)
+            ru = ops.gather_rows_deferred(U, self.user_m, self.user_v, self.user_last, users, self.step_state, *hp, out=self.r_user[:B], err_flag=self.err)
+            ri = ops.gather_rows_deferred(I, self.item_m, self.item_v, self.item_last, ids2, self.step_state, *hp, out=self.r_item[:2 * B], err_flag=self.err)
+            ar = self.pos_b[:B]
+            ops.bpr_forward_backward(ru, ri, ar, ar, self.pos_b[B:2 * B], 1.0 / bt, self.loss_slots, self.g_user[:B], gi, self.per_triplet[:B], self.err)
+            self.user_index.build(users, U.shape[0])
+            self.item_index.build(ids2, I.shape[0])
+            ops.adam_rows_sorted_deferred(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], self.dim, self.step_state, *hp)
+            ops.adam_rows_sorted_deferred(I, self.item_m, self.item_v, self.item_last, self.item_index, gi, self.dim, self.step_state, *hp)
+            self.n_seen += B
+            return
+        ops.bpr_forward_backward(U, I, users, pos, neg, 1.0 / bt, self.loss_slots, self.g_user[:B], gi,
+                                 self.per_triplet[:B], self.err)
+        self.user_index.build(users, U.shape[0])
+        self.item_index.build(ids2, I.shape[0])
         a = ops.adam_alpha(self.lr, self.t)
         dense = self.optimizer == "adam_dense"
-        ops.adam_rows_sorted(self.user, self.user_m, self.user_v, self.user_index, self.g_user[:B], self.dim, a,
+        ops.adam_rows_sorted(U, self.user_m, self.user_v, self.user_index, self.g_user[:B], self.dim, a,
                              mark=self.user_mark if dense else None)
-        ops.adam_rows_sorted(self.item, self.item_m, self.item_v, self.item_index, gi, self.dim, a,
+        ops.adam_rows_sorted(I, self.item_m, self.item_v, self.item_index, gi, self.dim, a,
                              mark=self.item_mark if dense else None)
         if dense:
-            ops.adam_dense_sweep(self.user, self.user_m, self.user_v, a, mark=self.user_mark)
-            ops.adam_dense_sweep(self.item, self.item_m, self.item_v, a, mark=self.item_mark)
+            ops.adam_dense_sweep(U, self.user_m, self.user_v, a, mark=self.user_mark)
+            ops.adam_dense_sweep(I, self.item_m, self.item_v, a, mark=self.item_mark)
         self.n_seen += B
 
     def pop_loss(self) -> float:
@@ -94,6 +163,7 @@ class BPREngine:
     STATE_TABLES = ("user", "item", "user_m", "user_v", "item_m", "item_v")
 
     def state_dict(self) -> dict:
+        self.flush()
         sd = {"t": self.t}
         sd.update({k: getattr(self, k) for k in self.STATE_TABLES})
         return sd
@@ -101,4 +171,8 @@ class BPREngine:
     def load_state_dict(self, sd: dict):
         self.t = int(sd["t"])
         for k in self.STATE_TABLES:
-            getattr(self, k).copy_(sd[k])
+            getattr(self, "_" + k if k in ("user", "item") else k).copy_(sd[k])
+        if self.deferred:                   # a checkpoint holds flushed tables: every row includes step t
+            self.user_last.fill_(self.t); self.item_last.fill_(self.t)
+            self._stale, self._flush_t = False, self.t
+            _lib.check(_lib.load().brStepStateSet(self.step_state.data_ptr(), self.t, self.lr, self.BETA1, self.BETA2, ops._stream()), "brStepStateSet")

@@ -582,7 +582,7 @@ def make_sharded_bpr(base_cls):
             B = self.max_batch
             self._idx_cap = int(5 * B) + 64
             self.user_index, self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device), ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
-            self.pos_b = torch.arange(B, device=self.device).to(self.id_dtype)
+            self.pos_b = torch.arange(2 * B, device=self.device).to(self.id_dtype)
 
         def _init_tables(self, num_users, num_items, init_seed):
             """only the rows this rank owns: a slice of `full_tables` (tests), else drawn with a rank-offset seed"""
@@ -600,6 +600,8 @@ def make_sharded_bpr(base_cls):
             if B > self.max_batch:
                 raise ValueError("batch exceeds max_batch")
             ctx, D = self.ctx, self.dim
+            if self.deferred:
+                self._advance()                                      # device step counter / alpha ring (the owner-side replay reads them)
             self.t += 1
             bt = B * ctx.world if batch_total is None else batch_total
             ids2 = self.item_ids[:2 * B]
@@ -609,8 +611,18 @@ def make_sharded_bpr(base_cls):
             xu.exchange_counts(xi)                                   # the step's one host sync
             ru, ri = xu.send_ids(), xi.send_ids()
             empty = torch.empty(0, D, device=self.device)
-            gu = ops.gather_rows([self.user], [ru], err_flag=self.err)[0] if ru.numel() else empty
-            gi = ops.gather_rows([self.item], [ri], err_flag=self.err)[0] if ri.numel() else empty
+            hp = (self.BETA1, self.BETA2, self.EPS)
+
+            def serve(tab, m, v, last, ids):
+                """owner side of the lookup; deferred: rows as of the previous step, replayed in registers"""
+                if not ids.numel():
+                    return empty
+                if self.deferred:
+                    return ops.gather_rows_deferred(tab, m, v, last, ids, self.step_state, *hp, err_flag=self.err)
+                return ops.gather_rows([tab], [ids], err_flag=self.err)[0]
+
+            gu = serve(self._user, self.user_m, self.user_v, getattr(self, "user_last", None), ru)
+            gi = serve(self._item, self.item_m, self.item_v, getattr(self, "item_last", None), ri)
             bu, bi = xu.return_rows(gu), xi.return_rows(gi)          # bucket order
             if B == 0:
                 eu, ei = empty, empty
@@ -628,12 +640,16 @@ def make_sharded_bpr(base_cls):
                 self._idx_cap = int(1.25 * max(xu.n_recv, xi.n_recv)) + 64
                 self.user_index, self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device), ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
             a = ops.adam_alpha(self.lr, self.t)
-            dense = self.optimizer == "adam_dense"
-            for tab, m, v, idx, ex, og, mark in ((self.user, self.user_m, self.user_v, self.user_index, xu, ou, getattr(self, "user_mark", None)),
-                                                 (self.item, self.item_m, self.item_v, self.item_index, xi, oi, getattr(self, "item_mark", None))):
+            dense = self.optimizer == "adam_dense" and not self.deferred     # per-step sweep of the untouched rows
+            for name, idx, ex, og in (("user", self.user_index, xu, ou), ("item", self.item_index, xi, oi)):
+                tab, m, v = getattr(self, "_" + name), getattr(self, name + "_m"), getattr(self, name + "_v")
+                mark = getattr(self, name + "_mark", None)
                 if ex.n_recv:
                     idx.build(ex.recv_local, tab.shape[0])
-                    ops.adam_rows_sorted(tab, m, v, idx, og, D, a, mark=mark if dense else None)
+                    if self.deferred:
+                        ops.adam_rows_sorted_deferred(tab, m, v, getattr(self, name + "_last"), idx, og, D, self.step_state, *hp)
+                    else:
+                        ops.adam_rows_sorted(tab, m, v, idx, og, D, a, mark=mark if dense else None)
                 if dense:
                     ops.adam_dense_sweep(tab, m, v, a, mark=mark)
             self.n_seen += B

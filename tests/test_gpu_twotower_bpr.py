@@ -123,6 +123,31 @@ def test_bpr_engine_three_steps(dev, optimizer):
     np.testing.assert_allclose(sc[0], O.bpr_predict(ut, it, 3, np.arange(I)), rtol=1e-4, atol=1e-6)
 
 
+def test_bpr_deferred_adam_is_bit_equal_to_the_sweep(dev):
+    """dense_impl="deferred" (per-row replay of the missed g = 0 steps) and "sweep" (every row every step) give the same tables bit
+    for bit - rows that sit out several steps, rows hit as positive and negative, a reload in between, the alpha ring wrapping."""
+    bpr = _m("bpr")
+    g = torch.Generator().manual_seed(4)
+    U, I, F, B = 400, 150, 16, 128
+    a = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="deferred", init_seed=3)
+    b = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="sweep", init_seed=3)
+    assert a.deferred and not b.deferred and torch.equal(a.user, b.user)
+    draw = lambda N: torch.randint(0, N, (B,), generator=g).int().to(dev)
+    for t in range(1, 1101):                                   # > BR_ALPHA_RING - 8 steps: one forced flush on the way
+        u, p, n = draw(U), draw(I), draw(I)
+        if t % 7 == 0:
+            p[:20] = 5; n[:9] = 5
+        a.train_step(u, p, n); b.train_step(u, p, n)
+        if t in (3, 40, 1100):
+            assert torch.equal(a.user, b.user) and torch.equal(a.item, b.item), t
+            assert torch.equal(a.user_m, b.user_m) and torch.equal(a.item_v, b.item_v), t
+        if t == 40:                                            # reload into a fresh deferred engine and carry on
+            c = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="deferred", init_seed=99)
+            c.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.state_dict().items()})
+            a = c
+    a.check_ids(); b.check_ids()
+
+
 def test_topk_ties_and_scores(dev):
     ops = _m("ops")
     z = np.load(os.path.join(GOLD, "topk_ties.npz"), allow_pickle=False)
