@@ -135,6 +135,9 @@ class TwoTowerEngine:
         """train_step (twoTower.py:89-102). labels only for rd_zero (RATING_TYPE)."""
         B = users.shape[0]
         if B == 0:
+            if self.dist is not None and self.dist.world > 1:
+                # the peers are about to enter the step's collectives: returning here would leave them waiting forever
+                raise ValueError("empty local batch in a data-parallel step: give every rank at least one pair (pad or drop the ragged tail)")
             return
         if B > self.max_batch:
             raise ValueError("batch exceeds max_batch")
