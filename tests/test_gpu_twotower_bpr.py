@@ -36,6 +36,47 @@ def test_inbatch_softmax_kernels(dev, Bq, dim):
     np.testing.assert_allclose(dc.cpu().numpy(), rdc, rtol=1e-4, atol=1e-5 * np.abs(rdc).max())
 
 
+@pytest.mark.parametrize("Bq,Bc,dim,idt", [(1, 1, 1, torch.int32), (3, 130, 7, torch.int64), (129, 63, 33, torch.int32), (260, 2, 100, torch.int32),
+                                           (1, 700, 128, torch.int64), (513, 257, 104, torch.int32), (64, 64, 57, torch.int32)])
+@pytest.mark.parametrize("with_ws", [True, False])
+def test_inbatch_softmax_ragged_shapes_and_workspace(dev, Bq, Bc, dim, idt, with_ws):
+    """rectangular / ragged (rows not multiples of 128 / 64, features not multiples of 4 / 8 / 32, one row, one column), int64 ids,
+    a diagonal that leaves the matrix for some queries, with the split workspace and through the C-ABI without one (ws = NULL:
+    one workgroup per 128 rows writes its results directly); no ids = no accidental-hit mask."""
+    ops, lib = _m("ops"), _m("_lib").load()
+    rng = np.random.default_rng(Bq * 1000 + Bc + dim)
+    q = rng.normal(0, 0.5, (Bq, dim)).astype(np.float32); c = rng.normal(0, 0.5, (Bc, dim)).astype(np.float32)
+    off = 0 if Bq <= Bc else 0                               # query i's positive is candidate i (+ off); queries past Bc have none
+    cid = rng.integers(0, 9, Bc); qid = np.where(np.arange(Bq) < Bc, cid[np.minimum(np.arange(Bq), Bc - 1)], rng.integers(0, 9, Bq))
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    qd, cd, qi, ci = td(q), td(c), td(qid).to(idt), td(cid).to(idt)
+    # float64 reference with the same rule: S_ij += float32.min / 100 where cand id == query's id and j is not the diagonal
+    S = q.astype(np.float64) @ c.astype(np.float64).T
+    diag = np.zeros((Bq, Bc), bool); ii = np.arange(Bq); ok = ii + off < Bc; diag[ii[ok], ii[ok] + off] = True
+    S = S + np.where((qid[:, None] == cid[None, :]) & ~diag, float(np.finfo(np.float32).min) / 100, 0.0)
+    m = S.max(1, keepdims=True); lse_ref = (m + np.log(np.exp(S - m).sum(1, keepdims=True)))[:, 0]
+    P = np.exp(S - lse_ref[:, None]) - diag
+    rdq, rdc = P @ c.astype(np.float64), P.T @ q.astype(np.float64)
+    loss_ref = float((lse_ref - np.where(ok, S[ii, np.minimum(ii + off, Bc - 1)], 0.0)).sum())
+    lse = torch.empty(Bq, device=dev); ls = torch.zeros(64, dtype=torch.float64, device=dev)
+    dq, dc = torch.full((Bq, dim), 7.0, device=dev), torch.full((Bc, dim), 7.0, device=dev)
+    if with_ws:
+        ops.inbatch_softmax_lse(qd, cd, qi, ci, off, lse, ls)
+        ops.inbatch_softmax_grad(qd, cd, qi, ci, off, lse, dq, dc)
+    else:
+        ty = ops.I64 if idt == torch.int64 else ops.I32
+        assert lib.brInBatchSoftmaxLse(qd.data_ptr(), cd.data_ptr(), qi.data_ptr(), ci.data_ptr(), ty, Bq, Bc, dim, off, lse.data_ptr(), ls.data_ptr(), None, 0, ops._stream()) == 0
+        assert lib.brInBatchSoftmaxGrad(qd.data_ptr(), cd.data_ptr(), qi.data_ptr(), ci.data_ptr(), ty, Bq, Bc, dim, off, lse.data_ptr(), dq.data_ptr(), dc.data_ptr(), None, 0,
+                                        ops._stream()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref, rtol=1e-5, atol=1e-5)
+    assert abs(ls.sum().item() - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+    np.testing.assert_allclose(dq.cpu().numpy(), rdq, rtol=1e-4, atol=1e-5 * max(1e-3, np.abs(rdq).max()))
+    np.testing.assert_allclose(dc.cpu().numpy(), rdc, rtol=1e-4, atol=1e-5 * max(1e-3, np.abs(rdc).max()))
+    sm = ops.score_matrix(qd, cd).cpu().numpy()
+    np.testing.assert_allclose(sm, q.astype(np.float64) @ c.astype(np.float64).T, rtol=1e-5, atol=1e-5)
+
+
 def test_inbatch_softmax_sharded_columns(dev):
     """data-parallel form: a rank's Bq queries against the all-gathered Bc candidates, diag_offset = rank*Bq."""
     ops = _m("ops")
