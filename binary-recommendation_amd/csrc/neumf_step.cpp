@@ -278,6 +278,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   const bool prefetch_fused = prefetch && s->keep_prefetch == 2 && (ph & BR_PH_ROWS_ITEM);
   const bool prefetch_aux = prefetch && !prefetch_fused && s->aux_stream;
   br::KeepArgs next_keep;
+  bool final_on_aux = false;
   if (prefetch_fused || prefetch_aux) {
     const uint32_t sites[3] = {0, 1, 2};
     const int widths[3] = {2 * D, n1, n2};
@@ -290,8 +291,21 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       hipStream_t as = (hipStream_t)s->aux_stream;
       (void)hipEventRecord(g_kfork, hs);
       (void)hipStreamWaitEvent(as, g_kfork, 0);
-      const int rc = br::dropout_keep_bits_ahead(p, s->seed, (uint32_t)s->step, 1, s->row0, krows, 3, sites, widths, outs, s->aux_stream);
+      int rc = br::dropout_keep_bits_ahead(p, s->seed, (uint32_t)s->step, 1, s->row0, krows, 3, sites, widths, outs, s->aux_stream);
       if (rc != BR_OK) return rc;
+      if ((ph & BR_PH_OPT_DENSE) && fused_final) {
+        // the dense finalize (slab reductions, BatchNorm parameter gradients, Adam on the flat vector) only needs the backward, which
+        // is behind the fork: it rides the same aux branch beside the Adam-rows kernel instead of waiting for it
+        const float* const rs[3] = {slabs1, slabs2, slabs_t};
+        const int rn[3] = {sp.ns1, sp.ns2, sp.ns_t};
+        const int64_t re[3] = {sp.el1, sp.el2, sp.el_t}, ro[3] = {oW1, oW2, oW3};
+        const double* const bs[2] = {bsum1, bsum2};
+        const int bn_n[2] = {n1, n2};
+        const int64_t bg[2] = {og1, og2}, bb[2] = {obe1, obe2};
+        rc = brDenseFinalize(rs, rn, re, ro, bs, bn_n, bg, bb, th, s->adam_m, s->adam_v, gr, n_dense, s->alpha_t, s->beta1, s->beta2, s->adam_eps, s->aux_stream);
+        if (rc != BR_OK) return rc;
+        final_on_aux = true;
+      }
       (void)hipEventRecord(g_kjoin, as);
     }
   }
@@ -331,7 +345,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       RUN(BR_TAG_SWEEP_ITEM, brAdamDenseSweep(s->item_tab, s->item_m, s->item_v, s->item_rows, 2 * D, s->alpha_t, s->beta1, s->beta2, s->adam_eps, im, stream));
   }
   if (prefetch_aux) (void)hipStreamWaitEvent(hs, g_kjoin, 0);
-  if ((ph & BR_PH_OPT_DENSE) && fused_final) {
+  if ((ph & BR_PH_OPT_DENSE) && fused_final && !final_on_aux) {
     const float* const rs[3] = {slabs1, slabs2, slabs_t};
     const int rn[3] = {sp.ns1, sp.ns2, sp.ns_t};
     const int64_t re[3] = {sp.el1, sp.el2, sp.el_t}, ro[3] = {oW1, oW2, oW3};
@@ -340,7 +354,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     const int64_t bg[2] = {og1, og2}, bb[2] = {obe1, obe2};
     RUN(BR_TAG_ADAM_FLAT, brDenseFinalize(rs, rn, re, ro, bs, bn_n, bg, bb, th, s->adam_m, s->adam_v, gr, n_dense, s->alpha_t, s->beta1, s->beta2,
                         s->adam_eps, stream));
-  } else if (ph & BR_PH_OPT_DENSE) {
+  } else if ((ph & BR_PH_OPT_DENSE) && !final_on_aux) {
     RUN(BR_TAG_ADAM_FLAT, brAdamFlat(th, s->adam_m, s->adam_v, gr, n_dense, s->alpha_t, s->beta1, s->beta2, s->adam_eps, stream));
   }
   if (!joined) (void)hipStreamWaitEvent(hs, g_join, 0);   // the consumers run in a later call: join the sorts here
