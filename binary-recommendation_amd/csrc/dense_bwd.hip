@@ -37,6 +37,12 @@ __device__ __forceinline__ float keep_bit(float x, uint32_t w, uint32_t pos) {  
   return __int_as_float(__float_as_int(x) & __builtin_amdgcn_sbfe((int)w, pos, 1u));
 }
 
+// Zs / Xs rows are 16 floats (64 B): the 16-B writes of 16 lanes that hold 16 consecutive rows would land on 4 bank groups (4-way
+// conflicts: rocprofv3 counted 37 % of the LDS cycles of the 128 x 100 layer as conflict cycles).  The 4-float column group q of row r is
+// stored at group q ^ ((r >> 2) & 3): writes become conflict-free, the b32 reads of the MFMA loops (16 columns x 4 rows r = 4s + g of one
+// k-step: the same XOR for every lane) stay conflict-free.
+__device__ __forceinline__ int bwd_swz(int col16, int row_quad) { return (((col16 >> 2) ^ (row_quad & 3)) << 2) | (col16 & 3); }
+
 template <int NT, int KT, bool IBN>
 __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           v[e] = __int_as_float(__float_as_int(da * dl) & lm);
         }
         dz[j] = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(Zb + (j * kBwdRows + rt * 16 + c16) * 16 + 4 * g) = dz[j];
+        *reinterpret_cast<float4*>(Zb + (j * kBwdRows + rt * 16 + c16) * 16 + 4 * (g ^ ((c16 >> 2) & 3))) = dz[j];     // swizzled: see bwd_swz
         __builtin_amdgcn_sched_barrier(0);
       }
       if (tile + gridDim.x < n_tiles) load_gy(tile + gridDim.x);        // next tile's gy / y in flight during the MFMAs
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
             if (kcol + 2 >= K) t.z = 0.f;
             if (kcol + 3 >= K) t.w = 0.f;
           }
-          *reinterpret_cast<float4*>(Xw + ((lc >> 2) * kBwdRows + lr + 8 * i) * 16 + 4 * (lc & 3)) = t;
+          *reinterpret_cast<float4*>(Xw + ((lc >> 2) * kBwdRows + lr + 8 * i) * 16 + 4 * ((lc & 3) ^ (((lr + 8 * i) >> 2) & 3))) = t;
         }
         if (tile + gridDim.x < n_tiles) load_x(tile + gridDim.x);     // next tile's x in flight during the MFMAs
       }
@@ -325,10 +331,11 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
 #pragma unroll 4
         for (int s = 0; s < kBwdRows / 4; ++s) {
           const int r = 4 * s + g;
-          const float a0 = Xw[r * 16 + c16], a1 = Xw[(kBwdRows + r) * 16 + c16];
+          const int cs = bwd_swz(c16, s);                  // (r >> 2) & 3 == s & 3
+          const float a0 = Xw[r * 16 + cs], a1 = Xw[(kBwdRows + r) * 16 + cs];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const float b = Zb[(nt * kBwdRows + r) * 16 + c16];
+            const float b = Zb[(nt * kBwdRows + r) * 16 + cs];
             acc[0][nt] = mfma16b(a0, b, acc[0][nt]);
             if (2 * q + 1 < KT) acc[1][nt] = mfma16b(a1, b, acc[1][nt]);
           }
@@ -337,9 +344,9 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
       // ---- db: column sums of dz (lane -> one column, half of the rows) ----
       if (db_live) {
         float s0 = 0.f;
-        const float* zc = Zb + ((dbcol >> 4) * kBwdRows + 32 * dbh) * 16 + (dbcol & 15);
+        const float* zc = Zb + ((dbcol >> 4) * kBwdRows + 32 * dbh) * 16;
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) s0 += zc[r * 16];
+        for (int r = 0; r < 32; ++r) s0 += zc[r * 16 + bwd_swz(dbcol & 15, r >> 2)];
         dbacc += s0;
       }
     }
