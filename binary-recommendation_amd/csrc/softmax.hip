@@ -8,6 +8,9 @@
 //     MODE_GRAD_R owned = queries     streamed = candidates   dQ_i = sum_j (exp(S_ij - lse_i) - [j = diag(i)]) C_j
 //     MODE_GRAD_C owned = candidates  streamed = queries      dC_j = sum_i (exp(S_ij - lse_i) - [j = diag(i)]) Q_i
 //     MODE_SCORES owned = candidates  streamed = queries      scores[q][c] (top-k scoring: topKmetrics.py:17-43, twoTower.py:64-69)
+//     MODE_LSE_GRAD_R = MODE_LSE and MODE_GRAD_R in ONE sweep (the training step needs both): the accumulator of dQ is kept relative
+//                 to the running row maximum and rescaled when it grows (online softmax); dQ_i = acc_i / l_i - C_diag(i) at the end.
+//                 The score tiles are formed twice per step instead of three times (4 GEMMs instead of 5 for lse + dQ + dC)
 //   MFMA: v_mfma_f32_32x32x2_f32.  The score tile is formed TRANSPOSED, D[m = streamed entity][n = owned row]: in the result
 //   layout a lane then holds ONE owned row (n = lane % 32) and its 16 registers hold 16 streamed entities
 //   (m = 8 (r / 4) + 4 (lane / 32) + r % 4), so
@@ -33,7 +36,7 @@ namespace br {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-enum { MODE_SCORES = 0, MODE_LSE = 1, MODE_GRAD_R = 2, MODE_GRAD_C = 3 };
+enum { MODE_SCORES = 0, MODE_LSE = 1, MODE_GRAD_R = 2, MODE_GRAD_C = 3, MODE_LSE_GRAD_R = 4 };
 
 // exp of a non-positive argument (score - running max, score - lse) on the hardware exp2: one evaluation per score made
 // these kernels VALU-bound with the accurate expf (~30 instructions each).  |x| <= ~88; the relative
@@ -61,7 +64,8 @@ template <int MODE, int KQ, typename IdT>
 __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
   constexpr int KH = 4 * KQ, Kp = 8 * KQ, ldt = Kp + 4;
   constexpr int FT = (Kp + 31) / 32;                     // 32-feature tiles of the second GEMM
-  constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C;
+  constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C || MODE == MODE_LSE_GRAD_R;
+  constexpr bool FUSED = MODE == MODE_LSE_GRAD_R;
   constexpr int NPRE = (2 * KQ + 3) / 4;                 // 16-byte vectors each thread stages per step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ts = smem;                                      // [64][ldt]     streamed tile, row-major (A operand of the score product)
@@ -222,6 +226,59 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
       run_m = nm;
       continue;
     }
+    if (FUSED) {
+      // ---- online softmax + dQ accumulator relative to the running maximum ----
+      float v[32];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          IdT ids4[4];
+          if (has_ids) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ids4[e] = tid[32 * sub + 8 * rq + jb + e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cj = 32 * sub + 8 * rq + e;
+            float x = sub ? s1[4 * rq + e] : s0[4 * rq + e];
+            const bool dg = cj == dd;
+            if (has_ids) x += (!dg && ids4[e] == own_id) ? kMinFloat : 0.f;
+            diag_s = dg ? x : diag_s;
+            v[16 * sub + 4 * rq + e] = cj < (int)(t_end - c0) - jb ? x : -INFINITY;
+          }
+        }
+      float m = v[0];
+#pragma unroll
+      for (int i = 1; i < 32; ++i) m = fmaxf(m, v[i]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));               // both lane halves of an owned row feed the same accumulator: one maximum
+      const float nm = fmaxf(run_m, m);                   // > -inf: every tile has at least one valid entity
+      const float sc = exp_hw(run_m - nm);                // 0 on the first step (run_m = -inf)
+      run_m = nm;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { v[i] = exp_hw(v[i] - nm); sum += v[i]; }
+      run_l = run_l * sc + sum;
+#pragma unroll
+      for (int t = 0; t < FT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[t][r] *= sc;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int j0 = 32 * sub + 8 * rq + jb;
+#pragma unroll
+          for (int t = 0; t < FT; ++t) {
+            const float4 a4 = *reinterpret_cast<const float4*>(TsT + (32 * t + l32) * kLdT + j0);
+            gacc[t] = mfma32(a4.x, v[16 * sub + 4 * rq + 0], gacc[t]);
+            gacc[t] = mfma32(a4.y, v[16 * sub + 4 * rq + 1], gacc[t]);
+            gacc[t] = mfma32(a4.z, v[16 * sub + 4 * rq + 2], gacc[t]);
+            gacc[t] = mfma32(a4.w, v[16 * sub + 4 * rq + 3], gacc[t]);
+          }
+        }
+      continue;
+    }
     // ---- GRAD: P in registers -> B operand of out^T[f][owned] += sum_k T[k][f] P[k][owned] ----
     // (streamed rows past the end and owned rows past the end need no mask: their T rows are zero / their results are not stored)
 #pragma unroll
@@ -260,6 +317,51 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
     }
   }
 
+  if (FUSED) {
+    // run_m is already common to the two lane halves of a row; l and the diagonal score are per half
+    const float l = run_l + __shfl_xor(run_l, 32, 64);
+    const float d = diag_s + __shfl_xor(diag_s, 32, 64);
+    const bool v4 = (a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(a.T) & 15) == 0;
+    if (a.part) {                                         // split: unnormalised accumulator slab + (max, sum, diag) per row
+      if (hb == 0 && own_ok) {
+        const int64_t ns = gridDim.y;
+        a.part[(0 * ns + blockIdx.y) * a.n_r + own] = run_m;
+        a.part[(1 * ns + blockIdx.y) * a.n_r + own] = l;
+        a.part[(2 * ns + blockIdx.y) * a.n_r + own] = d;
+      }
+    } else {
+      const float lse = run_m + logf(l);
+      double part = 0.0;
+      if (hb == 0 && own_ok) { a.lse_out[own] = lse; part = (double)lse - (double)d; }
+      part = wave_sum_d(part);
+      __shared__ double red[4];
+      if (lane == 0) red[wave] = part;
+      __syncthreads();
+      if (threadIdx.x == 0 && a.loss_sum) atomicAdd(a.loss_sum + (blockIdx.x & (BR_SUM_SLOTS - 1)), red[0] + red[1] + red[2] + red[3]);
+    }
+    const float inv_l = a.part ? 1.f : 1.f / l;           // direct: dQ = acc / l - C[diag]
+    const int64_t partner_row = own + a.diag;
+    const bool has_diag = !a.part && partner_row >= 0 && partner_row < a.n_t;
+    float* op = a.out + ((int64_t)blockIdx.y * a.n_r + (own_ok ? own : 0)) * a.ldo;
+    const float* cp = a.T + (has_diag ? partner_row : 0) * dim;
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int f = 32 * t + 8 * rq + jb;
+        if (!own_ok || f >= dim) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gacc[t][4 * rq + e] * inv_l - ((has_diag && f + e < dim) ? cp[f + e] : 0.f);
+        if (v4 && f + 3 < dim) {
+          *reinterpret_cast<float4*>(op + f) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (f + e < dim) op[f + e] = o[e];
+        }
+      }
+    return;
+  }
   if (MODE == MODE_LSE) {
     // lanes l and l + 32 hold disjoint streamed entities of the same owned row
     const float om = __shfl_xor(run_m, 32, 64), ol = __shfl_xor(run_l, 32, 64), od = __shfl_xor(diag_s, 32, 64);
@@ -329,6 +431,45 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restric
   mine = wave_sum_d(mine);
   __shared__ double red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum + (blockIdx.x & (BR_SUM_SLOTS - 1)), red[0] + red[1] + red[2] + red[3]);
+}
+
+// fused sweep with splits: per row M = max_s m_s, l = sum_s l_s e^(m_s - M), lse = M + log l, loss_sum += lse - diag;
+// dQ[i][f] = sum_s slab[s][i][f] e^(m_s - M) / l - C[i + diag][f]
+__global__ __launch_bounds__(256) void lse_grad_combine_kernel(const float* __restrict__ part, const float* __restrict__ slabs, int n_split, int64_t n_r,
+                                                                int dim, int64_t ldo, const float* __restrict__ C, int64_t n_c, int64_t diag,
+                                                                float* __restrict__ lse_out, double* __restrict__ loss_sum, float* __restrict__ dQ) {
+  // one 64-lane wave per row: lane -> features lane, lane + 64
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  double mine = 0.0;
+  if (i < n_r) {
+    float M = -INFINITY, d = 0.f;
+    for (int s = 0; s < n_split; ++s) M = fmaxf(M, part[(0 * (int64_t)n_split + s) * n_r + i]);
+    float l = 0.f;
+    for (int s = 0; s < n_split; ++s) {
+      const float ms = part[(0 * (int64_t)n_split + s) * n_r + i];
+      if (ms > -INFINITY) l += part[(1 * (int64_t)n_split + s) * n_r + i] * exp_hw(ms - M);
+      d += part[(2 * (int64_t)n_split + s) * n_r + i];
+    }
+    const float lse = M + logf(l);
+    if (lane == 0) { lse_out[i] = lse; mine = (double)lse - (double)d; }
+    const float inv_l = 1.f / l;
+    const int64_t pr = i + diag;
+    const bool has_diag = pr >= 0 && pr < n_c;
+    for (int f = lane; f < dim; f += 64) {
+      float acc = 0.f;
+      for (int s = 0; s < n_split; ++s) {
+        const float ms = part[(0 * (int64_t)n_split + s) * n_r + i];
+        if (ms > -INFINITY) acc += slabs[((int64_t)s * n_r + i) * ldo + f] * exp_hw(ms - M);
+      }
+      dQ[i * ldo + f] = acc * inv_l - (has_diag ? C[pr * dim + f] : 0.f);
+    }
+  }
+  mine = wave_sum_d(mine);
+  __shared__ double red[4];
+  if (lane == 0) red[threadIdx.x >> 6] = mine;
   __syncthreads();
   if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum + (blockIdx.x & (BR_SUM_SLOTS - 1)), red[0] + red[1] + red[2] + red[3]);
 }
@@ -412,7 +553,7 @@ int choose_splits(int64_t n_r, int64_t n_t, int64_t max_splits) {
 template <int MODE, int KQ, typename IdT>
 void launch_inbatch_k(const InbatchArgs& a, int n_split, hipStream_t s) {
   constexpr int Kp = 8 * KQ, FT = (Kp + 31) / 32;
-  constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C;
+  constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C || MODE == MODE_LSE_GRAD_R;
   const size_t shmem = ((size_t)kTs * (Kp + 4) + (GRAD ? (size_t)FT * 32 * kLdT : 0) + kTs) * sizeof(float) + kTs * sizeof(IdT);
   static bool attr = false;
   if (!attr) {
@@ -448,7 +589,9 @@ extern "C" int64_t brInBatchSoftmaxWorkspaceBytes(int64_t Bq, int64_t Bc, int di
   const int64_t lse = (int64_t)3 * choose_splits(Bq, Bc, 64) * Bq;
   const int64_t gq = choose_splits(Bq, Bc, 64) > 1 ? (int64_t)choose_splits(Bq, Bc, 64) * Bq * dim : 0;
   const int64_t gc = choose_splits(Bc, Bq, 64) > 1 ? (int64_t)choose_splits(Bc, Bq, 64) * Bc * dim : 0;
-  const int64_t fl = lse > gq ? (lse > gc ? lse : gc) : (gq > gc ? gq : gc);
+  const int64_t fused = gq ? gq + lse : 0;             // brInBatchSoftmaxLseGradQ: slabs + (max, sum, diag)
+  int64_t fl = lse > gq ? (lse > gc ? lse : gc) : (gq > gc ? gq : gc);
+  fl = fused > fl ? fused : fl;
   return fl * (int64_t)sizeof(float);
 }
 
@@ -469,6 +612,37 @@ extern "C" int brInBatchSoftmaxLse(const float* Q, const float* C, const void* q
     const int64_t tps = ceil_div(ceil_div(Bc, (int64_t)kTs), (int64_t)n_split) * kTs;
     lse_combine_kernel<<<(unsigned)ceil_div(Bq, (int64_t)256), 256, 0, s>>>((const float*)ws, (int)ceil_div(Bc, tps), Bq, row_lse, loss_sum);
     BR_CHECK_LAUNCH("brInBatchSoftmaxLse(combine)");
+  }
+  return BR_OK;
+}
+
+extern "C" int brInBatchSoftmaxLseGradQ(const float* Q, const float* C, const void* q_pos_ids, const void* cand_ids, int id_type, int64_t Bq,
+                                        int64_t Bc, int dim, int64_t diag_offset, float* row_lse, double* loss_sum, float* dQ, void* ws,
+                                        int64_t ws_bytes, brStream stream) {
+  BR_CHECK_ARG(Q && C && row_lse && dQ && Bq >= 0 && Bc >= 1 && dim >= 1 && dim <= 128, "brInBatchSoftmaxLseGradQ: bad args (dim <= 128)");
+  BR_CHECK_ARG((q_pos_ids == nullptr) == (cand_ids == nullptr), "brInBatchSoftmaxLseGradQ: ids both or neither");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brInBatchSoftmaxLseGradQ: bad id_type");
+  BR_CHECK_ARG(ws_bytes >= 0 && (ws != nullptr || ws_bytes == 0), "brInBatchSoftmaxLseGradQ: bad workspace");
+  if (Bq == 0) return BR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dim > 64) {      // the fused sweep's registers (stationary rows + two score tiles + the dQ accumulator + 32 probabilities) only fit up to 64 features
+    const int rc = brInBatchSoftmaxLse(Q, C, q_pos_ids, cand_ids, id_type, Bq, Bc, dim, diag_offset, row_lse, loss_sum, ws, ws_bytes, stream);
+    if (rc != BR_OK) return rc;
+    return brInBatchSoftmaxGrad(Q, C, q_pos_ids, cand_ids, id_type, Bq, Bc, dim, diag_offset, row_lse, dQ, nullptr, ws, ws_bytes, stream);
+  }
+  // workspace per split: the unnormalised dQ slab (Bq x dim) + (max, sum, diag) per row
+  const int64_t per_split = (Bq * dim + 3 * Bq) * (int64_t)sizeof(float);
+  const int n_split = choose_splits(Bq, Bc, ws ? ws_bytes / per_split : 1);
+  const int64_t tps = ceil_div(ceil_div(Bc, (int64_t)kTs), (int64_t)n_split) * kTs;
+  const int ns = (int)ceil_div(Bc, tps);                 // splits actually launched (launch_inbatch recomputes the same)
+  float* slabs = (float*)ws;
+  float* part = n_split > 1 ? slabs + (int64_t)ns * Bq * dim : nullptr;
+  InbatchArgs a{Q, C, Bq, Bc, dim, q_pos_ids, cand_ids, diag_offset, nullptr, n_split > 1 ? slabs : dQ, dim, part, row_lse, loss_sum, 0};
+  launch_inbatch<MODE_LSE_GRAD_R>(a, n_split, id_type, s);
+  BR_CHECK_LAUNCH("brInBatchSoftmaxLseGradQ");
+  if (n_split > 1) {
+    lse_grad_combine_kernel<<<(unsigned)ceil_div(Bq, (int64_t)4), 256, 0, s>>>(part, slabs, ns, Bq, dim, dim, C, Bc, diag_offset, row_lse, loss_sum, dQ);
+    BR_CHECK_LAUNCH("brInBatchSoftmaxLseGradQ(combine)");
   }
   return BR_OK;
 }

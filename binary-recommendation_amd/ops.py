@@ -408,6 +408,16 @@ def inbatch_softmax_lse(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, loss_su
                                           ws.data_ptr(), ws.numel(), _stream()), "brInBatchSoftmaxLse")
 
 
+def inbatch_softmax_lse_grad_q(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, loss_sum, dQ):
+    """lse + loss + dQ in one sweep (online softmax): the training step's first softmax pass."""
+    qi, qt = _ids(q_pos_ids, "q_pos_ids"); ci, ct = _ids(cand_ids, "cand_ids")
+    id_type = _same_id_type(qt, ct) if qi is not None else I32
+    ws = _softmax_workspace(Q, C)
+    check(_lib.load().brInBatchSoftmaxLseGradQ(_f32(Q, "Q").data_ptr(), _f32(C, "C").data_ptr(), _p(qi), _p(ci), id_type, Q.shape[0], C.shape[0],
+                                               Q.shape[1], int(diag_offset), _f32(row_lse, "row_lse").data_ptr(), loss_sum.data_ptr(),
+                                               _f32(dQ, "dQ").data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "brInBatchSoftmaxLseGradQ")
+
+
 def inbatch_softmax_grad(Q, C, q_pos_ids, cand_ids, diag_offset, row_lse, dQ=None, dC=None):
     qi, qt = _ids(q_pos_ids, "q_pos_ids"); ci, ct = _ids(cand_ids, "cand_ids")
     id_type = _same_id_type(qt, ct) if qi is not None else I32

@@ -540,10 +540,10 @@ def make_sharded_two_tower(base_cls):
             ctx = self.ctx
             off = ctx.rank * B
             c_all, ids_all = ctx.all_gather_rows(c.contiguous()), ctx.all_gather_rows(items.contiguous())
-            ops.inbatch_softmax_lse(q, c_all, items, ids_all, off, self.lse[:B], self.loss_slots)
             if dq is None:
+                ops.inbatch_softmax_lse(q, c_all, items, ids_all, off, self.lse[:B], self.loss_slots)
                 return
-            ops.inbatch_softmax_grad(q, c_all, items, ids_all, off, self.lse[:B], dq, None)
+            ops.inbatch_softmax_lse_grad_q(q, c_all, items, ids_all, off, self.lse[:B], self.loss_slots, dq)     # lse + loss + dQ in one sweep
             q_all, lse_all = ctx.all_gather_rows(q.contiguous()), ctx.all_gather_rows(self.lse[:B].contiguous())
             # dC of MY candidates against ALL queries: query g's positive is my candidate g - rank*B
             ops.inbatch_softmax_grad(q_all, c.contiguous(), ids_all, items, -off, lse_all, None, dc)

@@ -88,9 +88,11 @@ class TwoTowerEngine:
 
     def _softmax(self, q, c, items, B, dq, dc):
         """L4: in-batch softmax loss (+ gradients when dq is given) over the local batch."""
-        ops.inbatch_softmax_lse(q, c, items, items, 0, self.lse[:B], self.loss_slots)
-        if dq is not None:
-            ops.inbatch_softmax_grad(q, c, items, items, 0, self.lse[:B], dq, dc)
+        if dq is None:
+            ops.inbatch_softmax_lse(q, c, items, items, 0, self.lse[:B], self.loss_slots)
+            return
+        ops.inbatch_softmax_lse_grad_q(q, c, items, items, 0, self.lse[:B], self.loss_slots, dq)      # lse + loss + dQ in one sweep
+        ops.inbatch_softmax_grad(q, c, items, items, 0, self.lse[:B], None, dc)
 
     def _apply_tables(self, users, items, B):
         """S1 + O2/O1 on the two embedding tables from the per-pair row gradients deu / dei."""

@@ -327,6 +327,13 @@ int brInBatchSoftmaxLse(const float* Q, const float* C, const void* q_pos_ids,
                         const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
                         int64_t diag_offset, float* row_lse, double* loss_sum, void* ws,
                         int64_t ws_bytes, brStream stream);
+/* Pass 1 and the dQ half of pass 2 in ONE sweep (what a training step needs: twoTower.py:99-102): the dQ accumulator is kept relative
+ * to the running row maximum (online softmax) and normalised at the end, so the score tiles are formed twice per step instead of
+ * three times.  Same outputs as brInBatchSoftmaxLse + brInBatchSoftmaxGrad(dQ) to rounding. */
+int brInBatchSoftmaxLseGradQ(const float* Q, const float* C, const void* q_pos_ids,
+                             const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
+                             int64_t diag_offset, float* row_lse, double* loss_sum, float* dQ,
+                             void* ws, int64_t ws_bytes, brStream stream);
 int brInBatchSoftmaxGrad(const float* Q, const float* C, const void* q_pos_ids,
                          const void* cand_ids, int id_type, int64_t Bq, int64_t Bc, int dim,
                          int64_t diag_offset, const float* row_lse, float* dQ, float* dC,

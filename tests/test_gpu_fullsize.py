@@ -220,6 +220,13 @@ def test_inbatch_softmax_stripe_1024_x_65536(dev):
     _check(case, "loss", ls.sum().item(), loss, 1e-5, 0.0)
     _check(case, "row lse", lse.cpu().numpy(), rlse, 1e-5, 1e-6)
     _check(case, "dQ", dq.cpu().numpy(), rdq, 1e-4, 1e-5 * np.abs(rdq).max())
+    # the one-sweep form (lse + loss + dQ, online softmax, 64 column splits combined afterwards)
+    lse2 = torch.empty(Bq, device=dev); ls2 = torch.zeros(64, dtype=torch.float64, device=dev); dq2 = torch.empty(Bq, dim, device=dev)
+    ops.inbatch_softmax_lse_grad_q(Qd, Cd, qd, cd, off, lse2, ls2, dq2)
+    torch.cuda.synchronize()
+    _check(case, "loss (one sweep)", ls2.sum().item(), loss, 1e-5, 0.0)
+    _check(case, "row lse (one sweep)", lse2.cpu().numpy(), rlse, 1e-5, 1e-6)
+    _check(case, "dQ (one sweep)", dq2.cpu().numpy(), rdq, 1e-4, 1e-5 * np.abs(rdq).max())
 
 
 def test_inbatch_softmax_dc_stripe_8192(dev):

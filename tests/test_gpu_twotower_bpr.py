@@ -33,6 +33,11 @@ def test_inbatch_softmax_kernels(dev, Bq, dim):
     assert abs(ls.sum().item() - loss) <= 1e-5 * abs(loss)
     s = np.abs(rdq).max()
     np.testing.assert_allclose(dq.cpu().numpy(), rdq, rtol=1e-4, atol=1e-5 * s)
+    lse2 = torch.empty(Bq, device=dev); ls2 = torch.zeros(64, dtype=torch.float64, device=dev); dq2 = torch.empty(Bq, dim, device=dev)
+    ops.inbatch_softmax_lse_grad_q(qd, cd, idd, idd, 0, lse2, ls2, dq2)                # the one-sweep form
+    assert abs(ls2.sum().item() - loss) <= 1e-5 * abs(loss)
+    np.testing.assert_allclose(lse2.cpu().numpy(), lse.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dq2.cpu().numpy(), rdq, rtol=1e-4, atol=1e-5 * s)
     np.testing.assert_allclose(dc.cpu().numpy(), rdc, rtol=1e-4, atol=1e-5 * np.abs(rdc).max())
 
 
@@ -75,6 +80,17 @@ def test_inbatch_softmax_ragged_shapes_and_workspace(dev, Bq, Bc, dim, idt, with
     np.testing.assert_allclose(dc.cpu().numpy(), rdc, rtol=1e-4, atol=1e-5 * max(1e-3, np.abs(rdc).max()))
     sm = ops.score_matrix(qd, cd).cpu().numpy()
     np.testing.assert_allclose(sm, q.astype(np.float64) @ c.astype(np.float64).T, rtol=1e-5, atol=1e-5)
+    # lse + loss + dQ in one sweep (online softmax; above 64 features it runs the two passes itself)
+    lse2 = torch.empty(Bq, device=dev); ls2 = torch.zeros(64, dtype=torch.float64, device=dev); dq2 = torch.full((Bq, dim), 7.0, device=dev)
+    if with_ws:
+        ops.inbatch_softmax_lse_grad_q(qd, cd, qi, ci, off, lse2, ls2, dq2)
+    else:
+        ty = ops.I64 if idt == torch.int64 else ops.I32
+        assert lib.brInBatchSoftmaxLseGradQ(qd.data_ptr(), cd.data_ptr(), qi.data_ptr(), ci.data_ptr(), ty, Bq, Bc, dim, off, lse2.data_ptr(), ls2.data_ptr(), dq2.data_ptr(),
+                                            None, 0, ops._stream()) == 0
+    np.testing.assert_allclose(lse2.cpu().numpy(), lse_ref, rtol=1e-5, atol=1e-5)
+    assert abs(ls2.sum().item() - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+    np.testing.assert_allclose(dq2.cpu().numpy(), rdq, rtol=1e-4, atol=1e-5 * max(1e-3, np.abs(rdq).max()))
 
 
 def test_inbatch_softmax_sharded_columns(dev):
