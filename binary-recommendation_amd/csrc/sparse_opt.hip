@@ -61,6 +61,35 @@ __device__ __forceinline__ typename VecT<VEC>::type grow(const float* __restrict
   return sc ? vmul(v, sc[pos]) : v;
 }
 
+// acc += rows of positions [j, end) while they belong to `row`, in that order - the additions are sequential (the fp32 order is part
+// of the result), but the loads are not: eight ids / positions / gradient rows are requested together (one dependent round trip per eight
+// positions instead of per position; a hot id walks thousands).  Rows past the run's end are loaded and dropped.  -> first position
+// not added.
+template <typename IdT, int VEC, int W>
+__device__ __forceinline__ int64_t seg_walk(typename VecT<VEC>::type& acc, const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t j,
+                                            int64_t end, IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc) {
+  using V = typename VecT<VEC>::type;
+  for (; j + W <= end; j += W) {
+    IdT sv[W];
+    int32_t pv[W];
+    V v[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) sv[e] = sid[j + e];
+    if (sv[0] != row) return j;
+#pragma unroll
+    for (int e = 0; e < W; ++e) pv[e] = spos[j + e];
+#pragma unroll
+    for (int e = 0; e < W; ++e) v[e] = grow<VEC>(g, ldg, sc, pv[e]);
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      if (sv[e] != row) return j + e;
+      acc = vadd(acc, v[e]);
+    }
+  }
+  for (; j < end && sid[j] == row; ++j) acc = vadd(acc, grow<VEC>(g, ldg, sc, spos[j]));
+  return j;
+}
+
 template <typename IdT, int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type seg_acc(const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n, int64_t i,
                                                             IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc,
@@ -68,10 +97,18 @@ __device__ __forceinline__ typename VecT<VEC>::type seg_acc(const IdT* __restric
   using V = typename VecT<VEC>::type;
   V acc = grow<VEC>(g, ldg, sc, spos[i]);
   const int64_t own_end = part ? ((i / kSegBlock + 1) * kSegBlock < n ? (i / kSegBlock + 1) * kSegBlock : n) : n;
-  int64_t j = i + 1;
-  for (; j < own_end && sid[j] == row; ++j) acc = vadd(acc, grow<VEC>(g, ldg, sc, spos[j]));
-  if (part && j == own_end)
+  // (W = 1 here: the optimizer launches that inline this are bound by HBM latency at 8 waves / SIMD - the registers of a batched walk
+  //  cost them more on ordinary batches than they save on hot ids; the long runs are cut to <= 63 positions by the partials)
+  int64_t j = seg_walk<IdT, VEC, 1>(acc, sid, spos, i + 1, own_end, row, g, ldg, sc);
+  if (part && j == own_end) {
+    // one partial per later block of the run, four at a time (same order of additions)
+    for (; j + 3 * kSegBlock < n && sid[j + 3 * kSegBlock] == row; j += 4 * kSegBlock) {
+      const V p0 = vload<VEC>(part + (j / kSegBlock) * pdim), p1 = vload<VEC>(part + (j / kSegBlock + 1) * pdim);
+      const V p2 = vload<VEC>(part + (j / kSegBlock + 2) * pdim), p3 = vload<VEC>(part + (j / kSegBlock + 3) * pdim);
+      acc = vadd(vadd(vadd(vadd(acc, p0), p1), p2), p3);
+    }
     for (; j < n && sid[j] == row; j += kSegBlock) acc = vadd(acc, vload<VEC>(part + (j / kSegBlock) * pdim));
+  }
   return acc;
 }
 
@@ -105,7 +142,7 @@ __global__ __launch_bounds__(256) void segment_partials_kernel(SegJobs jobs, int
     const int64_t ldg = col < split ? jb.ldg0 : jb.ldg1;
     const float* sc = col < split ? nullptr : jb.sc1;
     V acc = grow<VEC>(g, ldg, sc, spos[i]);
-    for (int64_t j = i + 1; j < end && sid[j] == row; ++j) acc = vadd(acc, grow<VEC>(g, ldg, sc, spos[j]));
+    (void)seg_walk<IdT, VEC, 8>(acc, sid, spos, i + 1, end, row, g, ldg, sc);
     vstore<VEC>(jb.part + b * dim + col, acc);
   }
 }
