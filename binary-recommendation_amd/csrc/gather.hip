@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void neumf_embed_bwd_kernel(
     int64_t user_rows, int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items,
     int dim, int chunks, int lpr_log2, int64_t batch, int item_first, const float* __restrict__ dx0,
     const float* __restrict__ ddot, float* __restrict__ g_user_mlp, float* __restrict__ g_item_mlp,
-    float* __restrict__ g_user_mf, float* __restrict__ g_item_mf, int64_t ldg) {
+    float* __restrict__ g_user_mf, float* __restrict__ g_item_mf, int64_t ldg, int out_by_id) {
   using V = typename VecT<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,17 +236,20 @@ __global__ __launch_bounds__(256) void neumf_embed_bwd_kernel(
   if (b >= batch) return;
   const int64_t u = load_id(users, b), i = load_id(items, b);
   const bool uok = (uint64_t)u < (uint64_t)user_rows, iok = (uint64_t)i < (uint64_t)item_rows;
+  // out_by_id (row-sharded host: the "tables" are the received rows and the ids their slots): the gradient of pair b goes to row
+  // users[b] / items[b] of the outputs = straight into the padded send buffers of the exchange
+  const int64_t ou = out_by_id ? (uok ? u : -1) : b, oi = out_by_id ? (iok ? i : -1) : b;
   const float g = ddot[b];
   const int uoff = item_first ? dim : 0, ioff = item_first ? 0 : dim;
   for (int c = lir; c < chunks; c += lpr) {
     V uf = uok ? vload<VEC>(user_mf + u * ldu + c * VEC) : vzero<VEC>();
     V vf = iok ? vload<VEC>(item_mf + i * ldi + c * VEC) : vzero<VEC>();
-    vstore<VEC>(g_user_mf + b * ldg + c * VEC, vmul(vf, g));
-    vstore<VEC>(g_item_mf + b * ldg + c * VEC, vmul(uf, g));
+    if (ou >= 0) vstore<VEC>(g_user_mf + ou * ldg + c * VEC, vmul(vf, g));
+    if (oi >= 0) vstore<VEC>(g_item_mf + oi * ldg + c * VEC, vmul(uf, g));
     if (g_user_mlp) {
       const float* xr = dx0 + b * (2 * (int64_t)dim);
-      vstore<VEC>(g_user_mlp + b * ldg + c * VEC, vload<VEC>(xr + uoff + c * VEC));
-      vstore<VEC>(g_item_mlp + b * ldg + c * VEC, vload<VEC>(xr + ioff + c * VEC));
+      if (ou >= 0) vstore<VEC>(g_user_mlp + ou * ldg + c * VEC, vload<VEC>(xr + uoff + c * VEC));
+      if (oi >= 0) vstore<VEC>(g_item_mlp + oi * ldg + c * VEC, vload<VEC>(xr + ioff + c * VEC));
     }
   }
 }
@@ -490,7 +493,7 @@ extern "C" int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, 
                                     int64_t user_rows, int64_t item_rows, const void* users, const void* items,
                                     int id_type, int dim, int64_t batch, int item_first, const float* dx0,
                                     const float* ddot, float* g_user_mlp, float* g_item_mlp, float* g_user_mf,
-                                    float* g_item_mf, int64_t ldg, brStream stream) {
+                                    float* g_item_mf, int64_t ldg, int out_rows_by_id, brStream stream) {
   BR_CHECK_ARG(user_mf && item_mf && ddot && g_user_mf && g_item_mf, "brNeumfEmbedBackward: null pointer");
   BR_CHECK_ARG((g_user_mlp == nullptr) == (g_item_mlp == nullptr), "brNeumfEmbedBackward: g_*_mlp both or neither");
   BR_CHECK_ARG(!g_user_mlp || dx0, "brNeumfEmbedBackward: dx0 required for g_*_mlp");
@@ -504,11 +507,11 @@ extern "C" int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, 
   if (id_type == BR_IDS_I32) {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_bwd_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
                                user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int32_t*)users, (const int32_t*)items,
-                               dim, g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf, ldg)));
+                               dim, g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf, ldg, out_rows_by_id)));
   } else {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_bwd_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
                                user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int64_t*)users, (const int64_t*)items,
-                               dim, g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf, ldg)));
+                               dim, g.chunks, g.lpr_log2, batch, item_first, dx0, ddot, g_user_mlp, g_item_mlp, g_user_mf, g_item_mf, ldg, out_rows_by_id)));
   }
   BR_CHECK_LAUNCH("brNeumfEmbedBackward");
   return BR_OK;

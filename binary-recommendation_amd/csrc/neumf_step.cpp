@@ -261,7 +261,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       RUN(BR_TAG_EMBED_BWD, brMfGradInplace(s->g_user + D, s->g_item + D, 2 * D, s->ddot, B, D, stream));
     else if ((ph & BR_PH_EMBED) && !deferred)
       RUN(BR_TAG_EMBED_BWD, brNeumfEmbedBackward(s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows, s->users, s->items, s->id_type, D,
-                               B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, stream));
+                               B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, 0, stream));
   }
   if (build_index && !aux_index) {
     RUN(BR_TAG_INDEX_USER, brRowIndexBuildPair(s->users, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes,

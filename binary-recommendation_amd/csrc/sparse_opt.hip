@@ -931,6 +931,7 @@ __global__ __launch_bounds__(256) void shard_finish_kernel(ShardFinishJobs jobs,
 struct ShardPadJob {
   const void* sorted_dest; const int32_t* order; const void* send_local; const int64_t* counts;
   void* send_pad; int32_t* slot; int32_t* bpos; int64_t total_rows;
+  float* zero_rows; int zero_dim;      // optional [world*cap][zero_dim] buffer whose PAD rows are cleared (gradient send slots)
 };
 struct ShardPadJobs { ShardPadJob j[2]; };
 
@@ -955,6 +956,8 @@ __global__ __launch_bounds__(256) void shard_pad_kernel(ShardPadJobs jobs, int64
       const int64_t spare = jb.total_rows > d ? (jb.total_rows - d + world - 1) / world : 0;   // rows owner d holds = index of its spare row
       ((IdT*)jb.send_pad)[t] = (IdT)spare;
       jb.bpos[t] = -1;
+      if (jb.zero_rows)
+        for (int c = 0; c < jb.zero_dim; c += 4) *reinterpret_cast<float4*>(jb.zero_rows + t * jb.zero_dim + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -962,15 +965,18 @@ __global__ __launch_bounds__(256) void shard_pad_kernel(ShardPadJobs jobs, int64
 extern "C" int brShardPadPair(const void* sorted_dest_a, const void* sorted_dest_b, const int32_t* order_a, const int32_t* order_b,
                               const void* send_local_a, const void* send_local_b, const int64_t* counts_a, const int64_t* counts_b, int id_type,
                               int64_t n, int world, int64_t cap, int64_t total_rows_a, int64_t total_rows_b, void* send_pad_a, void* send_pad_b,
-                              int32_t* slot_a, int32_t* slot_b, int32_t* bpos_a, int32_t* bpos_b, int* err_flag, brStream stream) {
+                              int32_t* slot_a, int32_t* slot_b, int32_t* bpos_a, int32_t* bpos_b, float* zero_a, float* zero_b, int zero_dim, int* err_flag,
+                              brStream stream) {
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brShardPadPair: bad id_type");
+  BR_CHECK_ARG(!zero_a || (zero_dim >= 4 && zero_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(zero_a) & 15) == 0 && (reinterpret_cast<uintptr_t>(zero_b) & 15) == 0),
+               "brShardPadPair: zero rows need a dim that is a multiple of 4 and 16-byte alignment");
   BR_CHECK_ARG(world >= 1 && world <= 256 && n >= 0 && cap >= 1 && err_flag, "brShardPadPair: bad world / n / cap / flag");
   BR_CHECK_ARG(sorted_dest_a && order_a && send_local_a && counts_a && send_pad_a && slot_a && bpos_a, "brShardPadPair: null pointer (stream a)");
   const int n_jobs = sorted_dest_b ? 2 : 1;
   BR_CHECK_ARG(!sorted_dest_b || (order_b && send_local_b && counts_b && send_pad_b && slot_b && bpos_b), "brShardPadPair: null pointer (stream b)");
   ShardPadJobs J;
-  J.j[0] = ShardPadJob{sorted_dest_a, order_a, send_local_a, counts_a, send_pad_a, slot_a, bpos_a, total_rows_a};
-  J.j[1] = sorted_dest_b ? ShardPadJob{sorted_dest_b, order_b, send_local_b, counts_b, send_pad_b, slot_b, bpos_b, total_rows_b} : J.j[0];
+  J.j[0] = ShardPadJob{sorted_dest_a, order_a, send_local_a, counts_a, send_pad_a, slot_a, bpos_a, total_rows_a, zero_a, zero_dim};
+  J.j[1] = sorted_dest_b ? ShardPadJob{sorted_dest_b, order_b, send_local_b, counts_b, send_pad_b, slot_b, bpos_b, total_rows_b, zero_b, zero_dim} : J.j[0];
   const int64_t m = n > (int64_t)world * cap ? n : (int64_t)world * cap;
   const dim3 g((unsigned)ceil_div(m, 256), (unsigned)n_jobs);
   if (id_type == BR_IDS_I32) shard_pad_kernel<int32_t><<<g, 256, 0, (hipStream_t)stream>>>(J, n, world, cap, err_flag);

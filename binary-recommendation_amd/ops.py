@@ -147,7 +147,7 @@ def neumf_embed_forward(user_mlp, item_mlp, user_mf, item_mf, users, items, item
 
 
 def neumf_embed_backward(user_mf, item_mf, users, items, item_first, dx0, ddot, g_user_mf, g_item_mf,
-                         g_user_mlp=None, g_item_mlp=None):
+                         g_user_mlp=None, g_item_mlp=None, out_rows_by_id=False):
     """g_* may be (B, dim) buffers or column views of fused (B, 2*dim) buffers (shared row stride)."""
     u, ut = _ids(users, "users"); i, it = _ids(items, "items")
     id_type = _same_id_type(ut, it)
@@ -160,7 +160,7 @@ def neumf_embed_backward(user_mf, item_mf, users, items, item_first, dx0, ddot, 
     check(_lib.load().brNeumfEmbedBackward(user_mf.data_ptr(), item_mf.data_ptr(), user_mf.stride(0), item_mf.stride(0),
                                            user_mf.shape[0], item_mf.shape[0], _p(u), _p(i), id_type, dim, batch,
                                            int(item_first), _p(dx0), _f32(ddot, "ddot").data_ptr(), _p(g_user_mlp),
-                                           _p(g_item_mlp), g_user_mf.data_ptr(), g_item_mf.data_ptr(), ldg, _stream()),
+                                           _p(g_item_mlp), g_user_mf.data_ptr(), g_item_mf.data_ptr(), ldg, 1 if out_rows_by_id else 0, _stream()),
           "brNeumfEmbedBackward")
 
 

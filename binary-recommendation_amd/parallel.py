@@ -234,7 +234,7 @@ class PaddedExchange:
         _lib.check(lib.brShardPadPair(P(self.sdest[0]), P(self.sdest[1]), P(self.order[0]), P(self.order[1]), P(self.send[0]), P(self.send[1]),
                                       P(self.counts[0]), P(self.counts[1]), self.id_type, n, self.W, self.cap, self.total_rows[0], self.total_rows[1],
                                       P(self.send_pad[0]), P(self.send_pad[1]), P(self.slot[0]), P(self.slot[1]), P(self.bpos[0]), P(self.bpos[1]),
-                                      P(err_flag), ops._stream()), "brShardPadPair")
+                                      P(self.gpad[0]), P(self.gpad[1]), self.dim, P(err_flag), ops._stream()), "brShardPadPair")
         self.n = n
         return self
 
@@ -250,11 +250,14 @@ class PaddedExchange:
             self.ctx.all_to_all_equal(self.rows[s], self.served[s])
         return self.rows
 
-    def send_row_grads(self, g_a, g_b):
-        """per-pair row gradients (n x dim, batch order) -> padded slots (pad = 0) -> all-to-all #3 -> aligned with recv_ids."""
+    def send_row_grads(self, g_a=None, g_b=None):
+        """all-to-all #3: the padded gradient slots self.gpad (pad rows were cleared by plan()) -> owners, aligned with recv_ids.
+        g_a / g_b: per-pair rows (n x dim, batch order) to lay into the slots first; None = the producer wrote the slots itself
+        (brNeumfEmbedBackward out_rows_by_id)."""
         from . import _lib, ops
-        _lib.check(_lib.load().brRowsToSlotsPair(g_a.data_ptr(), g_b.data_ptr(), g_a.stride(0), self.bpos[0].data_ptr(), self.bpos[1].data_ptr(),
-                                                 self.gpad[0].data_ptr(), self.gpad[1].data_ptr(), self.n_slots, self.dim, ops._stream()), "brRowsToSlotsPair")
+        if g_a is not None:
+            _lib.check(_lib.load().brRowsToSlotsPair(g_a.data_ptr(), g_b.data_ptr(), g_a.stride(0), self.bpos[0].data_ptr(), self.bpos[1].data_ptr(),
+                                                     self.gpad[0].data_ptr(), self.gpad[1].data_ptr(), self.n_slots, self.dim, ops._stream()), "brRowsToSlotsPair")
         for s in range(2):
             self.ctx.all_to_all_equal(self.grecv[s], self.gpad[s])
         return self.grecv
@@ -461,16 +464,20 @@ def make_sharded_engine(base_cls):
 
         def _embed_backward_apply(self, users, items, B):
             cfg, D = self.cfg, self.cfg.dim
+            if self.exchange == "padded":
+                # fused per-pair row gradients [mlp | mf] written straight into the padded send slots (the ids ARE the slots)
+                x = self.px
+                gu, gi = x.gpad[0], x.gpad[1]
+                ops.neumf_embed_backward(self.r_user[:, D:], self.r_item[:, D:], self.pos_u, self.pos_i, cfg.item_first,
+                                         self.dx0[:B], self.ddot[:B], gu[:, D:], gi[:, D:], gu[:, :D], gi[:, :D], out_rows_by_id=True)
+                ou, oi = x.send_row_grads()                        # all-to-all #3
+                torch.cuda.current_stream(self.device).wait_event(self._ev_index)
+                self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
+                return
             gu, gi = self.g_user[:B], self.g_item[:B]
             # fused per-pair row gradients [mlp | mf] (the MLP halves are copied out of dx0 here)
             ops.neumf_embed_backward(self.r_user[:, D:], self.r_item[:, D:], self.pos_u, self.pos_i, cfg.item_first,
                                      self.dx0[:B], self.ddot[:B], gu[:, D:], gi[:, D:], gu[:, :D], gi[:, :D])
-            if self.exchange == "padded":
-                x = self.px
-                ou, oi = x.send_row_grads(gu, gi)                  # batch order -> padded slots -> all-to-all #3
-                torch.cuda.current_stream(self.device).wait_event(self._ev_index)
-                self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
-                return
             xu, xi = self.xu, self.xi
             # batch order -> bucket order, then all-to-all #3 to the owners
             bu = ops.gather_rows([gu], [xu.order.to(self.id_dtype)])[0]

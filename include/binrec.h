@@ -78,7 +78,9 @@ int brNeumfEmbedBackward(const float* user_mf, const float* item_mf, int64_t ld_
                          int64_t ld_item, int64_t user_rows, int64_t item_rows, const void* users,
                          const void* items, int id_type, int dim, int64_t batch, int item_first,
                          const float* dx0, const float* ddot, float* g_user_mlp, float* g_item_mlp,
-                         float* g_user_mf, float* g_item_mf, int64_t ldg, brStream stream);
+                         float* g_user_mf, float* g_item_mf, int64_t ldg, int out_rows_by_id,
+                         brStream stream);   /* out_rows_by_id: pair b's gradients go to rows users[b] / items[b] of the outputs
+                                                (row-sharded host: ids = slots of the padded exchange buffers) instead of row b */
 
 /* ---- L3: BPR triplet step — BPRModel.py:49-74,124-144; bpr.py:141-157 -----------------------
  * x = u·p - u·n ; l = 1 - sigmoid(x) ; loss = mean(l).  One fused launch: 3 gathers, 2 dots,
@@ -125,7 +127,9 @@ enum { BR_ERRFLAG_RANGE = 1, BR_ERRFLAG_CAPACITY = 2 };
 int brShardPadPair(const void* sorted_dest_a, const void* sorted_dest_b, const int32_t* order_a, const int32_t* order_b,
                    const void* send_local_a, const void* send_local_b, const int64_t* counts_a, const int64_t* counts_b, int id_type,
                    int64_t n, int world, int64_t cap, int64_t total_rows_a, int64_t total_rows_b, void* send_pad_a, void* send_pad_b,
-                   int32_t* slot_a, int32_t* slot_b, int32_t* bpos_a, int32_t* bpos_b, int* err_flag, brStream stream);
+                   int32_t* slot_a, int32_t* slot_b, int32_t* bpos_a, int32_t* bpos_b, float* zero_a, float* zero_b, int zero_dim,
+                   int* err_flag, brStream stream);   /* zero_*: optional [world*cap][zero_dim] buffers whose pad rows are cleared
+                                                         (the gradient send slots, written in place by brNeumfEmbedBackward out_rows_by_id) */
 /* dst[t] = bpos[t] >= 0 ? src[bpos[t]] : 0 (n_slots rows of dim floats; src rows at stride ld): per-pair rows -> padded send slots,
  * for one or two sets of equal shape (set b NULL: one). */
 int brRowsToSlotsPair(const float* src_a, const float* src_b, int64_t ld, const int32_t* bpos_a, const int32_t* bpos_b, float* dst_a,
