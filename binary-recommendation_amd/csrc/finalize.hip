@@ -59,9 +59,11 @@ __global__ __launch_bounds__(1024) void dense_finalize_kernel(FinalArgs a, AdamH
 #pragma unroll
     for (int q = 1; q < 16; ++q) g += part[q][lane];
     a.grad[e] = g;
-    float th = a.theta[e], m = a.m[e], v = a.v[e];
-    adam_update1(th, m, v, g, h);
-    a.theta[e] = th; a.m[e] = m; a.v[e] = v;
+    if (a.theta) {             // NULL: gradients only (a data-parallel host all-reduces them before its optimizer launch)
+      float th = a.theta[e], m = a.m[e], v = a.v[e];
+      adam_update1(th, m, v, g, h);
+      a.theta[e] = th; a.m[e] = m; a.v[e] = v;
+    }
   }
 }
 
@@ -73,7 +75,7 @@ extern "C" int brDenseFinalize(const float* const* slabs, const int* n_slabs, co
                                const double* const* bn_sums, const int* bn_n, const int64_t* dgamma_off, const int64_t* dbeta_off,
                                float* theta, float* m, float* v, float* grad, int64_t n, double alpha_t, double beta1, double beta2,
                                double eps, brStream stream) {
-  BR_CHECK_ARG(slabs && n_slabs && slab_elems && grad_off && bn_sums && bn_n && dgamma_off && dbeta_off && theta && m && v && grad && n >= 1,
+  BR_CHECK_ARG(slabs && n_slabs && slab_elems && grad_off && bn_sums && bn_n && dgamma_off && dbeta_off && grad && n >= 1 && (!theta || (m && v)),
                "brDenseFinalize: null pointer");
   FinalArgs a;
   int64_t covered = 0;

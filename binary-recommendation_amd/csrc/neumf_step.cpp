@@ -125,7 +125,8 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   BR_CHECK_ARG(B > 0 && D >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1 && n3 <= 32, "brNeumfStepRun: bad geometry");
   const bool train = s->training != 0;
   const bool deferred = s->adam_dense == 2;
-  const bool fused_final = train && s->fused_final != 0;     // reductions / BN grads / dense Adam in one launch at OPT_DENSE
+  const bool fused_final = train && s->fused_final == 1;     // reductions / BN grads / dense Adam in one launch at OPT_DENSE
+  const bool fused_grads = train && s->fused_final == 2;     // reductions / BN grads in one launch at BNG (the host all-reduces before its Adam)
   const SlabPlan sp = slab_plan(B, D, n1, n2, n3);
   float *slabs_t = s->slabs + sp.off_t, *slabs2 = s->slabs + sp.off2, *slabs1 = s->slabs + sp.off1;
   BR_CHECK_ARG(!deferred || (s->step_state && s->user_last && s->item_last), "brNeumfStepRun: deferred Adam needs step_state and the last[] arrays");
@@ -231,7 +232,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       RUN(BR_TAG_HEAD, brNeumfTailFused(s->a2, l2, th + oW3, th + ob3, th + oW4, th + ob4, s->dot, s->labels, nullptr, nullptr, nullptr, nullptr, &f2, p, keep2,
                       B, n2, n3, s->act, s->mf_first, s->loss, inv_b, s->a3, s->logit, s->prob, s->msums, s->ddot,
                       s->gh2, l2, bsum2, slabs_t, nst, stream));
-      if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs_t, nst, sp.el_t, gr + oW3, stream));
+      if (!fused_final && !fused_grads) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs_t, nst, sp.el_t, gr + oW3, stream));
     } else {
       RUN(BR_TAG_HEAD, brNeumfHead(s->a3, n3, s->dot, s->labels, th + oW4, th + ob4, B, n3, s->mf_first, s->loss, inv_b, s->logit, s->prob,
                       s->labels ? s->msums : nullptr, nullptr, 0, nullptr, nullptr, 0, stream));
@@ -242,15 +243,23 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
     const int ns2 = sp.ns2;
     RUN(BR_TAG_BWD_L2, brDenseBackward(s->gh2, l2, s->a2, l2, s->a1, l1, th + oW2, B, n1, n2, s->act, mean2, rstd2, th + og2, bsum2, bt_bn, scale1, shift1,
                         mean1, rstd1, p, keep1, s->gh1, l1, s->dz_ws, slabs2, ns2, bsum1, stream));
-    if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs2, ns2, sp.el2, gr + oW2, stream));
+    if (!fused_final && !fused_grads) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs2, ns2, sp.el2, gr + oW2, stream));
   }
   if (ph & BR_PH_BWD1) {
     const int ns1 = sp.ns1;
     RUN(BR_TAG_BWD_L1, brDenseBackward(s->gh1, l1, s->a1, l1, s->x0, 2 * D, th + oW1, B, 2 * D, n1, s->act, mean1, rstd1, th + og1, bsum1, bt_bn, nullptr,
                         nullptr, nullptr, nullptr, p, keep0, s->dx0, 2 * D, s->dz_ws, slabs1, ns1, nullptr, stream));
-    if (!fused_final) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs1, ns1, sp.el1, gr + oW1, stream));
+    if (!fused_final && !fused_grads) RUN(BR_TAG_REDUCE, brReduceSlabs(slabs1, ns1, sp.el1, gr + oW1, stream));
   }
-  if ((ph & BR_PH_BNG) && !fused_final) {
+  if ((ph & BR_PH_BNG) && fused_grads) {
+    const float* const rs[3] = {slabs1, slabs2, slabs_t};
+    const int rn[3] = {sp.ns1, sp.ns2, sp.ns_t};
+    const int64_t re[3] = {sp.el1, sp.el2, sp.el_t}, ro[3] = {oW1, oW2, oW3};
+    const double* const bs[2] = {bsum1, bsum2};
+    const int bn_n[2] = {n1, n2};
+    const int64_t bg[2] = {og1, og2}, bb[2] = {obe1, obe2};
+    RUN(BR_TAG_REDUCE, brDenseFinalize(rs, rn, re, ro, bs, bn_n, bg, bb, nullptr, nullptr, nullptr, gr, n_dense, 0.0, s->beta1, s->beta2, s->adam_eps, stream));
+  } else if ((ph & BR_PH_BNG) && !fused_final) {
     RUN(BR_TAG_SMALL, brBnParamGradsPair(bsum2, gr + og2, gr + obe2, n2, bsum1, gr + og1, gr + obe1, n1, stream));
   }
   if (ph & BR_PH_OPT_TABLES) {

@@ -251,7 +251,10 @@ class NeuMFEngine:
         st.dropout, st.bn_eps, st.bn_momentum = cfg.dropout, cfg.bn_eps, cfg.bn_momentum
         st.seed = cfg.seed
         st.bn_local = 1 if (self.dist is not None and not cfg.sync_bn) else 0
-        st.fused_final = 1 if self.dist is None else 0     # a data-parallel host all-reduces between reduction and optimizer
+        # a data-parallel host all-reduces `grad` between the reduction and the optimizer: per-replica BatchNorm reduces everything in one
+        # launch at BNG (2); with global BatchNorm statistics dgamma / dbeta are already global when BNG writes them, AFTER the all-reduce of
+        # the locally reduced dW (0: per-phase reductions)
+        st.fused_final = 1 if self.dist is None else (0 if cfg.sync_bn else 2)
         st.beta1, st.beta2, st.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
         P = lambda t: t.data_ptr()
         st.user_tab, st.user_m, st.user_v = P(self.fused["user"]), P(self.fused_m["user"]), P(self.fused_v["user"])

@@ -271,6 +271,7 @@ int brReduceSlabs(const float* slabs, int n_slabs, int64_t slab_elems, float* ou
  * ranges of the flat gradient (region r: n_slabs[r] slabs of slab_elems[r] floats -> grad[grad_off[r] ...)), the two BatchNorm
  * blocks' dgamma/dbeta from their backward column sums (as brBnParamGrads), then Adam on theta/m/v (as brAdamFlat).
  * The regions and BatchNorm blocks must tile [0, n) exactly. */
+/* theta == NULL (then m, v unused): gradients only */
 int brDenseFinalize(const float* const* slabs, const int* n_slabs, const int64_t* slab_elems, const int64_t* grad_off,
                     const double* const* bn_sums, const int* bn_n, const int64_t* dgamma_off, const int64_t* dbeta_off,
                     float* theta, float* m, float* v, float* grad, int64_t n, double alpha_t, double beta1, double beta2,
@@ -430,7 +431,9 @@ typedef struct brNeumfStep {
                          sums are all-reduced by the host and cover batch_total rows */
   int32_t fused_final;   /* 1 (single process): the slab reductions, the BatchNorm parameter gradients and the dense Adam run
                             as ONE launch at BR_PH_OPT_DENSE (brDenseFinalize) instead of inside their phases; `slabs` then
-                            holds three regions [tail | layer 2 | layer 1] (brNeumfStepSlabFloats) */
+                            holds three regions [tail | layer 2 | layer 1] (brNeumfStepSlabFloats).
+                            2 (data-parallel host): the reductions and the BatchNorm parameter gradients as ONE launch at BR_PH_BNG
+                            (brDenseFinalize without parameters); the host all-reduces `grad` and runs BR_PH_OPT_DENSE (brAdamFlat) */
   float dropout, bn_eps, bn_momentum, pad0;
   uint64_t seed;
   double alpha_t, beta1, beta2, adam_eps;
