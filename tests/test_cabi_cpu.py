@@ -23,7 +23,11 @@ def test_header_parses_all_entry_points():
             "brRowIndexWorkspaceBytes", "brRowIndexBuild", "brSegmentSumRows", "brScatterAddRows", "brAdamRowsSorted",
             "brAdamDenseSweep", "brAdamFlat", "brAdagradRowsSorted", "brAdagradFlat", "brDenseForward", "brDenseBackward",
             "brDenseBackwardSlabs", "brReduceSlabs", "brBnFinalize", "brBnInference", "brBnParamGrads", "brNeumfHead", "brHeadSlabs",
-            "brBceLogits", "brInBatchSoftmaxLse", "brInBatchSoftmaxGrad", "brTopKRows", "brGetLastError", "brVersion", "brDeviceInfo"}
+            "brBceLogits", "brInBatchSoftmaxLse", "brInBatchSoftmaxGrad", "brTopKRows", "brGetLastError", "brVersion", "brDeviceInfo",
+            # round 2
+            "brDropoutKeepBits", "brDropoutKeepWords", "brNeumfTailFused", "brInBatchSoftmaxLseGradQ", "brInBatchSoftmaxWorkspaceBytes", "brBootstrapDataset",
+            "brBprSampleTriplets", "brNcfNegativeCandidates", "brFullAuc", "brMapAtK", "brShardPlanPair", "brShardPadPair", "brRowsToSlotsPair",
+            "brAdamRowsSortedPair", "brAdamRowsSortedDeferred", "brAdamFlush", "brGatherRowsDeferred", "brDenseFinalize", "brNeumfStepRun"}
     assert must <= set(protos), must - set(protos)
     # pointer / scalar classification sanity
     rt, args, names = protos["brGatherRows"]
@@ -51,6 +55,15 @@ def test_argument_errors_are_reported_not_crashed(built):
     assert rc == -1
     with pytest.raises(lib.BinrecError):
         lib.check(rc, "brDenseForward")
+    # entry points added in round 2: argument checks run before anything touches a device
+    assert h.brInBatchSoftmaxLseGradQ(None, None, None, None, 0, 8, 8, 64, 0, None, None, None, None, 0, None) == -1 and b"LseGradQ" in h.brGetLastError()
+    assert h.brInBatchSoftmaxLse(None, None, None, None, 0, 8, 8, 200, 0, None, None, None, 0, None) == -1         # dim > 128
+    assert h.brShardPadPair(None, None, None, None, None, None, None, None, 0, 8, 2, 0, 10, 10, None, None, None, None, None, None, None, None, 0, None, None) == -1
+    assert h.brRowsToSlotsPair(None, None, 6, None, None, None, None, 4, 6, None) == -1                               # dim % 4 != 0
+    assert h.brFullAuc(None, 0, None, None, 1, 1, None, None) == -1 and h.brMapAtK(None, 1, 0, None, None, None, None, None) == -1
+    assert h.brDropoutKeepBits(1.5, 0, 0, 0, 4, 1, None, None, None, None) == -1                                      # drop_p out of range
+    assert h.brInBatchSoftmaxWorkspaceBytes(8192, 8192, 64) > 0 and h.brInBatchSoftmaxWorkspaceBytes(0, 8, 64) == 0
+    assert h.brDropoutKeepWords(65536, 100) == 65536 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
