@@ -106,31 +106,90 @@ class BPREngine:
             return
         if B > self.max_batch:
             raise ValueError("batch exceeds max_batch")
-        if self.deferred:
-            self._advance()
-        self.t += 1
-        bt = B if batch_total is None else batch_total
-        gi = self.g_item[:2 * B]
+        if self.deferred and self.t + 1 - self._flush_t >= self.ALPHA_RING - 8:      # the replay reads each missed step's alpha from a ring
+            self.flush()
         ids2 = self.item_ids[:2 * B]
-        ids2[:B].copy_(pos)
-        ids2[B:].copy_(neg)
+        for t in (users, pos, neg):
+            if t.dtype != self.id_dtype or not t.is_cuda or not t.is_contiguous() or t.shape[0] != B:
+                raise TypeError(f"ids must be contiguous {self.id_dtype} device tensors of one length")
+        # [pos | neg] side by side (the shared item table gets one index over both): one launch instead of two copies
+        _lib.check(_lib.load().brStageBatch(ids2.data_ptr(), ids2[B:].data_ptr(), None, pos.data_ptr(), neg.data_ptr(), None,
+                                            ops.I64 if self.id_dtype == torch.int64 else ops.I32, B, ops._stream()), "brStageBatch")
+        gr = getattr(self, "_graph", None)
+        if gr is not None and B == gr["batch"] and (batch_total is None or batch_total == B):
+            gr["users"].copy_(users)
+            self.t += 1
+            self._stale = self.deferred
+            gr["graph"].replay()
+            self.n_seen += B
+            return
+        self.t += 1
+        self._stale = self.deferred
+        self._step_body(users, ids2, B, B if batch_total is None else batch_total)
+        self.n_seen += B
+
+    def enable_graph(self, batch: int | None = None):
+        """Replay the step for batches of exactly `batch` triplets as ONE hipGraph (for hosts whose per-launch overhead is the bound:
+        at batch 65 536 on MI355X the eager step is GPU-bound at 0.195 ms and the replay, with its two forked index branches, takes
+        0.214 ms).  Deferred dense Adam only: then every per-step scalar (step counter, alpha) lives in the device step state.  The
+        user ids are copied into a static buffer per step."""
+        if not self.deferred:
+            raise ValueError("graph replay needs optimizer='adam_dense' with dense_impl='deferred' (per-step scalars on the device)")
+        B = self.max_batch if batch is None else int(batch)
+        if not 0 < B <= self.max_batch:
+            raise ValueError("graph batch must be in (0, max_batch]")
+        users = torch.zeros(B, dtype=self.id_dtype, device=self.device)
+        ids2 = self.item_ids[:2 * B]
+        ids2.zero_()
+        # every kernel runs once outside a capture first (code objects load on first launch); the model state is put back afterwards
+        keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state_dict().items()}
+        keep_loss = self.loss_slots.clone()
+        self._step_body(users, ids2, B, B)
+        torch.cuda.synchronize(self.device)
+        self.load_state_dict(keep)
+        self.loss_slots.copy_(keep_loss)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_body(users, ids2, B, B)
+        self.load_state_dict(keep)              # (the capture executes nothing; this re-syncs the device step counter after the dry run)
+        self.loss_slots.copy_(keep_loss)
+        self._graph = {"batch": B, "users": users, "graph": g}
+
+    def disable_graph(self):
+        self._graph = None
+
+    def _step_body(self, users, ids2, B, bt):
+        """the step's launches (ids2 = [pos | neg] already in place)"""
+        gi = self.g_item[:2 * B]
         U, I = self._user, self._item
+        if self.deferred:
+            _lib.check(_lib.load().brStepStateAdvance(self.step_state.data_ptr(), self.lr, self.BETA1, self.BETA2, None, 0, ops._stream()), "brStepStateAdvance")
+        # the two dedup indexes depend only on the ids: each on a side stream of its own (their sort kernels fill 8 and 16 CUs), beside
+        # the lookups and the triplet kernel; joined before the optimizer launches.  (On the launch stream they were 92 of the step's 248 us.)
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            self._ev = (torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
+        self._ev[0].record(main)                                   # the ids are complete; the previous step's readers of the indexes are done
+        for k, (idx, ids, rows) in enumerate(((self.user_index, users, U.shape[0]), (self.item_index, ids2, I.shape[0]))):
+            self._side[k].wait_event(self._ev[0])
+            with torch.cuda.stream(self._side[k]):
+                idx.build(ids, rows)
+                self._ev[1 + k].record(self._side[k])
         if self.deferred:
             hp = (self.BETA1, self.BETA2, self.EPS)
             ru = ops.gather_rows_deferred(U, self.user_m, self.user_v, self.user_last, users, self.step_state, *hp, out=self.r_user[:B], err_flag=self.err)
             ri = ops.gather_rows_deferred(I, self.item_m, self.item_v, self.item_last, ids2, self.step_state, *hp, out=self.r_item[:2 * B], err_flag=self.err)
             ar = self.pos_b[:B]
             ops.bpr_forward_backward(ru, ri, ar, ar, self.pos_b[B:2 * B], 1.0 / bt, self.loss_slots, self.g_user[:B], gi, self.per_triplet[:B], self.err)
-            self.user_index.build(users, U.shape[0])
-            self.item_index.build(ids2, I.shape[0])
+            main.wait_event(self._ev[1]); main.wait_event(self._ev[2])
             ops.adam_rows_sorted_deferred(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], self.dim, self.step_state, *hp)
             ops.adam_rows_sorted_deferred(I, self.item_m, self.item_v, self.item_last, self.item_index, gi, self.dim, self.step_state, *hp)
-            self.n_seen += B
             return
+        pos, neg = ids2[:B], ids2[B:]
         ops.bpr_forward_backward(U, I, users, pos, neg, 1.0 / bt, self.loss_slots, self.g_user[:B], gi,
                                  self.per_triplet[:B], self.err)
-        self.user_index.build(users, U.shape[0])
-        self.item_index.build(ids2, I.shape[0])
+        main.wait_event(self._ev[1]); main.wait_event(self._ev[2])
         a = ops.adam_alpha(self.lr, self.t)
         dense = self.optimizer == "adam_dense"
         ops.adam_rows_sorted(U, self.user_m, self.user_v, self.user_index, self.g_user[:B], self.dim, a,
@@ -140,7 +199,6 @@ class BPREngine:
         if dense:
             ops.adam_dense_sweep(U, self.user_m, self.user_v, a, mark=self.user_mark)
             ops.adam_dense_sweep(I, self.item_m, self.item_v, a, mark=self.item_mark)
-        self.n_seen += B
 
     def pop_loss(self) -> float:
         """Host sync: mean triplet loss since the last call."""

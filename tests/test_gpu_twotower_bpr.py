@@ -205,6 +205,29 @@ def test_bpr_deferred_adam_is_bit_equal_to_the_sweep(dev):
     a.check_ids(); b.check_ids()
 
 
+def test_bpr_graph_replay_equals_eager(dev):
+    """BPREngine.enable_graph: the step as one hipGraph (dedup indexes on forked side streams inside the capture) == the eager launches,
+    bit for bit, incl. a ragged batch in between that falls back to the eager path."""
+    bpr = _m("bpr")
+    g = torch.Generator().manual_seed(6)
+    U, I, F, B = 3000, 700, 32, 512
+    a = bpr.BPREngine(U, I, F, dev, B, init_seed=4)
+    b = bpr.BPREngine(U, I, F, dev, B, init_seed=4)
+    draw = lambda N, n=B: torch.randint(0, N, (n,), generator=g).int().to(dev)
+    for _ in range(2):                                           # enable after some training: the capture must not disturb the state
+        u, p, n = draw(U), draw(I), draw(I)
+        a.train_step(u, p, n); b.train_step(u, p, n)
+    a.enable_graph(B)
+    for t in range(6):
+        nb = 300 if t == 3 else B
+        u, p, n = draw(U, nb), draw(I, nb), draw(I, nb)
+        a.train_step(u, p, n); b.train_step(u, p, n)
+    a.check_ids(); b.check_ids()
+    assert a.t == b.t == 8
+    assert torch.equal(a.user, b.user) and torch.equal(a.item, b.item) and torch.equal(a.item_v, b.item_v)
+    assert abs(a.pop_loss() - b.pop_loss()) < 1e-9
+
+
 def test_topk_ties_and_scores(dev):
     ops = _m("ops")
     z = np.load(os.path.join(GOLD, "topk_ties.npz"), allow_pickle=False)
