@@ -525,6 +525,9 @@ def make_sharded_two_tower(base_cls):
 
         SHARDED_KEYS = ("user_emb", "item_emb", "user_acc", "item_acc", "user_v", "item_v")
 
+        def _start_indexes(self, users, items):
+            pass                                    # the owners index the ids they receive (_apply_tables)
+
         def save_sharded(self, path):
             save_sharded(self, path, self.ctx, [k for k in self.SHARDED_KEYS if k in self.state_dict()])
 

@@ -94,11 +94,24 @@ class TwoTowerEngine:
         ops.inbatch_softmax_lse_grad_q(q, c, items, items, 0, self.lse[:B], self.loss_slots, dq)      # lse + loss + dQ in one sweep
         ops.inbatch_softmax_grad(q, c, items, items, 0, self.lse[:B], None, dc)
 
+    def _start_indexes(self, users, items):
+        """the two dedup indexes depend only on the ids: each on a side stream of its own beside the lookup / towers / softmax, joined in
+        _apply_tables.  (The row-sharded subclass builds its indexes over the ids it RECEIVES and overrides this with a no-op.)"""
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            self._ev = (torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
+        self._ev[0].record(main)                   # the previous step's readers of the indexes are behind this point
+        for k, (idx, ids, rows) in enumerate(((self.user_index, users, self.user_emb.shape[0]), (self.item_index, items, self.item_emb.shape[0]))):
+            self._side[k].wait_event(self._ev[0])
+            with torch.cuda.stream(self._side[k]):
+                idx.build(ids, rows)
+                self._ev[1 + k].record(self._side[k])
+
     def _apply_tables(self, users, items, B):
         """S1 + O2/O1 on the two embedding tables from the per-pair row gradients deu / dei."""
-        E = self.E
-        self.user_index.build(users, self.user_emb.shape[0])
-        self.item_index.build(items, self.item_emb.shape[0])
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(self._ev[1]); main.wait_event(self._ev[2])
         self._opt_rows(self.user_emb, self.user_acc, getattr(self, "user_v", None), self.user_index, self.deu[:B])
         self._opt_rows(self.item_emb, self.item_acc, getattr(self, "item_v", None), self.item_index, self.dei[:B])
 
@@ -144,6 +157,7 @@ class TwoTowerEngine:
         if B > self.max_batch:
             raise ValueError("batch exceeds max_batch")
         self.t += 1
+        self._start_indexes(users, items)
         q, c = self.compute_emb(users, items, B)
         dq, dc = self.dq[:B], self.dc[:B]
         if self.rd_zero:
