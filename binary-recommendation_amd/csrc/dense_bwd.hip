@@ -20,6 +20,7 @@
 // Shapes: K, N <= 128 with 16-B aligned rows: every row stride a multiple of 4 floats (so rows of K or N floats are padded
 // to 4 and a 16-B access that starts inside a row stays inside its allocation); everything else runs the two-kernel path of mlp.hip.
 #include "dense.h"
+#include "stamps.h"
 
 namespace br {
 
@@ -62,6 +63,9 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
   const int64_t batch = a.batch;
   const int64_t n_tiles = (batch + kBwdRows - 1) / kBwdRows;
   const bool is_dx = wave < 4;                          // wave-uniform role
+  BR_STAMP_DECL;
+  BR_STAMP_RT(10);
+  BR_STAMP(0);
   const int sigmask = a.act == BR_ACT_SIGMOID ? -1 : 0, relumask = a.act == BR_ACT_RELU ? -1 : 0;
 
   // ---------------- staging: W image, BN constants ----------------
@@ -132,25 +136,36 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
     const int rt = wave;                                 // row tile of the 64-row tile
     float* patch = patches + wave * 16 * kBwdPatchLd;
     float4 vg[NT], vy[NT];
-    auto load_gy = [&](int64_t tile) {                   // A layout: lane (c16,g) <- row c16, columns 16j+4g..+3
+    // the A-layout loads touch 16 rows x 64 B per instruction: the CU's address pipe takes them at ~30 cycles each, and a wave that issues
+    // a whole tile's 2 NT loads back to back sits ~6 000 cycles at the issue port before its first MFMA (in-kernel stamps).  The next
+    // tile's loads are therefore issued two at a time between the MFMA blocks of the first pass (load_gy_j).
+    const float *pg_n = a.gy, *py_n = a.y;               // row pointers of the tile being prefetched
+    auto gy_rows = [&](int64_t tile) {
       int64_t row = tile * kBwdRows + rt * 16 + c16;
       row = row < batch ? row : batch - 1;
-      const float* pg = a.gy + row * a.ldgy + 4 * g;
-      const float* py = a.y + row * a.ldy + 4 * g;
+      pg_n = a.gy + row * a.ldgy + 4 * g;
+      py_n = a.y + row * a.ldy + 4 * g;
+    };
+    auto load_gy_j = [&](int j) {                        // A layout: lane (c16,g) <- row c16, columns 16j+4g..+3
+      const bool in = 16 * j + 16 <= N || 16 * j + 4 * g < N;          // the 16-B group starts inside N (rows are padded to 4 floats)
+      vg[j] = *reinterpret_cast<const float4*>(in ? pg_n + 16 * j : pg_n - 4 * g);
+      vy[j] = *reinterpret_cast<const float4*>(in ? py_n + 16 * j : py_n - 4 * g);
+    };
+    auto load_gy = [&](int64_t tile) {
+      gy_rows(tile);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const bool in = 16 * j + 16 <= N || 16 * j + 4 * g < N;        // the 16-B group starts inside N (rows are padded to 4 floats)
-        vg[j] = *reinterpret_cast<const float4*>(in ? pg + 16 * j : pg - 4 * g);
-        vy[j] = *reinterpret_cast<const float4*>(in ? py + 16 * j : py - 4 * g);
-      }
+      for (int j = 0; j < NT; ++j) load_gy_j(j);
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_gy(tile);
+    BR_STAMP(1);
     stage();
+    BR_STAMP(2);
     float isum[KT], isq[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) { isum[kt] = 0.f; isq[kt] = 0.f; }
     __syncthreads();                                     // staging visible
+    BR_STAMP(3);
     int it = 0;
     for (; tile < n_tiles; tile += gridDim.x, ++it) {
       const int64_t rbase = tile * kBwdRows + rt * 16;
@@ -180,7 +195,10 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
         *reinterpret_cast<float4*>(Zb + (j * kBwdRows + rt * 16 + c16) * 16 + 4 * (g ^ ((c16 >> 2) & 3))) = dz[j];     // swizzled: see bwd_swz
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (tile + gridDim.x < n_tiles) load_gy(tile + gridDim.x);        // next tile's gy / y in flight during the MFMAs
+      BR_STAMP(4);      // dz of the first tile published (includes the wait for gy / y)
+      const bool has_next = tile + gridDim.x < n_tiles;                  // wave-uniform
+      if (has_next) gy_rows(tile + gridDim.x);
+      if (has_next && !a.gx) load_gy(tile + gridDim.x);                  // (no dx product to hide them behind)
       // keep words of this lane's 4 C-layout rows (rows 4g..4g+3 of the row tile) and, with an input BN, the raw x of its outputs
       uint32_t kb[4][KW];
       if (a.keep && a.gx) {
@@ -192,6 +210,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           for (int w = 0; w < KW; ++w) kb[r][w] = a.keep[row * a.kw + w];
         }
       }
+      BR_STAMP(9);      // next tile's gy / y and this tile's keep words requested
       float xraw[4][KT];                                 // IBN: raw x of this lane's outputs (C layout), requested before the MFMAs
       if (IBN && a.gx) {
 #pragma unroll
@@ -203,7 +222,9 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           for (int kt = 0; kt < KT; ++kt) { const int k = kt * 16 + c16; xraw[r][kt] = xr_[k < K ? k : 0]; }
         }
       }
-      __syncthreads();                                   // Zs[it & 1] (and the dW waves' Xs) complete
+      // (no barrier here: the dx product needs only this wave's dz registers and the W image; the tile's barrier sits at the END of the
+      //  iteration, so that this wave's MFMA passes run while the dW waves - one per SIMD beside it - transform their next x tile, and
+      //  its dz arithmetic for the next tile runs while they multiply: see the dW loop)
       if (a.gx) {
         const int64_t left = batch - rbase;
         const int rows16 = left > 16 ? 16 : (left < 0 ? 0 : (int)left);
@@ -231,8 +252,10 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
             for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16b(dz[j].z, b[w].z, acc[w]);
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16b(dz[j].w, b[w].w, acc[w]);
+            if (kt0 == 0 && has_next) load_gy_j(j);                    // next tile's gy / y: two loads behind every MFMA block of the first pass
             __builtin_amdgcn_sched_barrier(0);
           }
+          BR_STAMP(5 + 2 * (kt0 / 4));      // pass MFMAs issued
           // epilogue of the pass: C layout (rows 4g..4g+3, column k = kt*16+c16): dropout transposed, producer-BN sums,
           // then through the patch into row layout and out as 16-B stores
 #pragma unroll
@@ -258,8 +281,10 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+          BR_STAMP(6 + 2 * (kt0 / 4));      // pass epilogue issued
         }
       }
+      __syncthreads();                                   // S_it: Zs[it & 1] is published; the dW waves' readers of Zs[(it - 1) & 1] are done
     }
     if (IBN && a.in_sums) {
 #pragma unroll
@@ -280,18 +305,25 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
     const bool col_in = kcol < K;
     float4 xv[8];
     uint32_t kx[8];
+    auto x_row = [&](int64_t tile, int i) {
+      int64_t row = tile * kBwdRows + lr + 8 * i;
+      return row < batch ? row : batch - 1;
+    };
     auto load_x = [&](int64_t tile) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        int64_t row = tile * kBwdRows + lr + 8 * i;
-        row = row < batch ? row : batch - 1;
+        const int64_t row = x_row(tile, i);
         xv[i] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + (col_in ? kcol : 0));
         kx[i] = a.keep ? a.keep[row * a.kw + (col_in ? q : 0)] : 0xFFFFFFFFu;     // word q covers columns 32q..32q+31
       }
     };
+    // one of the next tile's 16 loads (8 x rows, 8 keep words): issued one per k-step of the product - back to back they hold the wave
+    // at the issue port for thousands of cycles (the CU's address pipe takes ~30 cycles per 16-row access)
     int64_t tile = blockIdx.x;
     if (q_live && tile < n_tiles) load_x(tile);
+    BR_STAMP(1);
     stage();
+    BR_STAMP(2);
     f32x4 acc[2][NT];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -303,12 +335,60 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
     const int dbcol = q * DBC + dbc;
     const bool db_live = dbc < DBC && dbcol < Np;
     __syncthreads();                                     // staging visible
+    BR_STAMP(3);
     const float4 sc = *reinterpret_cast<const float4*>(ssb + (col_in ? kcol : 0)), sh = *reinterpret_cast<const float4*>(ssb + Kp + (col_in ? kcol : 0));
+    // Between two barriers the dx wave of this SIMD first computes dz of tile t (VALU) and then multiplies (MFMA); this wave does the
+    // opposite - first dW += T(x(t-1))^T dz(t-1) (MFMA: both operands were published before the last barrier), then T(x(t)) (VALU) -
+    // so the SIMD's matrix pipe is fed by one of the two at any time instead of by both and then by neither.
+    auto multiply = [&](const float* Zb) {
+      if (q_live) {
+        // ---- dW[32 x N] += T(x)^T · dz: contraction over the 64 rows, k-step s <-> rows 4s+g ----
+        // operands of k-step s+1 are read from LDS while the MFMAs of k-step s issue (left to itself hipcc waits for each pair of
+        // ds_reads right before the four MFMAs that use them: 12 100 cycles per tile for 7 200 cycles of MFMA work; with a scheduling
+        // fence per k-step and no explicit double buffer: 19 600)
+        float a0, a1, bq[NT];
+        auto fetch = [&](int s_, float& x0, float& x1, float (&bb)[NT]) {
+          const int r = 4 * s_ + g;
+          const int cs = bwd_swz(c16, s_);                 // (r >> 2) & 3 == s & 3
+          x0 = Xw[r * 16 + cs]; x1 = Xw[(kBwdRows + r) * 16 + cs];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bb[nt] = Zb[(nt * kBwdRows + r) * 16 + cs];
+        };
+        fetch(0, a0, a1, bq);
+#pragma unroll
+        for (int s = 0; s < kBwdRows / 4; ++s) {
+          float n0 = 0.f, n1 = 0.f, nb[NT];
+          if (s + 1 < kBwdRows / 4) fetch(s + 1, n0, n1, nb);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[0][nt] = mfma16b(a0, bq[nt], acc[0][nt]);
+            if (2 * q + 1 < KT) acc[1][nt] = mfma16b(a1, bq[nt], acc[1][nt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < kBwdRows / 4) {
+            a0 = n0; a1 = n1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[nt] = nb[nt];
+          }
+        }
+      }
+      // ---- db: column sums of dz (lane -> one column, half of the rows) ----
+      if (db_live) {
+        float s0 = 0.f;
+        const float* zc = Zb + ((dbcol >> 4) * kBwdRows + 32 * dbh) * 16;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) s0 += zc[r * 16 + bwd_swz(dbcol & 15, r >> 2)];
+        dbacc += s0;
+      }
+    };
     int it = 0;
     for (; tile < n_tiles; tile += gridDim.x, ++it) {
-      const float* Zb = Zs + (it & 1) * NT * kBwdRows * 16;
+      const bool has_next = tile + gridDim.x < n_tiles;                      // wave-uniform
+      if (it == 1) BR_STAMP(6);
+      if (it > 0) multiply(Zs + ((it - 1) & 1) * NT * kBwdRows * 16);        // tile it-1: its dz and its T(x) are complete
+      if (it == 1) BR_STAMP(7);      // first product done
       if (q_live) {
-        // ---- T(x) = BN affine + keep bits -> Xs[k-tile][row][16] ----
+        // ---- T(x) = BN affine + keep bits -> Xs[k-tile][row][16] (free again: the product above was its last reader) ----
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const uint32_t p0 = 4u * lc;
@@ -323,33 +403,14 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           }
           *reinterpret_cast<float4*>(Xw + ((lc >> 2) * kBwdRows + lr + 8 * i) * 16 + 4 * ((lc & 3) ^ (((lr + 8 * i) >> 2) & 3))) = t;
         }
-        if (tile + gridDim.x < n_tiles) load_x(tile + gridDim.x);     // next tile's x in flight during the MFMAs
+        if (has_next) load_x(tile + gridDim.x);            // next tile's x in flight (issuing these between the product's k-steps was
+                                                           // tried: each costs the wave ~600 cycles at the issue port either way)
       }
-      __syncthreads();                                   // Zs[it & 1] complete (Xs is this wave's own)
-      if (q_live) {
-        // ---- dW[32 x N] += T(x)^T · dz: contraction over the 64 rows, k-step s <-> rows 4s+g ----
-#pragma unroll 4
-        for (int s = 0; s < kBwdRows / 4; ++s) {
-          const int r = 4 * s + g;
-          const int cs = bwd_swz(c16, s);                  // (r >> 2) & 3 == s & 3
-          const float a0 = Xw[r * 16 + cs], a1 = Xw[(kBwdRows + r) * 16 + cs];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float b = Zb[(nt * kBwdRows + r) * 16 + cs];
-            acc[0][nt] = mfma16b(a0, b, acc[0][nt]);
-            if (2 * q + 1 < KT) acc[1][nt] = mfma16b(a1, b, acc[1][nt]);
-          }
-        }
-      }
-      // ---- db: column sums of dz (lane -> one column, half of the rows) ----
-      if (db_live) {
-        float s0 = 0.f;
-        const float* zc = Zb + ((dbcol >> 4) * kBwdRows + 32 * dbh) * 16;
-#pragma unroll 8
-        for (int r = 0; r < 32; ++r) s0 += zc[r * 16 + bwd_swz(dbcol & 15, r >> 2)];
-        dbacc += s0;
-      }
+      BR_STAMP(4);      // first T(x) written
+      __syncthreads();                                   // S_it: Zs[it & 1] complete (Xs is this wave's own)
+      BR_STAMP(5);      // first barrier passed
     }
+    if (it > 0) multiply(Zs + ((it - 1) & 1) * NT * kBwdRows * 16);          // the last tile
     // ---- the workgroup's slab: [dW (K x N) | db (N)], scaled by 1/(1-p) (folded out of T()) ----
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_elems;
     if (q_live) {
@@ -373,6 +434,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
       if (db_live && dbh == 0 && dbcol < N) slab[a.db_off + dbcol] = tot;
     }
   }
+  BR_STAMP(8);
   if (IBN && a.in_sums) {
     __syncthreads();
     double* rep = a.in_sums + (size_t)(blockIdx.x % kBwdRep) * 2 * K;
@@ -381,6 +443,8 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
       atomicAdd(rep + K + k, red[Kp + k]);
     }
   }
+  BR_STAMP_RT(11);
+  BR_STAMP_FLUSH(blockIdx.x * 8 + wave);
 }
 
 }  // namespace br

@@ -25,44 +25,13 @@
 #include <stdlib.h>
 #include "philox.h"
 #include "dense.h"
+#include "stamps.h"
 
 namespace br {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kRep = BR_STAT_REPLICAS;
-
-// In-kernel stamps of the diagnostic build (tools/diag/: this file compiled with -DBR_STAMPS into a test binary of its
-// own; MI355X guide "In-kernel stamps").  No stamp exists in the product build.
-#ifdef BR_STAMPS
-constexpr int kStampSlots = 12;
-__device__ unsigned long long* g_stamp_buf = nullptr;
-#define BR_STAMP_DECL unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define BR_STAMP(i)                                                                             \
-  do {                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-    unsigned long long t_;                                                                      \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
-    if (stamps_[i] == 0) stamps_[i] = t_;                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-  } while (0)
-#define BR_STAMP_RT(i)                                                                          \
-  do {                                                                                          \
-    unsigned long long t_;                                                                      \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-    stamps_[i] = t_;                                                                            \
-  } while (0)
-#define BR_STAMP_FLUSH(widx)                                                                    \
-  do {                                                                                          \
-    if ((threadIdx.x & 63) == 0 && g_stamp_buf)                                                 \
-      for (int i_ = 0; i_ < kStampSlots; ++i_) g_stamp_buf[(size_t)(widx) * kStampSlots + i_] = stamps_[i_]; \
-  } while (0)
-#else
-#define BR_STAMP_DECL
-#define BR_STAMP(i)
-#define BR_STAMP_RT(i)
-#define BR_STAMP_FLUSH(widx)
-#endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
