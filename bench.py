@@ -122,15 +122,21 @@ def time_us(fn, reps=20, rounds=5):
     return s.elapsed_time(e) * 1e3 / (reps * rounds), mode
 
 
-def loop_ms(step, n=30, warm=5):
+def loop_ms(step, n=20, warm=5, windows=3):
+    """ms per call of an eager step: the best of `windows` back-to-back windows of n calls (a shared box shows one-off hiccups of tens of
+    milliseconds - allocator / clock / neighbours - that a single mean would fold into every step)"""
     for _ in range(warm):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    best = None
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        best = dt if best is None else min(best, dt)
+    return best
 
 
 def gather_leg(ops, dev, U, I, D, B, seed):
