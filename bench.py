@@ -395,7 +395,11 @@ def main():
         "SMALL": (("bn / small (each)", "-", None, None), ("BNG",)),
     }
     use_graph = ctx is None and not args.no_graph
-    run_steps(eng, batches, args.warmup, row0, batch_total)   # warm-up outside the probe
+    # warm-up outside the probe, at least one pass over the batch cycle: the tables are then in the state of a RUNNING job (every row of
+    # the cycle carries moments and a lag).  On fresh tables (m = v = 0) the deferred kernels skip their replay arithmetic and look
+    # ~30 % faster than they are in steady state.
+    prime = max(args.warmup, n_batches if deferred_mode else 0)
+    run_steps(eng, batches, prime, row0, batch_total)
     pyprobe = None
     eager_profile = None
     graph_error = None

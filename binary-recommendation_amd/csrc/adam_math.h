@@ -98,6 +98,21 @@ __device__ __forceinline__ void adam_replay(V& th, V& m, V& v, uint32_t from, ui
   for (uint32_t j = from + 1; j <= upto; ++j) adam_decay(th, m, v, ring[j & (BR_ALPHA_RING - 1)], h);
 }
 
+// the same replay when `from` / `upto` are WAVE-UNIFORM (one row per wave): alpha comes through scalar loads from the ring in global
+// memory, requested one step ahead (no LDS image per workgroup), and a row nobody has touched yet (m == v == 0 in every lane) is
+// skipped by a scalar branch.  No per-lane skip: a lane with m == v == 0 runs theta = fma(-0, 1/eps, theta) = theta, the same bits.
+template <typename V>
+__device__ __forceinline__ void adam_replay_uniform(V& th, V& m, V& v, uint32_t from, uint32_t upto, const StepStateDev* __restrict__ ss,
+                                                    const AdamHp& h) {
+  if (__builtin_amdgcn_ballot_w64(!(all_zero(m) && all_zero(v))) == 0) return;
+  float a = ss->alpha_hist[(from + 1) & (BR_ALPHA_RING - 1)];
+  for (uint32_t j = from + 1; j <= upto; ++j) {
+    const float an = ss->alpha_hist[(j + 1) & (BR_ALPHA_RING - 1)];
+    adam_decay(th, m, v, a, h);
+    a = an;
+  }
+}
+
 // whole workgroup: copy the ring into LDS (call before any early return; ends with a barrier)
 __device__ __forceinline__ void stage_alpha_ring(float* lds_ring, const StepStateDev* ss) {
   for (int k = threadIdx.x; k < BR_ALPHA_RING; k += blockDim.x) lds_ring[k] = ss->alpha_hist[k];

@@ -35,6 +35,8 @@ struct AdamPairCall {
   const float* grads_hi_b; int64_t ldg_hi_b; uint8_t* mark_b; int32_t* last_b;
   int dim, id_type; int64_t n; int split; const float* hi_scale; const void* step_state; double alpha_t, beta1, beta2, eps;
   float *seg_ws_a, *seg_ws_b;
+  // deferred tables: the rows as the step's lookup replayed them, by position (columns [0,split) | [split,dim)), or null
+  const float *th_lo_a = nullptr, *th_hi_a = nullptr, *th_lo_b = nullptr, *th_hi_b = nullptr; int64_t ld_th = 0;
 };
 int adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream);
 

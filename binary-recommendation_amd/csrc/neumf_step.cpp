@@ -331,7 +331,9 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
           deferred ? s->user_last : nullptr,
           s->item_tab, s->item_m, s->item_v, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->dx0 + ioff, 2 * D, (fuse_mf ? s->g_user : s->g_item) + D, 2 * D, im,
           deferred ? s->item_last : nullptr, 2 * D, s->id_type, B, D, fuse_mf ? s->ddot : nullptr, s->step_state, s->alpha_t, s->beta1, s->beta2, s->adam_eps,
-          s->u_seg_ws, s->i_seg_ws};
+          s->u_seg_ws, s->i_seg_ws,
+          // the rows as this step's lookup replayed them: MLP halves in x0, MF halves in the stashes (both untouched since)
+          fuse_mf ? s->x0 + uoff : nullptr, fuse_mf ? s->g_user + D : nullptr, fuse_mf ? s->x0 + ioff : nullptr, fuse_mf ? s->g_item + D : nullptr, 2 * D};
       RUN(BR_TAG_ADAM_ROWS_USER, br::adam_rows_pair_keep(pc, prefetch_fused ? &next_keep : nullptr, stream));
     } else if ((ph & BR_PH_ROWS_USER) && deferred) {
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type,

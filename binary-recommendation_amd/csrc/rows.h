@@ -34,8 +34,12 @@ __device__ __forceinline__ float vadd(float a, float b) { return a + b; }
 __device__ __forceinline__ float4 vsub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float2 vsub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float vsub(float a, float b) { return a - b; }
-__device__ __forceinline__ float vdot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ float vdot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
+// the order is spelled out (one product, then fused multiply-adds in column order): kernels with different lane layouts reproduce
+// it and give the same bits (neumf_embed_fwd_deferred_wave_kernel chains it across two lanes)
+__device__ __forceinline__ float vdot(float4 a, float4 b) {
+  return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ float vdot(float2 a, float2 b) { return __builtin_fmaf(a.y, b.y, a.x * b.x); }
 __device__ __forceinline__ float vdot(float a, float b) { return a * b; }
 
 // Host-side geometry of a row group for a given embedding dim.

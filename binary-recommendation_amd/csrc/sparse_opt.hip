@@ -181,6 +181,11 @@ struct AdamRowsJob {
   const float* sc1;           // per-position factor of g1 rows, or null
   const float* part;          // segment partials of this table's gradient source (NULL: one-by-one walk)
   uint8_t* mark; int32_t* last;
+  // deferred mode, optional: the row as the step's lookup replayed it (theta at step t-1), per POSITION - columns [0,split) at
+  // th0 + pos*ldt0, [split,dim) at th1 + pos*ldt1.  With it the optimizer replays only m and v (two multiplies per step) instead of
+  // repeating the lookup's sqrt / rcp chain on theta: same bits (the lookup ran adam_replay on the same stored row).
+  const float* th0 = nullptr; int64_t ldt0 = 0;
+  const float* th1 = nullptr; int64_t ldt1 = 0;
 };
 struct AdamRowsJobs { AdamRowsJob j[2]; };
 
@@ -241,6 +246,51 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs
     vstore<VEC>(Vv + off, v);
   }
   if (last && lir == 0) last[row] = (int32_t)t;
+}
+
+// The same update with one WAVE per sorted position, for rows of 64 * VEC floats (the fused [mlp | mf] rows of embed_dim 32 / 64 / 128):
+// a lane owns VEC consecutive columns, so everything that depends on the position - head test, id, duplicate walk, the row's lag in
+// deferred mode - is wave-uniform (scalar loads and branches; the row-group form above runs two or four rows with different lags per
+// wave and every lane waits for the longest).  Deferred mode takes theta as the lookup replayed it (AdamRowsJob::th0 / th1) and
+// replays m and v only: no alpha ring, no sqrt / rcp per replayed step.
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, int64_t n, int split, AdamHp h, const StepStateDev* __restrict__ ss) {
+  using V = typename VecT<VEC>::type;
+  constexpr int dim = 64 * VEC;
+  const AdamRowsJob& jb = jobs.j[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (i >= n) return;
+  const IdT* __restrict__ sid = (const IdT*)jb.sid;
+  const int32_t* __restrict__ spos = jb.spos;
+  const IdT rid = sid[i];
+  if (i > 0 && sid[i - 1] == rid) return;
+  const int64_t row = (int64_t)rid;
+  if ((uint64_t)row >= (uint64_t)jb.table_rows) return;  // out-of-range ids were flagged by the forward
+  adam_resolve(h);
+  const int lane = (int)(threadIdx.x & 63);
+  const int col = lane * VEC;
+  const bool lo = col < split;
+  const int64_t off = row * dim + col;
+  int32_t* __restrict__ last = jb.last;
+  const int64_t pos = (int64_t)spos[i];
+  // the row's own loads first: they do not depend on the duplicate walk
+  V m = vload<VEC>(jb.M + off), v = vload<VEC>(jb.Vv + off);
+  const float* thp = jb.th0 ? (lo ? jb.th0 + pos * jb.ldt0 + col : jb.th1 + pos * jb.ldt1 + (col - split)) : jb.table + off;
+  V th = vload<VEC>(thp);
+  uint32_t t = 0, seen = 0;
+  if (last) { t = ss->step; seen = (uint32_t)last[row]; }
+  const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, rid, lo ? jb.g0 + col : jb.g1 + (col - split), lo ? jb.ldg0 : jb.ldg1, lo ? nullptr : jb.sc1,
+                                  jb.part ? jb.part + col : nullptr, dim);
+  // deferred: the g = 0 steps (seen, t-1] of the moments (adam_decay's first two products; theta came replayed)
+  for (uint32_t j = seen + 1; j < t; ++j) { m = vmul(m, h.b1); v = vmul(v, h.b2); }
+  adam_update(th, m, v, acc, h);
+  vstore<VEC>(jb.table + off, th);
+  vstore<VEC>(jb.M + off, m);
+  vstore<VEC>(jb.Vv + off, v);
+  if (lane == 0) {
+    if (jb.mark) jb.mark[row] = 1;
+    if (last) last[row] = (int32_t)t;
+  }
 }
 
 // Deferred mode, whole table: bring every row up to the current step (inclusive) — before the table is
@@ -664,7 +714,14 @@ struct AdamRowsArgs {      // one table's host-side arguments
   uint8_t* mark; int32_t* last;
   float* seg_ws;
   const float* hi_scale = nullptr;     // per-position factor of the row_grads_hi rows
+  const float* th_lo = nullptr; const float* th_hi = nullptr; int64_t ld_th = 0;   // replayed theta by position (AdamRowsJob::th0 / th1)
 };
+
+// BR_WAVE_ROWS=0: keep the row-group kernels (A/B runs)
+static bool wave_rows_enabled() {
+  static const bool on = [] { const char* e = getenv("BR_WAVE_ROWS"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_type, int64_t n, int split, double alpha_t, double beta1,
                             double beta2, double eps, const StepStateDev* ss, brStream stream, const KeepArgs* keep = nullptr) {
@@ -672,8 +729,8 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   if (n == 0) return BR_OK;
   AdamRowsJobs jobs;
   SegJob segs[2];
-  bool with_partials = true;
-  int64_t ldmin = 4;
+  bool with_partials = true, all_stashed = true;
+  int64_t ldmin = 4, th_min = 4;
   for (int q = 0; q < n_jobs; ++q) {
     AdamRowsArgs t = a[q];
     BR_CHECK_ARG(t.table && t.m && t.v && t.sorted_ids && t.sorted_pos && t.row_grads && dim >= 1 && t.table_rows > 0, "brAdamRowsSorted: bad args");
@@ -686,6 +743,14 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     ldmin = lm < ldmin ? lm : ldmin;
     jobs.j[q] = AdamRowsJob{t.table, t.m, t.v, t.table_rows, t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.hi_scale,
                             t.seg_ws, t.mark, t.last};
+    if (t.th_lo && t.th_hi && t.last) {
+      const uintptr_t ta = reinterpret_cast<uintptr_t>(t.th_lo) | reinterpret_cast<uintptr_t>(t.th_hi);
+      const int64_t tm = (t.ld_th % 4 == 0 && (ta & 15) == 0) ? 4 : (t.ld_th % 2 == 0 && (ta & 7) == 0) ? 2 : 1;
+      th_min = tm < th_min ? tm : th_min;
+      jobs.j[q].th0 = t.th_lo; jobs.j[q].ldt0 = t.ld_th; jobs.j[q].th1 = t.th_hi; jobs.j[q].ldt1 = t.ld_th;
+    } else if (t.last) {
+      all_stashed = false;
+    }
     segs[q] = SegJob{t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws, t.hi_scale};
     with_partials = with_partials && t.seg_ws != nullptr;
   }
@@ -698,6 +763,22 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     if (rc != BR_OK) return rc;
     probe_split(BR_TAG_SEG_PARTIALS, (hipStream_t)stream);
   }
+  hipStream_t s = (hipStream_t)stream;
+  AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
+  if (ss) h.alpha_ptr = &ss->alpha_t;
+  // rows of 64 / 128 / 256 floats: one wave per sorted position (deferred tables only with the lookup's replayed theta at hand)
+  const int wvec = dim / 64;
+  if (wave_rows_enabled() && !(keep && keep->batch > 0) && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ldmin >= wvec && th_min >= wvec &&
+      all_stashed) {
+    const dim3 wgrid((unsigned)ceil_div(n, 4), (unsigned)n_jobs);
+    if (id_type == BR_IDS_I32)
+      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int32_t, VEC><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
+    else
+      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int64_t, VEC><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
+    BR_CHECK_LAUNCH("brAdamRowsSorted(wave)");
+    return BR_OK;
+  }
+  for (int q = 0; q < 2; ++q) { jobs.j[q].th0 = jobs.j[q].th1 = nullptr; }
   KeepFuse kf;
   kf.total = 0; kf.blocks[0] = kf.blocks[1] = kf.blocks[2] = 0;
   int keep_x = 0;
@@ -709,9 +790,6 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     kf.a = KeepArgs{};
   }
   const dim3 grid((unsigned)(ceil_div(n, 256 >> g.lpr_log2) + keep_x), (unsigned)n_jobs);
-  AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
-  if (ss) h.alpha_ptr = &ss->alpha_t;
-  hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(g.vec, (adam_rows_sorted_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(jobs, dim, g.chunks, g.lpr_log2, n, split, h, ss, kf, keep_x)));
   else
@@ -754,8 +832,10 @@ extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int6
 int br::adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream) {
   BR_CHECK_ARG((c.last_a == nullptr) == (c.last_b == nullptr) && (c.last_a == nullptr || c.step_state), "brAdamRowsSortedPair: last arrays for both tables (with step_state) or neither");
   BR_CHECK_ARG(c.grads_hi_a && c.grads_hi_b, "brAdamRowsSortedPair: both gradient halves required");
-  const AdamRowsArgs a[2] = {{c.table_a, c.m_a, c.v_a, c.rows_a, c.sorted_ids_a, c.sorted_pos_a, c.grads_a, c.ldg_a, c.grads_hi_a, c.ldg_hi_a, c.mark_a, c.last_a, c.seg_ws_a, c.hi_scale},
-                             {c.table_b, c.m_b, c.v_b, c.rows_b, c.sorted_ids_b, c.sorted_pos_b, c.grads_b, c.ldg_b, c.grads_hi_b, c.ldg_hi_b, c.mark_b, c.last_b, c.seg_ws_b, c.hi_scale}};
+  const AdamRowsArgs a[2] = {{c.table_a, c.m_a, c.v_a, c.rows_a, c.sorted_ids_a, c.sorted_pos_a, c.grads_a, c.ldg_a, c.grads_hi_a, c.ldg_hi_a, c.mark_a, c.last_a, c.seg_ws_a, c.hi_scale,
+                              c.th_lo_a, c.th_hi_a, c.ld_th},
+                             {c.table_b, c.m_b, c.v_b, c.rows_b, c.sorted_ids_b, c.sorted_pos_b, c.grads_b, c.ldg_b, c.grads_hi_b, c.ldg_hi_b, c.mark_b, c.last_b, c.seg_ws_b, c.hi_scale,
+                              c.th_lo_b, c.th_hi_b, c.ld_th}};
   return adam_rows_launch(a, 2, c.dim, c.id_type, c.n, c.split, c.alpha_t, c.beta1, c.beta2, c.eps, c.last_a ? (const StepStateDev*)c.step_state : nullptr, stream, keep);
 }
 
