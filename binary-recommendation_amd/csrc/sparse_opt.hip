@@ -91,15 +91,30 @@ __device__ __forceinline__ int64_t seg_walk(typename VecT<VEC>::type& acc, const
 }
 
 template <typename IdT, int VEC>
+__device__ __forceinline__ void seg_acc_from(typename VecT<VEC>::type& acc, const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n,
+                                             int64_t i, int64_t j, IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc,
+                                             const float* __restrict__ part, int pdim);
+
+template <typename IdT, int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type seg_acc(const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n, int64_t i,
                                                             IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc,
                                                             const float* __restrict__ part, int pdim) {
   using V = typename VecT<VEC>::type;
   V acc = grow<VEC>(g, ldg, sc, spos[i]);
+  seg_acc_from<IdT, VEC>(acc, sid, spos, n, i, i + 1, row, g, ldg, sc, part, pdim);
+  return acc;
+}
+
+// the rest of a head's sum from position j on (everything in [i, j) is already in acc, in order)
+template <typename IdT, int VEC>
+__device__ __forceinline__ void seg_acc_from(typename VecT<VEC>::type& acc, const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n,
+                                             int64_t i, int64_t j, IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc,
+                                             const float* __restrict__ part, int pdim) {
+  using V = typename VecT<VEC>::type;
   const int64_t own_end = part ? ((i / kSegBlock + 1) * kSegBlock < n ? (i / kSegBlock + 1) * kSegBlock : n) : n;
   // (W = 1 here: the optimizer launches that inline this are bound by HBM latency at 8 waves / SIMD - the registers of a batched walk
   //  cost them more on ordinary batches than they save on hot ids; the long runs are cut to <= 63 positions by the partials)
-  int64_t j = seg_walk<IdT, VEC, 1>(acc, sid, spos, i + 1, own_end, row, g, ldg, sc);
+  j = seg_walk<IdT, VEC, 1>(acc, sid, spos, j, own_end, row, g, ldg, sc);
   if (part && j == own_end) {
     // one partial per later block of the run, four at a time (same order of additions)
     for (; j + 3 * kSegBlock < n && sid[j + 3 * kSegBlock] == row; j += 4 * kSegBlock) {
@@ -109,7 +124,6 @@ __device__ __forceinline__ typename VecT<VEC>::type seg_acc(const IdT* __restric
     }
     for (; j < n && sid[j] == row; j += kSegBlock) acc = vadd(acc, vload<VEC>(part + (j / kSegBlock) * pdim));
   }
-  return acc;
 }
 
 struct SegJob {                // one table's gradient source for the partials
@@ -248,48 +262,162 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs
   if (last && lir == 0) last[row] = (int32_t)t;
 }
 
-// The same update with one WAVE per sorted position, for rows of 64 * VEC floats (the fused [mlp | mf] rows of embed_dim 32 / 64 / 128):
-// a lane owns VEC consecutive columns, so everything that depends on the position - head test, id, duplicate walk, the row's lag in
-// deferred mode - is wave-uniform (scalar loads and branches; the row-group form above runs two or four rows with different lags per
-// wave and every lane waits for the longest).  Deferred mode takes theta as the lookup replayed it (AdamRowsJob::th0 / th1) and
-// replays m and v only: no alpha ring, no sqrt / rcp per replayed step.
-template <typename IdT, int VEC>
+__constant__ float kOneF = 1.f;
+__constant__ int32_t kZeroI = 0;
+// A kernel-argument pointer held in scalar registers from here on, typed as a GLOBAL pointer (behind the asm the compiler no longer
+// knows where it came from and would fall back to flat loads, which also count on lgkmcnt: every scalar-load wait would drain them).
+typedef __attribute__((address_space(1))) const float gcf;
+typedef __attribute__((address_space(1))) float gwf;
+typedef __attribute__((address_space(1))) const int32_t gci32;
+typedef __attribute__((address_space(1))) int32_t gwi32;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BR_PIN_S(x) asm volatile("" : "+s"(x))
+#define BR_PIN_V(x) asm volatile("" : "+v"(x))
+#else          // the host pass parses device functions too and knows no "s" / "v" registers
+#define BR_PIN_S(x) (void)(x)
+#define BR_PIN_V(x) (void)(x)
+#endif
+__device__ __forceinline__ gcf* sgpr_g(const float* x) { gcf* y = (gcf*)x; BR_PIN_S(y); return y; }
+__device__ __forceinline__ gwf* sgpr_g(float* x) { gwf* y = (gwf*)x; BR_PIN_S(y); return y; }
+__device__ __forceinline__ gwi32* sgpr_g(int32_t* x) { gwi32* y = (gwi32*)x; BR_PIN_S(y); return y; }
+__device__ __forceinline__ int64_t sgpr(int64_t x) { BR_PIN_S(x); return x; }
+// (the HIP vector classes have no constructors from address-space-qualified objects: go through the native vector types)
+template <int VEC> struct NatV { typedef float type __attribute__((ext_vector_type(VEC))); };
+template <> struct NatV<1> { typedef float type; };
+__device__ __forceinline__ float from_nat(float a) { return a; }
+__device__ __forceinline__ float2 from_nat(NatV<2>::type a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float4 from_nat(NatV<4>::type a) { return make_float4(a.x, a.y, a.z, a.w); }
+__device__ __forceinline__ float to_nat(float a) { return a; }
+__device__ __forceinline__ NatV<2>::type to_nat(float2 a) { NatV<2>::type r = {a.x, a.y}; return r; }
+__device__ __forceinline__ NatV<4>::type to_nat(float4 a) { NatV<4>::type r = {a.x, a.y, a.z, a.w}; return r; }
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type gvload(gcf* p) {
+  typedef __attribute__((address_space(1))) const typename NatV<VEC>::type GV;
+  const typename NatV<VEC>::type r = *(GV*)p;
+  return from_nat(r);
+}
+template <int VEC>
+__device__ __forceinline__ void gvstore(gwf* p, typename VecT<VEC>::type v) {
+  typedef __attribute__((address_space(1))) typename NatV<VEC>::type GV;
+  *(GV*)p = to_nat(v);
+}
+
+// a use the compiler cannot move or drop: the value has to be in its registers here (all loads issued above are waited for at once)
+__device__ __forceinline__ void pin(float& a) { BR_PIN_V(a); }
+__device__ __forceinline__ void pin(float2& a) { BR_PIN_V(a.x); BR_PIN_V(a.y); }
+__device__ __forceinline__ void pin(float4& a) { BR_PIN_V(a.x); BR_PIN_V(a.y); BR_PIN_V(a.z); BR_PIN_V(a.w); }
+
+// The same update with one WAVE per row, for rows of 64 * VEC floats (the fused [mlp | mf] rows of embed_dim 32 / 64 / 128): a lane
+// owns VEC consecutive columns, so everything that depends on the position - head test, id, duplicate walk, the row's lag in deferred
+// mode - is wave-uniform (scalar loads and branches; the row-group form above runs two or four rows with different lags per wave and
+// every lane waits for the longest).  A wave takes a STRIP of S consecutive sorted positions: one round trip for the strip's ids and
+// positions, then every row load of the strip's heads (m, v, theta) and every gradient row a head of the strip can need are requested
+// before the first is used - S rows of 3.5 KB in flight per wave instead of one, which is what an HBM-latency-bound gather / scatter
+// of 512-B rows needs - and a head finds its duplicates inside the strip already in registers (added in position order, as seg_acc
+// does; a run that leaves the strip continues through seg_acc_from).  Deferred mode takes theta as the lookup replayed it
+// (AdamRowsJob::th0 / th1) and replays m and v only: no alpha ring, no sqrt / rcp per replayed step.
+template <typename IdT, int VEC, int S>
 __global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, int64_t n, int split, AdamHp h, const StepStateDev* __restrict__ ss) {
   using V = typename VecT<VEC>::type;
   constexpr int dim = 64 * VEC;
+  static_assert(kSegBlock % S == 0, "a strip stays inside one partial block");
   const AdamRowsJob& jb = jobs.j[blockIdx.y];
-  const int64_t i = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (i >= n) return;
+  const int64_t base = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * S;
+  if (base >= n) return;
   const IdT* __restrict__ sid = (const IdT*)jb.sid;
   const int32_t* __restrict__ spos = jb.spos;
-  const IdT rid = sid[i];
-  if (i > 0 && sid[i - 1] == rid) return;
-  const int64_t row = (int64_t)rid;
-  if ((uint64_t)row >= (uint64_t)jb.table_rows) return;  // out-of-range ids were flagged by the forward
+  // round 1: the strip's ids / positions (+ the predecessor's id)
+  IdT id[S];
+  int64_t pos[S];
+  const IdT prev = sid[base > 0 ? base - 1 : 0];
+#pragma unroll
+  for (int e = 0; e < S; ++e) {
+    const int64_t q = base + e < n ? base + e : n - 1;
+    id[e] = sid[q];
+    pos[e] = (int64_t)spos[q];
+  }
+  bool head[S], live[S], need_g[S];
+  bool any = false;
+#pragma unroll
+  for (int e = 0; e < S; ++e) {
+    const bool in = base + e < n;
+    head[e] = in && (e == 0 ? (base == 0 || prev != id[0]) : id[e] != id[e - 1]);
+    live[e] = head[e] && (uint64_t)(int64_t)id[e] < (uint64_t)jb.table_rows;   // out-of-range ids were flagged by the forward
+    any = any || head[e];
+    need_g[e] = in && any;          // a position before the strip's first head belongs to an earlier strip's head
+  }
+  if (!any) return;
   adam_resolve(h);
   const int lane = (int)(threadIdx.x & 63);
   const int col = lane * VEC;
   const bool lo = col < split;
-  const int64_t off = row * dim + col;
-  int32_t* __restrict__ last = jb.last;
-  const int64_t pos = (int64_t)spos[i];
-  // the row's own loads first: they do not depend on the duplicate walk
-  V m = vload<VEC>(jb.M + off), v = vload<VEC>(jb.Vv + off);
-  const float* thp = jb.th0 ? (lo ? jb.th0 + pos * jb.ldt0 + col : jb.th1 + pos * jb.ldt1 + (col - split)) : jb.table + off;
-  V th = vload<VEC>(thp);
-  uint32_t t = 0, seen = 0;
-  if (last) { t = ss->step; seen = (uint32_t)last[row]; }
-  const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, rid, lo ? jb.g0 + col : jb.g1 + (col - split), lo ? jb.ldg0 : jb.ldg1, lo ? nullptr : jb.sc1,
-                                  jb.part ? jb.part + col : nullptr, dim);
-  // deferred: the g = 0 steps (seen, t-1] of the moments (adam_decay's first two products; theta came replayed)
-  for (uint32_t j = seen + 1; j < t; ++j) { m = vmul(m, h.b1); v = vmul(v, h.b2); }
-  adam_update(th, m, v, acc, h);
-  vstore<VEC>(jb.table + off, th);
-  vstore<VEC>(jb.M + off, m);
-  vstore<VEC>(jb.Vv + off, v);
-  if (lane == 0) {
-    if (jb.mark) jb.mark[row] = 1;
-    if (last) last[row] = (int32_t)t;
+  // the job's fields as scalars first (a per-lane choice between two fields of the argument block would otherwise be compiled into a
+  // per-lane LOAD of the chosen field: a dependent vector load in front of everything)
+  gcf* g0 = sgpr_g(jb.g0); gcf* g1 = sgpr_g(jb.g1);
+  const int64_t ldg0 = sgpr(jb.ldg0), ldg1 = sgpr(jb.ldg1);
+  gcf* t0 = sgpr_g(jb.th0); gcf* t1 = sgpr_g(jb.th1);
+  const int64_t ldt0 = sgpr(jb.ldt0), ldt1 = sgpr(jb.ldt1);
+  gwf* const tab = sgpr_g(jb.table); gwf* const Mp = sgpr_g(jb.M); gwf* const Vp = sgpr_g(jb.Vv);
+  gcf* sc = sgpr_g(jb.sc1);
+  gwi32* const last = sgpr_g(jb.last);
+  gcf* gp = lo ? g0 + col : g1 + (col - split);
+  const int64_t ldg = lo ? ldg0 : ldg1;
+  const bool stashed = t0 != nullptr;
+  gcf* tp = lo ? t0 + col : t1 + (col - split);
+  const int64_t ldt = lo ? ldt0 : ldt1;
+  // round 2: everything the strip needs, requested together.  Branch-free on purpose: behind scalar branches the compiler sinks each
+  // load to its first use and the wave is back to one row in flight.  A position that is no live head reads row 0 instead (the
+  // same three lines for everybody: cache hits), a position before the strip's first head its own gradient row (dropped).
+  V g[S], m[S], v[S], th[S];
+  float scale[S];
+  int32_t seen_v[S];               // last[row]: a vector load (the kernel writes the array, so no scalar cache) - uniform, read out below
+#pragma unroll
+  for (int e = 0; e < S; ++e) {
+    const int64_t row = live[e] ? (int64_t)id[e] : 0;
+    const int64_t off = row * dim + col;
+    g[e] = gvload<VEC>(gp + pos[e] * ldg);
+    scale[e] = *(sc ? sc + pos[e] : (gcf*)&kOneF);
+    m[e] = gvload<VEC>(Mp + off);
+    v[e] = gvload<VEC>(Vp + off);
+    th[e] = gvload<VEC>(stashed && live[e] ? tp + pos[e] * ldt : (gcf*)(tab + off));
+    seen_v[e] = *(last ? last + row : (gwi32*)&kZeroI);
+  }
+  const uint32_t t = last ? ss->step : 0u;
+  uint32_t seen[S];
+#pragma unroll
+  for (int e = 0; e < S; ++e) {                                               // one wait for the whole strip
+    pin(g[e]), pin(m[e]), pin(v[e]), pin(th[e]);
+    BR_PIN_V(seen_v[e]);
+    seen[e] = (uint32_t)__builtin_amdgcn_readfirstlane(seen_v[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < S; ++e)
+    if (!lo) g[e] = vmul(g[e], scale[e]);                      // the MF halves: stashed partner row times ddot[pos] (grow())
+#pragma unroll
+  for (int e = 0; e < S; ++e) {
+    if (!live[e]) continue;
+    const int64_t i = base + e;
+    V acc = g[e];
+    bool open = true;                                          // the run is still going at the strip's end
+#pragma unroll
+    for (int f = e + 1; f < S; ++f) {
+      open = open && base + f < n && !head[f];
+      if (open) acc = vadd(acc, g[f]);
+    }
+    if (open && base + S < n)
+      seg_acc_from<IdT, VEC>(acc, sid, spos, n, i, base + S, id[e], (const float*)gp, ldg, lo ? nullptr : (const float*)sc, jb.part ? jb.part + col : nullptr, dim);
+    // deferred: the g = 0 steps (seen, t-1] of the moments (adam_decay's first two products; theta came replayed)
+    V mm = m[e], vv = v[e], tt = th[e];
+    for (uint32_t j = seen[e] + 1; j < t; ++j) { mm = vmul(mm, h.b1); vv = vmul(vv, h.b2); }
+    adam_update(tt, mm, vv, acc, h);
+    const int64_t off = (int64_t)id[e] * dim + col;
+    gvstore<VEC>(tab + off, tt);
+    gvstore<VEC>(Mp + off, mm);
+    gvstore<VEC>(Vp + off, vv);
+    if (lane == 0) {
+      if (jb.mark) jb.mark[(int64_t)id[e]] = 1;
+      if (last) last[(int64_t)id[e]] = (int32_t)t;
+    }
   }
 }
 
@@ -770,11 +898,12 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   const int wvec = dim / 64;
   if (wave_rows_enabled() && !(keep && keep->batch > 0) && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ldmin >= wvec && th_min >= wvec &&
       all_stashed) {
-    const dim3 wgrid((unsigned)ceil_div(n, 4), (unsigned)n_jobs);
+    constexpr int kStrip = 4;
+    const dim3 wgrid((unsigned)ceil_div(n, 4 * kStrip), (unsigned)n_jobs);
     if (id_type == BR_IDS_I32)
-      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int32_t, VEC><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
+      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int32_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
     else
-      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int64_t, VEC><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
+      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int64_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
     BR_CHECK_LAUNCH("brAdamRowsSorted(wave)");
     return BR_OK;
   }
