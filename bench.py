@@ -366,8 +366,12 @@ def main():
     rows_pair = 8 + 2 * D * 4 + (4 if fused_rows else 0)            # sorted id + position, one 2D-float gradient row (+ ddot)
     per_uniq = 6 * 2 * D * 4 + (8 if deferred_mode else 0)           # table, m, v rows read and written (+ last[])
     ROWS_ALL = ("OPT_TABLES", "ROWS_USER", "SWEEP_USER", "ROWS_ITEM", "SWEEP_ITEM")
+    # riders of the pair launch (single GPU, dropout on): the next step's keep-bit planes written + the dense finalize's slabs read and
+    # theta / m / v / grad of the dense vector updated - their algorithmic bytes count towards that launch
+    riders = deferred_mode and ctx is None and eng.cfg.dropout > 0 and os.environ.get("BR_KEEP_PREFETCH", "2") == "2"
+    rider_bytes = (B * 4 * sum((w + 31) // 32 for w in (2 * D, n1, n2)) + 4 * int(eng.slabs.numel()) + 7 * 4 * int(eng.theta.buf.numel())) if riders else 0
     SPEC = {
-        "EMBED_FWD": (("neumf_embed_fwd_deferred (4 lookups + replay of lagging rows + GMF dot + concat)", "neumf_embed_fwd_deferred_kernel", "hbm",
+        "EMBED_FWD": (("neumf_embed_fwd_deferred (4 lookups + replay of lagging rows + GMF dot + concat)", "neumf_embed_fwd_deferred_wave_kernel", "hbm",
                        B * (4 * D * 4 + 2 * D * 4 + 2 * D * 4 + 12)) if deferred_mode and ctx is None else
                       ("neumf_embed_fwd (4 lookups + GMF dot + concat)", "neumf_embed_fwd_kernel", "hbm", B * (4 * D * 4 + 2 * D * 4 + 12)), ("FWD1",)),
         "EMBED_BWD": (("mf_grad_inplace" if deferred_mode and ctx is None else "neumf_embed_bwd", "neumf_embed_bwd_kernel", "hbm", B * (4 * D * 4 + 8)), ("OPT_TABLES",)),
@@ -385,7 +389,8 @@ def main():
         "INDEX_USER": (("row index, both tables: chunk rank / merge", "chunk_rank_kernel", None, None), ("FWD1",)),
         "INDEX_ITEM": (("row index [item]", "chunk_rank_kernel", None, None), ("FWD1",)),
         "SEG_PARTIALS": (("segment partial sums of long duplicate runs (both tables)", "segment_partials_kernel", None, None), ROWS_ALL),
-        "ADAM_ROWS_USER": ((("adam_rows_sorted[user + item, one launch]", "adam_rows_sorted_kernel", "hbm", 2 * B * rows_pair + (uniq_u + uniq_i) * per_uniq) if ctx is None else
+        "ADAM_ROWS_USER": ((("adam_rows[user + item, one launch" + (" + riders: next step's keep-bit planes, dense finalize]" if riders else "]"),
+                             "adam_rows_wave_kernel", "hbm", 2 * B * rows_pair + (uniq_u + uniq_i) * per_uniq + rider_bytes) if ctx is None else
                             ("adam_rows_sorted[user]", "adam_rows_sorted_kernel", "hbm", B * rows_pair + uniq_u * per_uniq)), ROWS_ALL),
         "ADAM_ROWS_ITEM": (("adam_rows_sorted[item]", "adam_rows_sorted_kernel", "hbm", B * rows_pair + uniq_i * per_uniq), ROWS_ALL),
         "SWEEP_USER": ((f"adam_dense_sweep[user {loc_users}x{2 * D}]", "adam_dense_sweep_kernel", "hbm", 6 * 4 * loc_users * 2 * D), ("SWEEP_USER",)),

@@ -38,7 +38,9 @@ struct AdamPairCall {
   // deferred tables: the rows as the step's lookup replayed them, by position (columns [0,split) | [split,dim)), or null
   const float *th_lo_a = nullptr, *th_hi_a = nullptr, *th_lo_b = nullptr, *th_hi_b = nullptr; int64_t ld_th = 0;
 };
-int adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream);
+// fin != NULL: the launch may also carry the dense finalize as riders of its grid; *fin_done tells whether it did
+struct FinalArgs;
+int adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream, const FinalArgs* fin = nullptr, bool* fin_done = nullptr);
 
 int dense_backward_fused(const BwdArgs& a, hipStream_t s);    // BR_ERR_UNSUPPORTED when the LDS image does not fit
 int dense_bwd_fused_grid(int64_t batch);                      // workgroups = slabs written

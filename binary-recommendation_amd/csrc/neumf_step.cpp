@@ -1,6 +1,7 @@
 // brNeumfStepRun: the NeuMF step as one host call (launch sequencing only; see include/binrec.h).
 #include "common.h"
 #include "dense.h"
+#include "finalize.h"
 
 #include <vector>
 
@@ -334,7 +335,22 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
           s->u_seg_ws, s->i_seg_ws,
           // the rows as this step's lookup replayed them: MLP halves in x0, MF halves in the stashes (both untouched since)
           fuse_mf ? s->x0 + uoff : nullptr, fuse_mf ? s->g_user + D : nullptr, fuse_mf ? s->x0 + ioff : nullptr, fuse_mf ? s->g_item + D : nullptr, 2 * D};
-      RUN(BR_TAG_ADAM_ROWS_USER, br::adam_rows_pair_keep(pc, prefetch_fused ? &next_keep : nullptr, stream));
+      // keep_prefetch == 2: the next step's planes and the dense finalize ride in this launch's grid (no fork / join in the step)
+      br::FinalArgs fin;
+      bool fin_ok = false, fin_done = false;
+      if (prefetch_fused && (ph & BR_PH_OPT_DENSE) && fused_final) {
+        const float* const rs[3] = {slabs1, slabs2, slabs_t};
+        const int rn[3] = {sp.ns1, sp.ns2, sp.ns_t};
+        const int64_t re[3] = {sp.el1, sp.el2, sp.el_t}, ro[3] = {oW1, oW2, oW3};
+        const double* const bs[2] = {bsum1, bsum2};
+        const int bn_n[2] = {n1, n2};
+        const int64_t bg[2] = {og1, og2}, bb[2] = {obe1, obe2};
+        const int rc = br::make_final_args(fin, rs, rn, re, ro, bs, bn_n, bg, bb, th, s->adam_m, s->adam_v, gr, n_dense);
+        if (rc != BR_OK) return rc;
+        fin_ok = true;
+      }
+      RUN(BR_TAG_ADAM_ROWS_USER, br::adam_rows_pair_keep(pc, prefetch_fused ? &next_keep : nullptr, stream, fin_ok ? &fin : nullptr, &fin_done));
+      final_on_aux = final_on_aux || fin_done;
     } else if ((ph & BR_PH_ROWS_USER) && deferred) {
       RUN(BR_TAG_ADAM_ROWS_USER, brAdamRowsSortedDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->user_rows, 2 * D, s->u_sorted_ids, s->id_type,
                            s->u_sorted_pos, B, s->dx0 + uoff, 2 * D, s->g_user + D, 2 * D, D, s->step_state, s->beta1, s->beta2, s->adam_eps, s->u_seg_ws, stream));

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "rows.h"
 #include "adam_math.h"
+#include "finalize.h"
 #include "dense.h"
 
 #include <algorithm>
@@ -316,13 +317,40 @@ __device__ __forceinline__ void pin(float4& a) { BR_PIN_V(a.x); BR_PIN_V(a.y); B
 // of 512-B rows needs - and a head finds its duplicates inside the strip already in registers (added in position order, as seg_acc
 // does; a run that leaves the strip continues through seg_acc_from).  Deferred mode takes theta as the lookup replayed it
 // (AdamRowsJob::th0 / th1) and replays m and v only: no alpha ring, no sqrt / rcp per replayed step.
+// Riders: the grid may carry two other pieces of the step as extra workgroups, spread evenly between the row workgroups
+// (every P-th workgroup is a rider) - the NEXT step's dropout keep-bit planes (Philox: ALU work beside an HBM-bound kernel) and the
+// dense finalize (slab reductions + BatchNorm gradients + Adam on the flat vector: only needs the backward).  As launches of their
+// own they needed a fork / join around this kernel inside the step's hipGraph (~10 us each on the main branch, ROCm 7.2).
+struct AdamRiders {
+  KeepFuse kf;             // kf.total workgroups of keep-bit planes
+  FinalArgs fin;           // n_final workgroups of the dense finalize
+  int n_final, total;      // total = kf.total + n_final riders
+  int rows_x;              // row workgroups per job
+};
+
 template <typename IdT, int VEC, int S>
-__global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, int64_t n, int split, AdamHp h, const StepStateDev* __restrict__ ss) {
+__global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, int64_t n, int split, AdamHp h, const StepStateDev* __restrict__ ss,
+                                                              const AdamRiders rd) {
   using V = typename VecT<VEC>::type;
   constexpr int dim = 64 * VEC;
   static_assert(kSegBlock % S == 0, "a strip stays inside one partial block");
-  const AdamRowsJob& jb = jobs.j[blockIdx.y];
-  const int64_t base = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * S;
+  __shared__ float fin_part[16][64];
+  int64_t rb = blockIdx.x;                                    // row workgroup: job = rb / rows_x
+  if (rd.total > 0) {
+    const int P = (int)gridDim.x / rd.total;
+    const int q = (int)blockIdx.x / P;
+    if ((int)blockIdx.x - q * P == 0 && q < rd.total) {       // rider q
+      if (q < rd.kf.total) { keep_fuse_block(rd.kf, q); return; }
+      adam_resolve(h);
+      finalize_block256(rd.fin, h, q - rd.kf.total, fin_part);
+      return;
+    }
+    const int before = ((int)blockIdx.x + P - 1) / P;          // riders left of this workgroup
+    rb -= before < rd.total ? before : rd.total;
+  }
+  const int job = (int)(rb / rd.rows_x);
+  const AdamRowsJob& jb = jobs.j[job];
+  const int64_t base = ((rb - (int64_t)job * rd.rows_x) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * S;
   if (base >= n) return;
   const IdT* __restrict__ sid = (const IdT*)jb.sid;
   const int32_t* __restrict__ spos = jb.spos;
@@ -852,7 +880,9 @@ static bool wave_rows_enabled() {
 }
 
 static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_type, int64_t n, int split, double alpha_t, double beta1,
-                            double beta2, double eps, const StepStateDev* ss, brStream stream, const KeepArgs* keep = nullptr) {
+                            double beta2, double eps, const StepStateDev* ss, brStream stream, const KeepArgs* keep = nullptr,
+                            const FinalArgs* fin = nullptr, bool* fin_done = nullptr) {
+  if (fin_done) *fin_done = false;
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brAdamRowsSorted: bad id_type");
   if (n == 0) return BR_OK;
   AdamRowsJobs jobs;
@@ -894,17 +924,27 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   hipStream_t s = (hipStream_t)stream;
   AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
   if (ss) h.alpha_ptr = &ss->alpha_t;
-  // rows of 64 / 128 / 256 floats: one wave per sorted position (deferred tables only with the lookup's replayed theta at hand)
+  // rows of 64 / 128 / 256 floats: one wave per row (deferred tables only with the lookup's replayed theta at hand)
   const int wvec = dim / 64;
-  if (wave_rows_enabled() && !(keep && keep->batch > 0) && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ldmin >= wvec && th_min >= wvec &&
-      all_stashed) {
+  if (wave_rows_enabled() && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ldmin >= wvec && th_min >= wvec && all_stashed) {
     constexpr int kStrip = 4;
-    const dim3 wgrid((unsigned)ceil_div(n, 4 * kStrip), (unsigned)n_jobs);
+    AdamRiders rd;
+    rd.kf.total = 0; rd.kf.blocks[0] = rd.kf.blocks[1] = rd.kf.blocks[2] = 0; rd.kf.a = KeepArgs{};
+    rd.n_final = 0;
+    if (keep && keep->batch > 0) {
+      rd.kf.a = *keep;
+      for (int i = 0; i < keep->n_sites; ++i) { rd.kf.blocks[i] = (int)ceil_div(keep->batch * keep->s[i].kw, (int64_t)256); rd.kf.total += rd.kf.blocks[i]; }
+    }
+    if (fin) { rd.fin = *fin; rd.n_final = (int)ceil_div(fin->n, 64); } else { rd.fin = FinalArgs{}; }
+    rd.total = rd.kf.total + rd.n_final;
+    rd.rows_x = (int)ceil_div(n, 4 * kStrip);
+    const unsigned wgrid = (unsigned)((int64_t)rd.rows_x * n_jobs + rd.total);
     if (id_type == BR_IDS_I32)
-      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int32_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
+      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int32_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss, rd)));
     else
-      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int64_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss)));
+      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int64_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss, rd)));
     BR_CHECK_LAUNCH("brAdamRowsSorted(wave)");
+    if (fin_done) *fin_done = fin != nullptr;
     return BR_OK;
   }
   for (int q = 0; q < 2; ++q) { jobs.j[q].th0 = jobs.j[q].th1 = nullptr; }
@@ -958,14 +998,15 @@ extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int6
   return adam_rows_launch(a, 2, dim, id_type, n, split, alpha_t, beta1, beta2, eps, last_a ? (const StepStateDev*)step_state : nullptr, stream);
 }
 
-int br::adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream) {
+int br::adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream, const FinalArgs* fin, bool* fin_done) {
   BR_CHECK_ARG((c.last_a == nullptr) == (c.last_b == nullptr) && (c.last_a == nullptr || c.step_state), "brAdamRowsSortedPair: last arrays for both tables (with step_state) or neither");
   BR_CHECK_ARG(c.grads_hi_a && c.grads_hi_b, "brAdamRowsSortedPair: both gradient halves required");
   const AdamRowsArgs a[2] = {{c.table_a, c.m_a, c.v_a, c.rows_a, c.sorted_ids_a, c.sorted_pos_a, c.grads_a, c.ldg_a, c.grads_hi_a, c.ldg_hi_a, c.mark_a, c.last_a, c.seg_ws_a, c.hi_scale,
                               c.th_lo_a, c.th_hi_a, c.ld_th},
                              {c.table_b, c.m_b, c.v_b, c.rows_b, c.sorted_ids_b, c.sorted_pos_b, c.grads_b, c.ldg_b, c.grads_hi_b, c.ldg_hi_b, c.mark_b, c.last_b, c.seg_ws_b, c.hi_scale,
                               c.th_lo_b, c.th_hi_b, c.ld_th}};
-  return adam_rows_launch(a, 2, c.dim, c.id_type, c.n, c.split, c.alpha_t, c.beta1, c.beta2, c.eps, c.last_a ? (const StepStateDev*)c.step_state : nullptr, stream, keep);
+  return adam_rows_launch(a, 2, c.dim, c.id_type, c.n, c.split, c.alpha_t, c.beta1, c.beta2, c.eps, c.last_a ? (const StepStateDev*)c.step_state : nullptr, stream, keep,
+                          fin, fin_done);
 }
 
 extern "C" int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,

@@ -308,8 +308,9 @@ class NeuMFEngine:
         # dropout planes: laid out for max_batch rows; a single-process training step prefetches the next step's planes beside its
         # Adam-rows kernel (brNeumfStep.keep_prefetch), and this step skips the generation if it is the one they were made for
         st.keep_rows = self.max_batch
-        # BR_KEEP_PREFETCH=2: planes inside the Adam-rows grid instead of a launch on the aux stream (include/binrec.h keep_prefetch)
-        st.keep_prefetch = int(os.environ.get("BR_KEEP_PREFETCH", "1")) if (training and self.dist is None and st.aux_stream) else 0
+        # 2 (default): the planes and the dense finalize ride in the Adam-rows launch's grid; BR_KEEP_PREFETCH=1: launches of their own
+        # on the aux stream beside it (a fork / join inside the step's hipGraph; include/binrec.h keep_prefetch)
+        st.keep_prefetch = int(os.environ.get("BR_KEEP_PREFETCH", "2")) if (training and self.dist is None and st.aux_stream) else 0
         st.keep_ready = 1 if (training and self._keep_for == (self.t, row0)) else 0
 
     def _alloc_sparse(self, B):
