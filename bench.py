@@ -168,12 +168,22 @@ def bpr_leg(dev, U, I, F, B, seed):
     """BASELINE configs[2]: the BPR triplet step (src/models/BPRModel.py:38-74) at the same synthetic scale, Keras-Adam."""
     bpr = importlib.import_module("binary-recommendation_amd.bpr")
     g = torch.Generator().manual_seed(seed)
-    out = {"workload": f"BPR step, {U} users x {I} items, {F} factors, {B} triplets, uniform ids"}
+    out = {"workload": f"BPR step, {U} users x {I} items, {F} factors, {B} triplets, uniform ids, 16 batches cycled (tables in steady state)"}
     for name, opt, impl in (("adam_dense", "adam_dense", "deferred"), ("adam_dense_sweep", "adam_dense", "sweep"), ("adam_lazy", "adam_lazy", "sweep")):
         e = bpr.BPREngine(U, I, F, dev, B, optimizer=opt, dense_impl=impl)
-        u, p, n = (torch.randint(0, N, (B,), generator=g).int().to(dev) for N in (U, I, I))
-        ms = loop_ms(lambda: e.train_step(u, p, n))
+        # a cycle of 16 distinct batches, applied once before the clock starts: rows then carry moments and lags as in a running job
+        # (one batch repeated leaves every lag at 0 and the deferred replay with nothing to do)
+        nb = 16
+        trip = [tuple(torch.randint(0, N, (B,), generator=g).int().to(dev) for N in (U, I, I)) for _ in range(nb)]
+        k = [0]
+
+        def one():
+            e.train_step(*trip[k[0] % nb]); k[0] += 1
+        for _ in range(nb):
+            one()
+        ms = loop_ms(one)
         e.check_ids()
+        u, p, n = trip[0]
         uu = int(torch.unique(u).numel()) + int(torch.unique(torch.cat([p, n])).numel())
         # 3 rows in, 3 row gradients out and in again, touched rows of table + m + v read and written; the sweep: every row of both tables
         alg = B * 3 * F * 4 * 3 + (6 * 4 * F * (U + I) if impl == "sweep" and opt == "adam_dense" else uu * 6 * 4 * F)

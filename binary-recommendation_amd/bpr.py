@@ -183,8 +183,10 @@ class BPREngine:
             ar = self.pos_b[:B]
             ops.bpr_forward_backward(ru, ri, ar, ar, self.pos_b[B:2 * B], 1.0 / bt, self.loss_slots, self.g_user[:B], gi, self.per_triplet[:B], self.err)
             main.wait_event(self._ev[1]); main.wait_event(self._ev[2])
-            ops.adam_rows_sorted_deferred(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], self.dim, self.step_state, *hp)
-            ops.adam_rows_sorted_deferred(I, self.item_m, self.item_v, self.item_last, self.item_index, gi, self.dim, self.step_state, *hp)
+            # the gathered rows ARE the tables' rows replayed to step t-1: the optimizer takes theta from them and replays m, v only
+            ops.adam_rows_sorted_deferred(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], self.dim, self.step_state, *hp,
+                                          replayed=ru)
+            ops.adam_rows_sorted_deferred(I, self.item_m, self.item_v, self.item_last, self.item_index, gi, self.dim, self.step_state, *hp, replayed=ri)
             return
         pos, neg = ids2[:B], ids2[B:]
         ops.bpr_forward_backward(U, I, users, pos, neg, 1.0 / bt, self.loss_slots, self.g_user[:B], gi,

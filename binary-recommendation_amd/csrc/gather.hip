@@ -264,6 +264,32 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_kernel(
   }
 }
 
+// The same gather with one WAVE per row, for rows of 64 * VEC floats: the replay loop runs exactly the row's lag with scalar
+// control flow (the row-group form holds 2 - 16 rows per wave and every lane waits for the longest lag), a fresh row skips its
+// m / v loads, alpha comes through scalar loads from the ring (adam_replay_uniform).  Same bits.
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void gather_rows_deferred_wave_kernel(
+    const float* __restrict__ table, const float* __restrict__ M, const float* __restrict__ Vv, const int32_t* __restrict__ last,
+    int64_t rows, const IdT* __restrict__ ids, int64_t n, const StepStateDev* __restrict__ ss, AdamHp h, float* __restrict__ out,
+    int64_t ld_out, int* err) {
+  using V = typename VecT<VEC>::type;
+  constexpr int dim = 64 * VEC;
+  const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (b >= n) return;
+  const int lane = (int)(threadIdx.x & 63);
+  int64_t r = load_id(ids, b);
+  const bool ok = (uint64_t)r < (uint64_t)rows;
+  if (!ok) { if (err && lane == 0) *err = 1; r = 0; }
+  const uint32_t t = ss->step, seen = (uint32_t)last[r];
+  const int64_t off = r * dim + lane * VEC;
+  V th = vload<VEC>(table + off);
+  if (seen + 1 < t) {
+    V m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
+    adam_replay_uniform(th, m, v, seen, t - 1, ss, h);
+  }
+  vstore<VEC>(out + b * ld_out + lane * VEC, ok ? th : vzero<VEC>());
+}
+
 // B1 of the GMF dot on the stashed MF rows, in place: (u, i) -> (ddot * i, ddot * u).  No __restrict__: the
 // two outputs ARE the two inputs.
 template <int VEC>
@@ -542,6 +568,19 @@ extern "C" int brGatherRowsDeferred(const float* table, const float* m, const fl
   const AdamHp h = make_hp(0.0, beta1, beta2, eps);
   const StepStateDev* ss = (const StepStateDev*)step_state;
   hipStream_t s = (hipStream_t)stream;
+  static const bool wave_rows = [] { const char* e = getenv("BR_WAVE_ROWS"); return !(e && e[0] == '0'); }();
+  const int wvec = dim / 64;
+  if (wave_rows && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ld_out % wvec == 0 && (reinterpret_cast<uintptr_t>(out) & (4 * wvec - 1)) == 0) {
+    const unsigned wgrid = (unsigned)ceil_div(n, 4);
+    if (id_type == BR_IDS_I32)
+      BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_kernel<int32_t, VEC><<<wgrid, 256, 0, s>>>(table, m, v, last, table_rows, (const int32_t*)ids, n, ss, h,
+                                                                                                   out, ld_out, err_flag)));
+    else
+      BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_kernel<int64_t, VEC><<<wgrid, 256, 0, s>>>(table, m, v, last, table_rows, (const int64_t*)ids, n, ss, h,
+                                                                                                   out, ld_out, err_flag)));
+    BR_CHECK_LAUNCH("brGatherRowsDeferred(wave)");
+    return BR_OK;
+  }
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(g.vec, (gather_rows_deferred_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(table, m, v, last, table_rows, dim, g.chunks, g.lpr_log2,
                                                                                            (const int32_t*)ids, n, ss, h, out, ld_out, err_flag)));

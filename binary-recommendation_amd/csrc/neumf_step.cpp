@@ -182,6 +182,9 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   // dedup sorts on the aux stream, forked right behind the step-counter launch: they depend only on the ids and then run beside the
   // embedding lookup (an HBM-latency-bound gather without LDS).  Beside the first dense layer they cost it ~20 us: its one-wave grid
   // had to wait for the 16 CUs the sort workgroups (64 KB of LDS each) were holding.
+  // (capturing the lookup AHEAD of the aux launches was tried: a replayed graph starts a fork's nodes ~6 us apart in capture order, so
+  //  the lookup started 7 us earlier - but the sort's 16 fat workgroups then queue behind the lookup's grid, finish beside the first
+  //  dense layer and hold the 16 CUs its one-generation grid needs: 29 -> 49 us there.  Sorts first, lookup flowing around them.)
   if ((ph & BR_PH_FWD1) && aux_index) {
     if (!ensure_events()) { br::set_error("brNeumfStepRun: hipEventCreate failed"); return BR_ERR_HIP; }
     hipStream_t as = (hipStream_t)s->aux_stream;

@@ -984,6 +984,19 @@ extern "C" int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_
   return adam_rows_launch(&a, 1, dim, id_type, n, split, 0.0, beta1, beta2, eps, (const StepStateDev*)step_state, stream);
 }
 
+extern "C" int brAdamRowsSortedDeferredReplayed(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,
+                                                const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                                                const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
+                                                const float* replayed_rows, int64_t ld_replayed, const void* step_state, double beta1,
+                                                double beta2, double eps, float* seg_ws, brStream stream) {
+  BR_CHECK_ARG(last && step_state, "brAdamRowsSortedDeferredReplayed: last / step_state missing");
+  BR_CHECK_ARG(replayed_rows && ld_replayed >= dim, "brAdamRowsSortedDeferredReplayed: replayed rows missing or ld < dim");
+  const int sp = row_grads_hi ? split : dim;
+  AdamRowsArgs a{table, m, v, table_rows, sorted_ids, sorted_pos, row_grads, ldg, row_grads_hi, ldg_hi, nullptr, last, seg_ws};
+  a.th_lo = replayed_rows; a.th_hi = replayed_rows + sp; a.ld_th = ld_replayed;
+  return adam_rows_launch(&a, 1, dim, id_type, n, split, 0.0, beta1, beta2, eps, (const StepStateDev*)step_state, stream);
+}
+
 // both fused tables of a NeuMF step in one launch (same dim / n / split; `last` arrays: deferred mode, `marks`: sweep mode)
 extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a, const void* sorted_ids_a, const int32_t* sorted_pos_a,
                                     const float* grads_a, int64_t ldg_a, const float* grads_hi_a, int64_t ldg_hi_a, uint8_t* mark_a, int32_t* last_a,

@@ -518,9 +518,11 @@ class NeuMFEngine:
         self._adam_tables({"user": (rg["user_mlp"][0], 2 * D, rg["user_mf"][0], 2 * D),
                            "item": (rg["item_mlp"][0], 2 * D, rg["item_mf"][0], 2 * D)})
 
-    def _adam_tables(self, rg):
+    def _adam_tables(self, rg, replayed=None):
         """rg: stream -> (mlp-half grads, stride, mf-half grads, stride), aligned with the positions the
-        indexes were built on.  One launch per fused table (+ the dense sweep in Keras mode)."""
+        indexes were built on.  One launch per fused table (+ the dense sweep in Keras mode).
+        replayed: stream -> the fused rows as this step's deferred gather wrote them, by the same positions (a row-sharded owner:
+        the rows it served) - the optimizer then replays the moments only."""
         cfg, D = self.cfg, self.cfg.dim
         a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
         hp = dict(beta1=cfg.beta1, beta2=cfg.beta2, eps=cfg.adam_eps)
@@ -531,7 +533,8 @@ class NeuMFEngine:
             g0, ld0, g1, ld1 = rg[stream]
             if self.deferred:
                 ops.adam_rows_sorted_deferred(self.fused[stream], self.fused_m[stream], self.fused_v[stream], self.last[stream], idx, g0, ld0,
-                                              self.step_state, row_grads_hi=g1, ldg_hi=ld1, split=D if g1 is not None else 0, **hp)
+                                              self.step_state, row_grads_hi=g1, ldg_hi=ld1, split=D if g1 is not None else 0,
+                                              replayed=None if replayed is None else replayed[stream], **hp)
                 continue
             ops.adam_rows_sorted(self.fused[stream], self.fused_m[stream], self.fused_v[stream], idx, g0, ld0, a, mark=mark,
                                  row_grads_hi=g1, ldg_hi=ld1, split=D if g1 is not None else 0, **hp)

@@ -109,7 +109,16 @@ def gather_rows_deferred(table, m, v, last, ids, step_state, beta1=0.9, beta2=0.
 
 
 def adam_rows_sorted_deferred(table, m, v, last, index, row_grads, ldg, step_state, beta1=0.9, beta2=0.999, eps=1e-7,
-                              row_grads_hi=None, ldg_hi=0, split=0):
+                              row_grads_hi=None, ldg_hi=0, split=0, replayed=None):
+    """replayed: (n, >= dim) rows as this step's gather_rows_deferred wrote them, aligned with the positions the index was built
+    on - the optimizer then replays the moments only (brAdamRowsSortedDeferredReplayed)."""
+    if replayed is not None:
+        check(_lib.load().brAdamRowsSortedDeferredReplayed(table.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), table.shape[0], table.shape[1],
+                                                           index.sorted_ids.data_ptr(), index.id_type, index.sorted_pos.data_ptr(), index.n,
+                                                           row_grads.data_ptr(), ldg, _p(row_grads_hi), ldg_hi, split, _f32(replayed, "replayed").data_ptr(),
+                                                           replayed.stride(0), step_state.data_ptr(), beta1, beta2, eps,
+                                                           index.seg_ws(table.shape[1]).data_ptr(), _stream()), "brAdamRowsSortedDeferredReplayed")
+        return
     check(_lib.load().brAdamRowsSortedDeferred(table.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), table.shape[0], table.shape[1],
                                                index.sorted_ids.data_ptr(), index.id_type, index.sorted_pos.data_ptr(), index.n,
                                                row_grads.data_ptr(), ldg, _p(row_grads_hi), ldg_hi, split, step_state.data_ptr(),

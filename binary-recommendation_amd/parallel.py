@@ -472,7 +472,9 @@ def make_sharded_engine(base_cls):
                                          self.dx0[:B], self.ddot[:B], gu[:, D:], gi[:, D:], gu[:, :D], gi[:, :D], out_rows_by_id=True)
                 ou, oi = x.send_row_grads()                        # all-to-all #3
                 torch.cuda.current_stream(self.device).wait_event(self._ev_index)
-                self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
+                # x.served still holds the rows this rank served for these very slots = its rows replayed to step t-1
+                self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)},
+                                  replayed={"user": x.served[0], "item": x.served[1]} if self.deferred else None)
                 return
             gu, gi = self.g_user[:B], self.g_item[:B]
             # fused per-pair row gradients [mlp | mf] (the MLP halves are copied out of dx0 here)

@@ -517,6 +517,16 @@ int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, in
                              const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
                              const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
                              const void* step_state, double beta1, double beta2, double eps, float* seg_ws, brStream stream);
+/* Same, handed the rows as the step's lookup replayed them: replayed_rows + pos * ld_replayed = row sorted_ids[.] of position pos as
+ * brGatherRowsDeferred wrote it this step (bpr.py: the gathered rows; a row-sharded owner: the rows it served).  The optimizer then
+ * replays only the moments (two multiplies per lagging step instead of the lookup's sqrt / rcp chain on theta): same bits, since the
+ * lookup ran the same replay on the same stored row.  Replaces Keras' sparse apply of an Embedding variable (NFC_plain.py:155,
+ * BPRModel.py:52) on the touched rows. */
+int brAdamRowsSortedDeferredReplayed(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,
+                                     const void* sorted_ids, int id_type, const int32_t* sorted_pos, int64_t n,
+                                     const float* row_grads, int64_t ldg, const float* row_grads_hi, int64_t ldg_hi, int split,
+                                     const float* replayed_rows, int64_t ld_replayed, const void* step_state, double beta1,
+                                     double beta2, double eps, float* seg_ws, brStream stream);
 /* The user and the item table of one NeuMF step in ONE launch (same dim, n, split; each alone leaves HBM half idle).
  * last_* non-NULL (both): deferred mode (step_state required, alpha_t ignored); else brAdamRowsSorted semantics with marks.
  * hi_scale (n floats, may be NULL): the grads_hi rows of BOTH tables are multiplied by hi_scale[position] as they are read.  The
