@@ -21,6 +21,7 @@ trainers/NFC_plain.py's step from oracle/torch_ref.py on a bounded sample).
 from __future__ import annotations
 
 import argparse
+import ctypes
 import importlib
 import json
 import os
@@ -223,20 +224,22 @@ def twotower_leg(ops, dev, U, I, E, S, B, seed):
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "timing": mode}}
 
 
-def run_steps(eng, batches, n, row0, batch_total):
+def run_steps(eng, batches, n, row0, batch_total, arm=None):
     nb = len(batches)
     for s in range(n):
         u, i, y = batches[s % nb]
+        if arm is not None:
+            arm(s)              # points the graph's event-record nodes at this replay's event pair (brProbeGraphArm)
         eng.train_step(u, i, y, row0=row0, batch_total=batch_total)
 
 
-def timed(eng, batches, steps, warmup, ctx, row0, batch_total):
+def timed(eng, batches, steps, warmup, ctx, row0, batch_total, arm=None):
     run_steps(eng, batches, warmup, row0, batch_total)
     if ctx is not None:
         ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(eng, batches, steps, row0, batch_total)
+    run_steps(eng, batches, steps, row0, batch_total, arm)
     torch.cuda.synchronize()
     if ctx is not None:
         ctx.barrier()
@@ -410,6 +413,7 @@ def main():
         "SMALL": (("bn / small (each)", "-", None, None), ("BNG",)),
     }
     use_graph = ctx is None and not args.no_graph
+    graph_exec = None
     # warm-up outside the probe, at least one pass over the batch cycle: the tables are then in the state of a RUNNING job (every row of
     # the cycle carries moments and a lag).  On fresh tables (m = v = 0) the deferred kernels skip their replay arithmetic and look
     # ~30 % faster than they are in steady state.
@@ -443,15 +447,58 @@ def main():
                          "note": "eager, serial launch sequence with a HIP event pair around every launch (source of the per-kernel table)"}
         log(f"eager profiling pass: {dte / np_ * 1e3:.3f} ms/step")
         dom_tag = pick_dominant(per_tag, np_)
+        # the timed region replays the WHOLE step as one hipGraph; the dominant kernel is bracketed inside it by event-record nodes
+        # (brProbeGraph*: a node per replay pointed at that replay's own event pair), so its duration is measured live in every step
+        # Every record node is a barrier in the replayed graph (~7 us each, measured), so the timed region alternates two captures of
+        # the same step: the plain graph, and every PROBE_EVERY-th step the one that carries the two nodes.
+        PROBE_EVERY = 4
+        graph_exec = g_probe = g_plain = None
         try:
-            eng.enable_graph(B, eager_phases=SPEC[dom_tag][1])
+            lib.brProbeGraphSelect(TAG[dom_tag])
+            eng.enable_graph(B, keep_graph=True)
+            g_probe = eng._graph
+            gobj = g_probe["graphs"][0]
+            if lib.brProbeGraphNodes() > 0 and hasattr(gobj, "raw_cuda_graph_exec"):
+                graph_exec = ctypes.c_void_p(int(gobj.raw_cuda_graph_exec()))
+                if lib.brProbeGraphEnable(args.steps) != 0 or lib.brProbeGraphArm(graph_exec, 0) != 0:
+                    log(f"graph probe refused: {lib.brGetLastError().decode()}")
+                    graph_exec = None
+            lib.brProbeGraphSelect(-1)
+            if graph_exec is None:
+                # no record nodes in this runtime: keep the dominant kernel between two graphs instead (graph A -> eager launch with
+                # events -> graph B), the round-1 arrangement
+                eng.enable_graph(B, eager_phases=SPEC[dom_tag][1])
+            else:
+                eng.enable_graph(B)
+                g_plain = eng._graph
             run_steps(eng, batches, max(2, args.warmup), row0, batch_total)
         except Exception as exc:  # noqa: BLE001  - a driver / runtime that cannot capture this step: time the eager sequence
             log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
             eng.disable_graph()
             use_graph = False
             graph_error = f"{type(exc).__name__}: {exc}"
-    if use_graph:
+    if use_graph and graph_exec is not None:
+        probed = [k for k in range(args.steps) if k % PROBE_EVERY == 0]
+
+        def arm(k):
+            if k % PROBE_EVERY == 0:
+                if lib.brProbeGraphArm(graph_exec, k) != 0:
+                    raise RuntimeError(lib.brGetLastError().decode())
+                eng._graph = g_probe
+            else:
+                eng._graph = g_plain
+        dt = timed(eng, batches, args.steps, 0, ctx, row0, batch_total, arm)
+        eng._graph = g_plain
+        ms, tot = ctypes.c_float(), 0.0
+        for k in probed:
+            if lib.brProbeGraphRead(k, ctypes.byref(ms)) != 0:
+                raise RuntimeError(lib.brGetLastError().decode())
+            tot += ms.value
+        per_tag[TAG[dom_tag]] = (tot / len(probed) * 1e3, len(probed))
+        probe_src = {t: ((f"timed region: event-record nodes inside the replayed graph, every {PROBE_EVERY}th step ({len(probed)} of {args.steps})", len(probed))
+                         if t == TAG[dom_tag] else ("eager profiling pass", np_)) for t in per_tag}
+        lib.brProbeGraphEnable(0)
+    elif use_graph:
         if lib.brProbeEnable(16 * args.steps) != 0:
             raise RuntimeError(lib.brGetLastError().decode())
         dt = timed(eng, batches, args.steps, 0, ctx, row0, batch_total)
@@ -524,8 +571,7 @@ def main():
 
     lazy = sweep_leg = flush_info = full_graph = None
     if use_graph:
-        # the same engine with the WHOLE step in one graph (what a training loop runs; no launch is left
-        # outside, so nothing can be bracketed by events)
+        # the same graph without the two event-record nodes (what a training loop runs)
         try:
             eng.enable_graph(B)
             dtg = timed(eng, batches, args.steps, args.warmup, ctx, row0, batch_total)
@@ -630,7 +676,8 @@ def main():
                        "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
             "roofline": roofline, "cpu_baseline": cpu, "legs": legs, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
             "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i},
-            "launch_mode": (f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)" if use_graph
+            "launch_mode": ((f"hipGraph replay of the whole step, one graph per step; {dom_key} bracketed by event-record nodes inside every 4th replay (a HIP event pair each)"
+                             if graph_exec is not None else f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)") if use_graph
                             else "eager launches (brNeumfStepRun)"),
             "eager": eager_profile, "graph_error": graph_error,
             "kernels": kernels,

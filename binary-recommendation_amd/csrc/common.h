@@ -23,6 +23,7 @@ struct StepStateDev {
 const StepStateDev* current_step_state();
 void set_current_step_state(const StepStateDev* p);
 void probe_split(int first_tag, hipStream_t s);   // launch probe of the step driver (neumf_step.cpp), a no-op unless a record is open
+void probe_mark(hipStream_t s);                   // "the launch this call is tagged for comes next" (graph-resident probe; else a no-op)
 
 #define BR_CHECK_ARG(cond, ...)            \
   do {                                     \

@@ -16,19 +16,61 @@ struct Probe {
   bool open = false;
 };
 Probe g_probe;
+// One tag can also be bracketed inside a captured hipGraph: event-record NODES added to the graph under capture (see include/binrec.h
+// brProbeGraph*).  The nodes record into a placeholder pair until brProbeGraphArm points them at a replay's own pair.
+struct GraphProbe {
+  int sel = -1;                         // the tag to bracket in captures
+  hipEvent_t ph0 = nullptr, ph1 = nullptr;
+  std::vector<hipGraphNode_t> begins;   // record nodes in front of the launch (a split call re-records: the last one counts)
+  std::vector<hipGraphNode_t> ends;
+  bool open = false;
+  bool pending = false;                 // selected call under capture whose measured kernel is not its first launch (br::probe_mark)
+  std::vector<hipEvent_t> ev;           // 2 per slot
+};
+GraphProbe g_gp;
+// calls that launch a helper kernel of another tag first and tell where the measured launch starts (br::probe_mark)
+inline bool tag_marks(int tag) { return tag == BR_TAG_ADAM_ROWS_USER || tag == BR_TAG_ADAM_ROWS_ITEM; }
+inline bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+}
+// an event-record node behind everything the capturing stream has issued so far; later work of the stream depends on it
+inline bool capture_record(hipStream_t s, hipEvent_t ev, std::vector<hipGraphNode_t>& out) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t g = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t nd = 0;
+  if (hipStreamGetCaptureInfo_v2(s, &st, &id, &g, &deps, &nd) != hipSuccess || st != hipStreamCaptureStatusActive || !g) return false;
+  hipGraphNode_t node = nullptr;
+  if (hipGraphAddEventRecordNode(&node, g, deps, nd, ev) != hipSuccess) return false;
+  if (hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies) != hipSuccess) return false;
+  out.push_back(node);
+  return true;
+}
 inline void probe_begin(int tag, hipStream_t s) {
   g_probe.open = false;
+  g_gp.open = g_gp.pending = false;
+  if (capturing(s)) {
+    // timed events cannot be recorded into a stream capture (hipErrorInvalidHandle on ROCm 7.2): the selected tag gets record nodes
+    if (tag == g_gp.sel && g_gp.ph0) {
+      if (tag_marks(tag)) g_gp.pending = true;
+      else g_gp.open = capture_record(s, g_gp.ph0, g_gp.begins);
+    }
+    return;
+  }
   if (g_probe.n < g_probe.cap) {
-    // timed events cannot be recorded into a stream capture (hipErrorInvalidHandle on ROCm 7.2):
-    // launches that are being captured into a hipGraph are not probed
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
     g_probe.tag[g_probe.n] = tag;
     (void)hipEventRecord(g_probe.ev[2 * g_probe.n], s);
     g_probe.open = true;
   }
 }
 inline void probe_end(hipStream_t s) {
+  g_gp.pending = false;
+  if (g_gp.open) {
+    g_gp.open = false;
+    (void)capture_record(s, g_gp.ph1, g_gp.ends);
+  }
   if (g_probe.open) {
     g_probe.open = false;
     (void)hipEventRecord(g_probe.ev[2 * g_probe.n + 1], s);
@@ -36,6 +78,50 @@ inline void probe_end(hipStream_t s) {
   }
 }
 }  // namespace
+
+// the measured launch of a tag_marks() call comes next (every record node is a barrier in the replayed graph: only two of them)
+void br::probe_mark(hipStream_t s) {
+  if (g_gp.pending) {
+    g_gp.pending = false;
+    g_gp.open = capture_record(s, g_gp.ph0, g_gp.begins);
+  }
+}
+
+extern "C" int brProbeGraphSelect(int tag) {
+  g_gp.sel = tag; g_gp.open = g_gp.pending = false;
+  if (tag >= 0) { g_gp.begins.clear(); g_gp.ends.clear(); }      // (< 0: later captures carry no nodes, the placed ones stay armable)
+  if (tag >= 0 && !g_gp.ph0) {
+    if (hipEventCreate(&g_gp.ph0) != hipSuccess || hipEventCreate(&g_gp.ph1) != hipSuccess) { br::set_error("brProbeGraphSelect: hipEventCreate failed"); return BR_ERR_HIP; }
+  }
+  return BR_OK;
+}
+extern "C" int brProbeGraphNodes(void) { return g_gp.ends.empty() ? 0 : (int)(g_gp.begins.size() + g_gp.ends.size()); }
+extern "C" int brProbeGraphEnable(int capacity) {
+  for (hipEvent_t e : g_gp.ev) (void)hipEventDestroy(e);
+  g_gp.ev.clear();
+  if (capacity <= 0) return BR_OK;
+  g_gp.ev.resize(2 * (size_t)capacity);
+  for (auto& e : g_gp.ev)
+    if (hipEventCreate(&e) != hipSuccess) { br::set_error("brProbeGraphEnable: hipEventCreate failed"); return BR_ERR_HIP; }
+  return BR_OK;
+}
+extern "C" int brProbeGraphArm(void* graph_exec, int slot) {
+  BR_CHECK_ARG(graph_exec && slot >= 0 && 2 * (size_t)slot + 1 < g_gp.ev.size() && !g_gp.ends.empty(), "brProbeGraphArm: no record nodes / bad slot");
+  hipGraphExec_t ex = (hipGraphExec_t)graph_exec;
+  for (hipGraphNode_t nd : g_gp.begins)
+    if (hipGraphExecEventRecordNodeSetEvent(ex, nd, g_gp.ev[2 * slot]) != hipSuccess) { br::set_error("brProbeGraphArm: hipGraphExecEventRecordNodeSetEvent failed"); return BR_ERR_HIP; }
+  for (hipGraphNode_t nd : g_gp.ends)
+    if (hipGraphExecEventRecordNodeSetEvent(ex, nd, g_gp.ev[2 * slot + 1]) != hipSuccess) { br::set_error("brProbeGraphArm: hipGraphExecEventRecordNodeSetEvent failed"); return BR_ERR_HIP; }
+  return BR_OK;
+}
+extern "C" int brProbeGraphRead(int slot, float* ms) {
+  BR_CHECK_ARG(ms && slot >= 0 && 2 * (size_t)slot + 1 < g_gp.ev.size(), "brProbeGraphRead: bad slot");
+  if (hipEventElapsedTime(ms, g_gp.ev[2 * slot], g_gp.ev[2 * slot + 1]) != hipSuccess) {
+    br::set_error("brProbeGraphRead: events not complete (synchronise the stream first)");
+    return BR_ERR_HIP;
+  }
+  return BR_OK;
+}
 
 // a call that launches two kernels splits its record: what ran so far is retagged `first_tag`, the rest keeps the call's tag
 void br::probe_split(int first_tag, hipStream_t s) {

@@ -924,6 +924,7 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   hipStream_t s = (hipStream_t)stream;
   AdamHp h = make_hp(alpha_t, beta1, beta2, eps);
   if (ss) h.alpha_ptr = &ss->alpha_t;
+  probe_mark(s);
   // rows of 64 / 128 / 256 floats: one wave per row (deferred tables only with the lookup's replayed theta at hand)
   const int wvec = dim / 64;
   if (wave_rows_enabled() && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ldmin >= wvec && th_min >= wvec && all_stashed) {

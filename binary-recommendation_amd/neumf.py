@@ -402,7 +402,7 @@ class NeuMFEngine:
     PHASE_ORDER = ("FWD1", "FWD2", "FWD3", "BWD2", "BWD1", "BNG", "OPT_TABLES", "ROWS_USER", "SWEEP_USER", "ROWS_ITEM",
                    "SWEEP_ITEM", "OPT_DENSE")
 
-    def enable_graph(self, batch: int | None = None, eager_phases: tuple = ()):
+    def enable_graph(self, batch: int | None = None, eager_phases: tuple = (), keep_graph: bool = False):
         """Capture the single-GPU training step for batches of exactly `batch` pairs into a hipGraph and
         replay it from `train_step` (other batch sizes keep the eager launch sequence).  The two per-step
         scalars (dropout step counter, Adam alpha_t) then live in device memory (brNeumfStep.step_state)
@@ -411,16 +411,20 @@ class NeuMFEngine:
         exactly those tensors).
         eager_phases: consecutive names from PHASE_ORDER that stay OUTSIDE the graphs (graph A -> eager launches
         -> graph B) so that HIP events can bracket them; timed events cannot be recorded inside a capture on
-        ROCm 7.2 (bench.py keeps its dominant kernel there)."""
+        ROCm 7.2 (bench.py's fallback when the runtime refuses event-record nodes).
+        keep_graph: keep the captured hipGraph_t alive beside its executable (torch.cuda.CUDAGraph(keep_graph=True)) - node handles
+        placed during the capture (brProbeGraph*) stay valid for hipGraphExec*SetEvent."""
         if self.dist is not None:
             raise ValueError("graph replay covers the single-GPU step (collectives run between the phases otherwise)")
         B = self.max_batch if batch is None else int(batch)
         if not 0 < B <= self.max_batch:
             raise ValueError("graph batch must be in (0, max_batch]")
         dev, st, PH = self.device, self.step_struct, self.PH
-        self.in_users = torch.zeros(B, dtype=self.id_dtype, device=dev)
-        self.in_items = torch.zeros(B, dtype=self.id_dtype, device=dev)
-        self.in_labels = torch.zeros(B, dtype=torch.float32, device=dev)
+        if getattr(self, "in_users", None) is None or self.in_users.shape[0] != B:
+            # (kept across captures of the same batch size: an earlier capture that is still replayed reads these very buffers)
+            self.in_users = torch.zeros(B, dtype=self.id_dtype, device=dev)
+            self.in_items = torch.zeros(B, dtype=self.id_dtype, device=dev)
+            self.in_labels = torch.zeros(B, dtype=torch.float32, device=dev)
         self._alloc_step_state(st)
         # every kernel of the step runs once outside a capture first (code objects load on first launch);
         # the model state is put back afterwards
@@ -451,9 +455,11 @@ class NeuMFEngine:
             if not cap:
                 graphs.append(None)
                 continue
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._run(ph)
+            if keep_graph:
+                g.instantiate()
             graphs.append(g)
         parts = [ph for ph, _ in parts]
         # the capture itself executes nothing, but the dry run above advanced the device step counter

@@ -561,6 +561,21 @@ enum {
 int brProbeEnable(int capacity);
 int brProbeCount(void);
 int brProbeRead(int i, int* tag, float* ms);
+/* The same measurement INSIDE a replayed hipGraph, for one tag.  A timed event recorded into a stream capture cannot be read
+ * (hipEventElapsedTime: invalid resource handle, ROCm 7.2), an event-record NODE can: while brNeumfStepRun is being captured
+ * (hipStreamBeginCapture / torch.cuda.graph), the launch tagged `tag` gets such a node in front and behind
+ * (hipStreamGetCaptureInfo_v2 + hipGraphAddEventRecordNode + hipStreamUpdateCaptureDependencies).
+ *   brProbeGraphSelect(tag)        before the capture (tag >= 0 forgets earlier nodes; tag < 0: later captures carry none)
+ *   brProbeGraphNodes()            after it: record nodes placed (0: that launch was not in the capture)
+ *   brProbeGraphEnable(capacity)   event pairs for `capacity` replays (0 frees them)
+ *   brProbeGraphArm(exec, slot)    before a replay of the instantiated graph `exec` (hipGraphExec_t): its nodes record into pair `slot`
+ *   brProbeGraphRead(slot, &ms)    after synchronising: elapsed ms of the launch in that replay
+ * tools/diag/graph_events.cpp is the stand-alone check of the mechanism.  Process-global, not thread-safe. */
+int brProbeGraphSelect(int tag);
+int brProbeGraphNodes(void);
+int brProbeGraphEnable(int capacity);
+int brProbeGraphArm(void* graph_exec, int slot);
+int brProbeGraphRead(int slot, float* ms);
 
 #ifdef __cplusplus
 }
