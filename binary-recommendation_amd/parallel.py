@@ -422,6 +422,7 @@ def make_sharded_engine(base_cls):
             # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64)
             gu = self._serve_rows("user", ru) if ru.numel() else empty
             gi = self._serve_rows("item", ri) if ri.numel() else empty
+            self._served = {"user": gu, "item": gi}    # kept for the optimizer: this rank's rows replayed to step t-1, by received slot
             self.r_user, self.r_item = xu.return_rows(gu), xi.return_rows(gi)      # all-to-all #2
             self.pos_u = xu.inv.to(self.id_dtype)
             self.pos_i = xi.inv.to(self.id_dtype)
@@ -488,7 +489,11 @@ def make_sharded_engine(base_cls):
             self._grow_index(max(xu.n_recv, xi.n_recv))
             self.user_index.build(xu.recv_local, self.local_rows("user_mf"))
             self.item_index.build(xi.recv_local, self.local_rows("item_mf"))
-            self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)})
+            rep = getattr(self, "_served", None) if self.deferred else None
+            if rep is not None and (rep["user"].shape[0] != xu.n_recv or rep["item"].shape[0] != xi.n_recv or not xu.n_recv or not xi.n_recv):
+                rep = None
+            self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)}, replayed=rep)
+            self._served = None
 
     return ShardedNeuMFEngine
 
@@ -653,13 +658,15 @@ def make_sharded_bpr(base_cls):
                 self.user_index, self.item_index = ops.RowIndex(self._idx_cap, self.id_dtype, self.device), ops.RowIndex(self._idx_cap, self.id_dtype, self.device)
             a = ops.adam_alpha(self.lr, self.t)
             dense = self.optimizer == "adam_dense" and not self.deferred     # per-step sweep of the untouched rows
-            for name, idx, ex, og in (("user", self.user_index, xu, ou), ("item", self.item_index, xi, oi)):
+            for name, idx, ex, og, served in (("user", self.user_index, xu, ou, gu), ("item", self.item_index, xi, oi, gi)):
                 tab, m, v = getattr(self, "_" + name), getattr(self, name + "_m"), getattr(self, name + "_v")
                 mark = getattr(self, name + "_mark", None)
                 if ex.n_recv:
                     idx.build(ex.recv_local, tab.shape[0])
                     if self.deferred:
-                        ops.adam_rows_sorted_deferred(tab, m, v, getattr(self, name + "_last"), idx, og, D, self.step_state, *hp)
+                        # (the rows this rank served for these positions = its rows replayed to step t-1)
+                        ops.adam_rows_sorted_deferred(tab, m, v, getattr(self, name + "_last"), idx, og, D, self.step_state, *hp,
+                                                      replayed=served if served.shape[0] == ex.n_recv else None)
                     else:
                         ops.adam_rows_sorted(tab, m, v, idx, og, D, a, mark=mark if dense else None)
                 if dense:

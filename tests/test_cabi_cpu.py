@@ -27,7 +27,8 @@ def test_header_parses_all_entry_points():
             # round 2
             "brDropoutKeepBits", "brDropoutKeepWords", "brNeumfTailFused", "brInBatchSoftmaxLseGradQ", "brInBatchSoftmaxWorkspaceBytes", "brBootstrapDataset",
             "brBprSampleTriplets", "brNcfNegativeCandidates", "brFullAuc", "brMapAtK", "brShardPlanPair", "brShardPadPair", "brRowsToSlotsPair",
-            "brAdamRowsSortedPair", "brAdamRowsSortedDeferred", "brAdamFlush", "brGatherRowsDeferred", "brDenseFinalize", "brNeumfStepRun"}
+            "brAdamRowsSortedPair", "brAdamRowsSortedDeferred", "brAdamFlush", "brGatherRowsDeferred", "brDenseFinalize", "brNeumfStepRun",
+            "brAdamRowsSortedDeferredReplayed", "brProbeGraphSelect", "brProbeGraphNodes", "brProbeGraphEnable", "brProbeGraphArm", "brProbeGraphRead"}
     assert must <= set(protos), must - set(protos)
     # pointer / scalar classification sanity
     rt, args, names = protos["brGatherRows"]
@@ -64,6 +65,10 @@ def test_argument_errors_are_reported_not_crashed(built):
     assert h.brDropoutKeepBits(1.5, 0, 0, 0, 4, 1, None, None, None, None) == -1                                      # drop_p out of range
     assert h.brInBatchSoftmaxWorkspaceBytes(8192, 8192, 64) > 0 and h.brInBatchSoftmaxWorkspaceBytes(0, 8, 64) == 0
     assert h.brDropoutKeepWords(65536, 100) == 65536 * 4
+    # replayed-rows optimizer entry and the graph-resident probe
+    assert h.brAdamRowsSortedDeferredReplayed(None, None, None, None, 10, 64, None, 0, None, 4, None, 64, None, 0, 0, None, 64, None, 0.9, 0.999, 1e-7, None, None) == -1
+    assert b"Replayed" in h.brGetLastError()
+    assert h.brProbeGraphNodes() == 0 and h.brProbeGraphArm(None, 0) == -1 and h.brProbeGraphRead(0, None) == -1
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -185,3 +185,48 @@ def test_row_index_pair_matches_two_builds(dev):
         assert torch.equal(x.sorted_ids, y.sorted_ids) and torch.equal(x.sorted_pos, y.sorted_pos)
     su = np.argsort(u.cpu().numpy(), kind="stable")
     np.testing.assert_array_equal(a.sorted_pos.cpu().numpy(), su)
+
+
+@pytest.mark.parametrize("dim,split", [(64, 0), (128, 64), (256, 0), (48, 0)])
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_deferred_adam_with_replayed_rows_is_bit_equal(dev, dim, split, idt):
+    """brAdamRowsSortedDeferredReplayed (theta taken as the step's deferred gather replayed it, moments-only replay; one wave per
+    row on 64 / 128 / 256-float rows, strips of 4 sorted positions) against brAdamRowsSortedDeferred replaying theta itself in the
+    row-group kernel: tables, moments and last[] bit-equal over steps with lags, duplicate runs that cross strips and 64-blocks
+    (two-level ordered sum), out-of-range ids and a ragged tail.  dim 48: not a wave shape - the entry falls back to the same kernel."""
+    from importlib import import_module
+    ops = _ops()
+    _lib = import_module("binary-recommendation_amd._lib")
+    lib = _lib.load()
+    rng = np.random.default_rng(dim + (7 if idt == torch.int64 else 0))
+    rows, n, lr, b1, b2 = 3000, 1237, 0.005, 0.9, 0.999
+    td = lambda a: torch.from_numpy(a.copy()).to(dev)
+    th0 = rng.uniform(-0.05, 0.05, size=(rows, dim)).astype(np.float32)
+    tabs = [[td(th0), torch.zeros(rows, dim, device=dev), torch.zeros(rows, dim, device=dev), torch.zeros(rows, dtype=torch.int32, device=dev)] for _ in range(2)]
+    ss = torch.zeros(int(lib.brStepStateBytes()), dtype=torch.uint8, device=dev)
+    _lib.check(lib.brStepStateSet(ss.data_ptr(), 0, lr, b1, b2, ops._stream()), "brStepStateSet")
+    idx = ops.RowIndex(n, idt, dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    for t in range(1, 9):
+        _lib.check(lib.brStepStateAdvance(ss.data_ptr(), lr, b1, b2, None, 0, ops._stream()), "brStepStateAdvance")
+        ids = rng.integers(0, rows, size=n)
+        ids[:300] = 7                                   # one hot id: a run over several 64-blocks of the sorted order
+        ids[300:306] = rng.integers(0, rows)            # a short run that crosses a strip of 4
+        ids[400] = rows + 5                             # out of range: skipped by the optimizer, flagged by the gather
+        if t % 3 == 0:
+            ids[500:] = rng.integers(0, 40, size=n - 500)   # many rows touched again after a short lag
+        idd = td(ids).to(idt)
+        g = td(rng.normal(scale=1e-2, size=(n, dim)).astype(np.float32))
+        idx.build(idd, rows)
+        reps = []
+        for tab, m, v, last in tabs:
+            reps.append(ops.gather_rows_deferred(tab, m, v, last, idd, ss, b1, b2, 1e-7, err_flag=err))
+        assert torch.equal(reps[0].view(torch.int32), reps[1].view(torch.int32))
+        kw = dict(row_grads_hi=g[:, split:], ldg_hi=dim, split=split) if split else {}
+        ops.adam_rows_sorted_deferred(*tabs[0], idx, g, dim, ss, b1, b2, 1e-7, **kw)
+        ops.adam_rows_sorted_deferred(*tabs[1], idx, g, dim, ss, b1, b2, 1e-7, replayed=reps[1], **kw)
+        torch.cuda.synchronize()
+        for a, b, name in zip(tabs[0], tabs[1], ("theta", "m", "v", "last")):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{name} differs at step {t}"
+    assert int(err.item()) == 1
+    assert int((tabs[0][3] > 0).sum().item()) > 100 and float(tabs[0][1].abs().max().item()) > 0
