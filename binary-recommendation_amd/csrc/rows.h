@@ -42,6 +42,20 @@ __device__ __forceinline__ float vdot(float4 a, float4 b) {
 __device__ __forceinline__ float vdot(float2 a, float2 b) { return __builtin_fmaf(a.y, b.y, a.x * b.x); }
 __device__ __forceinline__ float vdot(float a, float b) { return a * b; }
 
+// Register pins: an empty asm the compiler cannot move or drop.  pin(v) = "the value has to be in its registers here" - put behind
+// a batch of independent loads it makes them one batch (all issued, then waited for at once) where the compiler would otherwise
+// sink each load to its first use behind a branch.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BR_PIN_S(x) asm volatile("" : "+s"(x))
+#define BR_PIN_V(x) asm volatile("" : "+v"(x))
+#else          // the host pass parses device functions too and knows no "s" / "v" registers
+#define BR_PIN_S(x) (void)(x)
+#define BR_PIN_V(x) (void)(x)
+#endif
+__device__ __forceinline__ void pin(float& a) { BR_PIN_V(a); }
+__device__ __forceinline__ void pin(float2& a) { BR_PIN_V(a.x); BR_PIN_V(a.y); }
+__device__ __forceinline__ void pin(float4& a) { BR_PIN_V(a.x); BR_PIN_V(a.y); BR_PIN_V(a.z); BR_PIN_V(a.w); }
+
 // Host-side geometry of a row group for a given embedding dim.
 struct RowGeom {
   int vec;       // floats per lane access: 4, 2 or 1

@@ -271,13 +271,6 @@ typedef __attribute__((address_space(1))) const float gcf;
 typedef __attribute__((address_space(1))) float gwf;
 typedef __attribute__((address_space(1))) const int32_t gci32;
 typedef __attribute__((address_space(1))) int32_t gwi32;
-#if defined(__HIP_DEVICE_COMPILE__)
-#define BR_PIN_S(x) asm volatile("" : "+s"(x))
-#define BR_PIN_V(x) asm volatile("" : "+v"(x))
-#else          // the host pass parses device functions too and knows no "s" / "v" registers
-#define BR_PIN_S(x) (void)(x)
-#define BR_PIN_V(x) (void)(x)
-#endif
 __device__ __forceinline__ gcf* sgpr_g(const float* x) { gcf* y = (gcf*)x; BR_PIN_S(y); return y; }
 __device__ __forceinline__ gwf* sgpr_g(float* x) { gwf* y = (gwf*)x; BR_PIN_S(y); return y; }
 __device__ __forceinline__ gwi32* sgpr_g(int32_t* x) { gwi32* y = (gwi32*)x; BR_PIN_S(y); return y; }
@@ -303,10 +296,6 @@ __device__ __forceinline__ void gvstore(gwf* p, typename VecT<VEC>::type v) {
   *(GV*)p = to_nat(v);
 }
 
-// a use the compiler cannot move or drop: the value has to be in its registers here (all loads issued above are waited for at once)
-__device__ __forceinline__ void pin(float& a) { BR_PIN_V(a); }
-__device__ __forceinline__ void pin(float2& a) { BR_PIN_V(a.x); BR_PIN_V(a.y); }
-__device__ __forceinline__ void pin(float4& a) { BR_PIN_V(a.x); BR_PIN_V(a.y); BR_PIN_V(a.z); BR_PIN_V(a.w); }
 
 // The same update with one WAVE per row, for rows of 64 * VEC floats (the fused [mlp | mf] rows of embed_dim 32 / 64 / 128): a lane
 // owns VEC consecutive columns, so everything that depends on the position - head test, id, duplicate walk, the row's lag in deferred
