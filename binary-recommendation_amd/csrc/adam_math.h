@@ -53,9 +53,10 @@ typedef float pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void adam_decay_pk(pk2& th, pk2& m, pk2& v, float alpha, const AdamHp& h) {
   m = m * h.b1;
   v = v * h.b2;
-  pk2 r;
-  r.x = adam_inv_denom(v.x, h.eps);
-  r.y = adam_inv_denom(v.y, h.eps);
+  // adam_inv_denom on both elements, the + eps as one packed add (same IEEE sum per element)
+  pk2 d = {__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)};
+  d = d + h.eps;
+  const pk2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
   th = __builtin_elementwise_fma(-(m * alpha), r, th);
 }
 __device__ __forceinline__ void adam_decay(float& th, float& m, float& v, float alpha, const AdamHp& h) {

@@ -12,6 +12,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-f
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err && echo "fetch ok" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err && echo "write ok" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU -d $OUT/sq -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err && echo "sq ok"
+# one replayed step's timeline (start / duration / gap per kernel) before the traces go
+python3 $GRAFT_REPO_ROOT/tools/timeline.py $OUT/trace -30 > $OUT/graph_replay_timeline_$TAG.txt 2>&1 && echo "timeline ok"
 # keep only what is needed (the raw per-dispatch counter CSVs are large)
 python3 $GRAFT_REPO_ROOT/tools/summarize_profile.py $OUT $TAG > $OUT/summary_$TAG.json && echo "summary ok"
 rm -f $OUT/fetch/*counter_collection.csv $OUT/write/*counter_collection.csv $OUT/sq/*counter_collection.csv $OUT/*/*kernel_trace.csv
