@@ -1001,6 +1001,24 @@ extern "C" int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int6
   return adam_rows_launch(a, 2, dim, id_type, n, split, alpha_t, beta1, beta2, eps, last_a ? (const StepStateDev*)step_state : nullptr, stream);
 }
 
+extern "C" int brAdamRowsSortedPairReplayed(float* table_a, float* m_a, float* v_a, int64_t rows_a, const void* sorted_ids_a, const int32_t* sorted_pos_a,
+                                            const float* grads_a, int64_t ldg_a, const float* grads_hi_a, int64_t ldg_hi_a, int32_t* last_a,
+                                            const float* replayed_a,
+                                            float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
+                                            const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, int32_t* last_b,
+                                            const float* replayed_b, int64_t ld_replayed,
+                                            int dim, int id_type, int64_t n, int split, const void* step_state,
+                                            double beta1, double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream) {
+  BR_CHECK_ARG(last_a && last_b && step_state, "brAdamRowsSortedPairReplayed: last arrays / step_state missing");
+  BR_CHECK_ARG(grads_hi_a && grads_hi_b && split >= 1 && split < dim, "brAdamRowsSortedPairReplayed: both gradient halves and 1 <= split < dim required");
+  BR_CHECK_ARG(replayed_a && replayed_b && ld_replayed >= dim, "brAdamRowsSortedPairReplayed: replayed rows missing or ld < dim");
+  AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, nullptr, last_a, seg_ws_a},
+                       {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, nullptr, last_b, seg_ws_b}};
+  a[0].th_lo = replayed_a; a[0].th_hi = replayed_a + split; a[0].ld_th = ld_replayed;
+  a[1].th_lo = replayed_b; a[1].th_hi = replayed_b + split; a[1].ld_th = ld_replayed;
+  return adam_rows_launch(a, 2, dim, id_type, n, split, 0.0, beta1, beta2, eps, (const StepStateDev*)step_state, stream);
+}
+
 int br::adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream, const FinalArgs* fin, bool* fin_done) {
   BR_CHECK_ARG((c.last_a == nullptr) == (c.last_b == nullptr) && (c.last_a == nullptr || c.step_state), "brAdamRowsSortedPair: last arrays for both tables (with step_state) or neither");
   BR_CHECK_ARG(c.grads_hi_a && c.grads_hi_b, "brAdamRowsSortedPair: both gradient halves required");

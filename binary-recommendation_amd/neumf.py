@@ -533,6 +533,16 @@ class NeuMFEngine:
         a = ops.adam_alpha(cfg.lr, self.t, cfg.beta1, cfg.beta2)
         hp = dict(beta1=cfg.beta1, beta2=cfg.beta2, eps=cfg.adam_eps)
         dense = cfg.optimizer == "adam_dense" and not self.deferred      # per-step sweep of the untouched rows
+        if (self.deferred and replayed is not None and rg["user"][2] is None and rg["item"][2] is None
+                and self.user_index.n == self.item_index.n and rg["user"][1] == rg["item"][1] == 2 * D
+                and replayed["user"].stride(0) == replayed["item"].stride(0)):
+            # fixed-capacity exchange: both streams have the same number of slots -> the two shards in ONE launch (each alone leaves
+            # HBM half idle: random 512-B rows behind a dependent chain per row)
+            ops.adam_rows_sorted_deferred_pair_replayed(
+                self.fused["user"], self.fused_m["user"], self.fused_v["user"], self.last["user"], self.user_index, rg["user"][0], replayed["user"],
+                self.fused["item"], self.fused_m["item"], self.fused_v["item"], self.last["item"], self.item_index, rg["item"][0], replayed["item"],
+                D, self.step_state, **hp)
+            return
         for stream in ("user", "item"):
             idx = self.user_index if stream == "user" else self.item_index
             mark = (self.user_mark if stream == "user" else self.item_mark) if dense else None

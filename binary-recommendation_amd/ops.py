@@ -108,6 +108,20 @@ def gather_rows_deferred(table, m, v, last, ids, step_state, beta1=0.9, beta2=0.
     return out
 
 
+def gather_rows_deferred_pair(tab_a, m_a, v_a, last_a, ids_a, out_a, tab_b, m_b, v_b, last_b, ids_b, out_b, step_state, beta1=0.9, beta2=0.999, eps=1e-7,
+                              err_flag=None):
+    """gather_rows_deferred on two tables of one geometry in one launch (brGatherRowsDeferredPair)."""
+    ta, ty = _ids(ids_a, "ids_a"); tb, tyb = _ids(ids_b, "ids_b")
+    n, dim = ta.shape[0], tab_a.shape[1]
+    if ty != tyb or tb.shape[0] != n or tab_b.shape[1] != dim or out_a.stride(0) != out_b.stride(0) or out_a.shape[0] < n or out_b.shape[0] < n:
+        raise ValueError("gather_rows_deferred_pair: the two gathers must share id type, length, dim and output stride")
+    check(_lib.load().brGatherRowsDeferredPair(_f32(tab_a, "table_a").data_ptr(), m_a.data_ptr(), v_a.data_ptr(), last_a.data_ptr(), tab_a.shape[0], ta.data_ptr(),
+                                               _f32(out_a, "out_a").data_ptr(), _f32(tab_b, "table_b").data_ptr(), m_b.data_ptr(), v_b.data_ptr(), last_b.data_ptr(),
+                                               tab_b.shape[0], tb.data_ptr(), _f32(out_b, "out_b").data_ptr(), dim, ty, n, step_state.data_ptr(), beta1, beta2, eps,
+                                               out_a.stride(0), _p(err_flag), _stream()), "brGatherRowsDeferredPair")
+    return out_a, out_b
+
+
 def adam_rows_sorted_deferred(table, m, v, last, index, row_grads, ldg, step_state, beta1=0.9, beta2=0.999, eps=1e-7,
                               row_grads_hi=None, ldg_hi=0, split=0, replayed=None):
     """replayed: (n, >= dim) rows as this step's gather_rows_deferred wrote them, aligned with the positions the index was built
@@ -123,6 +137,23 @@ def adam_rows_sorted_deferred(table, m, v, last, index, row_grads, ldg, step_sta
                                                index.sorted_ids.data_ptr(), index.id_type, index.sorted_pos.data_ptr(), index.n,
                                                row_grads.data_ptr(), ldg, _p(row_grads_hi), ldg_hi, split, step_state.data_ptr(),
                                                beta1, beta2, eps, index.seg_ws(table.shape[1]).data_ptr(), _stream()), "brAdamRowsSortedDeferred")
+
+
+def adam_rows_sorted_deferred_pair_replayed(tab_a, m_a, v_a, last_a, idx_a, g_a, rep_a, tab_b, m_b, v_b, last_b, idx_b, g_b, rep_b, split, step_state,
+                                            beta1=0.9, beta2=0.999, eps=1e-7):
+    """two deferred tables of one geometry in ONE launch (brAdamRowsSortedPairReplayed): g_x = (n, dim) row gradients by position
+    ([0, split) | [split, dim) read as two halves), rep_x = the rows as this step's deferred gather wrote them, same positions."""
+    dim, n = tab_a.shape[1], idx_a.n
+    if idx_b.n != n or tab_b.shape[1] != dim or g_a.stride(0) != g_b.stride(0) or rep_a.stride(0) != rep_b.stride(0):
+        raise ValueError("adam_rows_sorted_deferred_pair_replayed: the two tables must share dim, positions and strides")
+    ld, ldr = g_a.stride(0), rep_a.stride(0)
+    check(_lib.load().brAdamRowsSortedPairReplayed(
+        tab_a.data_ptr(), m_a.data_ptr(), v_a.data_ptr(), tab_a.shape[0], idx_a.sorted_ids.data_ptr(), idx_a.sorted_pos.data_ptr(),
+        g_a.data_ptr(), ld, g_a.data_ptr() + 4 * split, ld, last_a.data_ptr(), _f32(rep_a, "rep_a").data_ptr(),
+        tab_b.data_ptr(), m_b.data_ptr(), v_b.data_ptr(), tab_b.shape[0], idx_b.sorted_ids.data_ptr(), idx_b.sorted_pos.data_ptr(),
+        g_b.data_ptr(), ld, g_b.data_ptr() + 4 * split, ld, last_b.data_ptr(), _f32(rep_b, "rep_b").data_ptr(), ldr,
+        dim, idx_a.id_type, n, split, step_state.data_ptr(), beta1, beta2, eps, idx_a.seg_ws(dim).data_ptr(), idx_b.seg_ws(dim).data_ptr(),
+        _stream()), "brAdamRowsSortedPairReplayed")
 
 
 def row_dot(a, b, out=None):

@@ -406,8 +406,14 @@ def make_sharded_engine(base_cls):
                 with torch.cuda.stream(self._side):
                     ops.row_index_build_pair(self.user_index, ru, self.local_rows("user_mf"), self.item_index, ri, self.local_rows("item_mf"))
                     self._ev_index.record(self._side)
-                self._serve_rows("user", ru, out=x.served[0])      # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64)
-                self._serve_rows("item", ri, out=x.served[1])
+                if self.deferred and ru.shape[0] == ri.shape[0]:  # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64): both shards, one launch
+                    cfg = self.cfg
+                    ops.gather_rows_deferred_pair(self.fused["user"], self.fused_m["user"], self.fused_v["user"], self.last["user"], ru, x.served[0],
+                                                  self.fused["item"], self.fused_m["item"], self.fused_v["item"], self.last["item"], ri, x.served[1],
+                                                  self.step_state, cfg.beta1, cfg.beta2, cfg.adam_eps, err_flag=self.err)
+                else:
+                    self._serve_rows("user", ru, out=x.served[0])
+                    self._serve_rows("item", ri, out=x.served[1])
                 self.r_user, self.r_item = x.return_rows()         # all-to-all #2
                 self.pos_u, self.pos_i = x.slot[0][:B], x.slot[1][:B]
                 if self.id_dtype != torch.int32:

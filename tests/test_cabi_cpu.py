@@ -28,7 +28,7 @@ def test_header_parses_all_entry_points():
             "brDropoutKeepBits", "brDropoutKeepWords", "brNeumfTailFused", "brInBatchSoftmaxLseGradQ", "brInBatchSoftmaxWorkspaceBytes", "brBootstrapDataset",
             "brBprSampleTriplets", "brNcfNegativeCandidates", "brFullAuc", "brMapAtK", "brShardPlanPair", "brShardPadPair", "brRowsToSlotsPair",
             "brAdamRowsSortedPair", "brAdamRowsSortedDeferred", "brAdamFlush", "brGatherRowsDeferred", "brDenseFinalize", "brNeumfStepRun",
-            "brAdamRowsSortedDeferredReplayed", "brProbeGraphSelect", "brProbeGraphNodes", "brProbeGraphEnable", "brProbeGraphArm", "brProbeGraphRead"}
+            "brAdamRowsSortedDeferredReplayed", "brAdamRowsSortedPairReplayed", "brGatherRowsDeferredPair", "brProbeGraphSelect", "brProbeGraphNodes", "brProbeGraphEnable", "brProbeGraphArm", "brProbeGraphRead"}
     assert must <= set(protos), must - set(protos)
     # pointer / scalar classification sanity
     rt, args, names = protos["brGatherRows"]
