@@ -379,13 +379,17 @@ def main():
     rows_pair = 8 + 2 * D * 4 + (4 if fused_rows else 0)            # sorted id + position, one 2D-float gradient row (+ ddot)
     per_uniq = 6 * 2 * D * 4 + (8 if deferred_mode else 0)           # table, m, v rows read and written (+ last[])
     ROWS_ALL = ("OPT_TABLES", "ROWS_USER", "SWEEP_USER", "ROWS_ITEM", "SWEEP_ITEM")
+    # single GPU, deferred, batch > 16 384, embed_dim 64 / 128: the chunk sorts ride in the lookup's launch (neumf_step.cpp fused_index)
+    fused_sort = deferred_mode and ctx is None and B > 16384 and D in (64, 128) and os.environ.get("BR_FUSED_SORT", "1") != "0" and os.environ.get("BR_WAVE_ROWS", "1") != "0"
     # riders of the pair launch (single GPU, dropout on): the next step's keep-bit planes written + the dense finalize's slabs read and
     # theta / m / v / grad of the dense vector updated - their algorithmic bytes count towards that launch
     riders = deferred_mode and ctx is None and eng.cfg.dropout > 0 and os.environ.get("BR_KEEP_PREFETCH", "2") == "2"
     rider_bytes = (B * 4 * sum((w + 31) // 32 for w in (2 * D, n1, n2)) + 4 * int(eng.slabs.numel()) + 7 * 4 * int(eng.theta.buf.numel())) if riders else 0
     SPEC = {
-        "EMBED_FWD": (("neumf_embed_fwd_deferred (4 lookups + replay of lagging rows + GMF dot + concat)", "neumf_embed_fwd_deferred_wave_kernel", "hbm",
-                       B * (4 * D * 4 + 2 * D * 4 + 2 * D * 4 + 12)) if deferred_mode and ctx is None else
+        "EMBED_FWD": (((("lookup on deferred tables (4 lookups + replay of lagging rows + GMF dot + concat) + the chunk sorts of both id streams riding in its grid",
+                         "lookup_sort_kernel") if fused_sort else
+                        ("neumf_embed_fwd_deferred (4 lookups + replay of lagging rows + GMF dot + concat)", "neumf_embed_fwd_deferred_wave_kernel")) + ("hbm",
+                       B * (4 * D * 4 + 2 * D * 4 + 2 * D * 4 + 12))) if deferred_mode and ctx is None else
                       ("neumf_embed_fwd (4 lookups + GMF dot + concat)", "neumf_embed_fwd_kernel", "hbm", B * (4 * D * 4 + 2 * D * 4 + 12)), ("FWD1",)),
         "EMBED_BWD": (("mf_grad_inplace" if deferred_mode and ctx is None else "neumf_embed_bwd", "neumf_embed_bwd_kernel", "hbm", B * (4 * D * 4 + 8)), ("OPT_TABLES",)),
         "KEEP_BITS": ((f"dropout keep-bit planes (Philox4x32-10, {2 * D} + {n1} + {n2} bits per row)", "keep_bits_kernel", None, None), ("FWD1",)),

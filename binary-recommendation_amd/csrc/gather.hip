@@ -5,6 +5,7 @@
 #include "common.h"
 #include "rows.h"
 #include "adam_math.h"
+#include "lookup_wave.h"
 
 namespace br {
 
@@ -180,57 +181,10 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_deferred_kernel(
 // every lane waits for the longest of four lags (twice the work at a geometric lag distribution) - and a fresh row skips its m / v
 // loads by a scalar branch.  x0, the stashes and `dot` have the same bits as the row-group form (vdot's order chained across lanes).
 template <typename IdT, int VEC>
-__global__ __launch_bounds__(256) void neumf_embed_fwd_deferred_wave_kernel(
-    const float* __restrict__ user_tab, const float* __restrict__ user_m, const float* __restrict__ user_v,
-    const int32_t* __restrict__ user_last, const float* __restrict__ item_tab, const float* __restrict__ item_m,
-    const float* __restrict__ item_v, const int32_t* __restrict__ item_last, int64_t user_rows, int64_t item_rows,
-    const IdT* __restrict__ users, const IdT* __restrict__ items, int64_t batch, int item_first,
-    const StepStateDev* __restrict__ ss, AdamHp h, float* __restrict__ x0, float* __restrict__ dot,
-    float* __restrict__ stash_user, float* __restrict__ stash_item, int64_t ld_stash, int* err) {
-  using V = typename VecT<VEC>::type;
-  constexpr int dim = 32 * VEC;
-  constexpr int64_t ld = 2 * dim;
+__global__ __launch_bounds__(256) void neumf_embed_fwd_deferred_wave_kernel(const LookupArgs a) {
   const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (b >= batch) return;
-  const int lane = (int)(threadIdx.x & 63);
-  const int col = lane * VEC;                         // column of the fused row: [0, dim) MLP, [dim, 2 dim) MF
-  int64_t u = load_id(users, b), i = load_id(items, b);
-  const bool uok = (uint64_t)u < (uint64_t)user_rows, iok = (uint64_t)i < (uint64_t)item_rows;
-  if ((!uok || !iok) && err && lane == 0) *err = 1;
-  if (!uok) u = 0;
-  if (!iok) i = 0;
-  const uint32_t t = ss->step;                        // the step being computed: rows must include steps <= t-1
-  const uint32_t lu = (uint32_t)user_last[u], li = (uint32_t)item_last[i];
-  const int64_t uo = u * ld + col, io = i * ld + col;
-  V ur = vload<VEC>(user_tab + uo), ir = vload<VEC>(item_tab + io);
-  V um = vzero<VEC>(), uv = vzero<VEC>(), im = vzero<VEC>(), iv = vzero<VEC>();
-  if (lu + 1 < t) { um = vload<VEC>(user_m + uo); uv = vload<VEC>(user_v + uo); }
-  if (li + 1 < t) { im = vload<VEC>(item_m + io); iv = vload<VEC>(item_v + io); }
-  if (li + 1 < t) adam_replay_uniform(ir, im, iv, li, t - 1, ss, h);
-  if (lu + 1 < t) adam_replay_uniform(ur, um, uv, lu, t - 1, ss, h);
-  if (!uok) ur = vzero<VEC>();
-  if (!iok) ir = vzero<VEC>();
-  const bool mlp = lane < 32;
-  const int uoff = item_first ? dim : 0, ioff = item_first ? 0 : dim;
-  vstore<VEC>(mlp ? x0 + b * ld + uoff + col : stash_user + b * ld_stash + (col - dim), ur);
-  vstore<VEC>(mlp ? x0 + b * ld + ioff + col : stash_item + b * ld_stash + (col - dim), ir);
-  // GMF dot of the MF halves in the row-group form's order: partial of four columns by a chain of fused multiply-adds, then the xor tree
-  float s;
-  if constexpr (VEC == 4) {
-    s = 0.f + vdot(ur, ir);
-    s += __shfl_xor(s, 16, 64);
-  } else {
-    static_assert(VEC == 2, "wave lookup: embed_dim 64 or 128");
-    const float e = __builtin_fmaf(ur.y, ir.y, ur.x * ir.x);
-    const float prev = __shfl_up(e, 1, 64);          // odd lanes: the first two columns of their group of four
-    s = 0.f + __builtin_fmaf(ur.y, ir.y, __builtin_fmaf(ur.x, ir.x, prev));
-    s += __shfl_xor(s, 16, 64);
-  }
-  s += __shfl_xor(s, 8, 64);
-  s += __shfl_xor(s, 4, 64);
-  s += __shfl_xor(s, 2, 64);
-  if constexpr (VEC == 4) s += __shfl_xor(s, 1, 64);
-  if (lane == 63) dot[b] = s;
+  if (b >= a.batch) return;
+  lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
 }
 
 // G1 on a deferred-Adam table (adam_math.h): out[b] = the row of ids[b] brought up to step t-1 in registers,
@@ -558,12 +512,10 @@ extern "C" int brNeumfEmbedForwardDeferred(const float* user_tab, const float* u
   if (wave_rows && dim % 32 == 0 && (wvec == 2 || wvec == 4) && ld_stash % wvec == 0 &&
       ((reinterpret_cast<uintptr_t>(stash_user) | reinterpret_cast<uintptr_t>(stash_item) | reinterpret_cast<uintptr_t>(x0)) & (4 * wvec - 1)) == 0) {
     const unsigned wgrid = (unsigned)ceil_div(batch, 4);
-#define BR_WAVE_LOOKUP(IdT, VEC_)                                                                                                       \
-  neumf_embed_fwd_deferred_wave_kernel<IdT, VEC_><<<wgrid, 256, 0, s>>>(user_tab, user_m, user_v, user_last, item_tab, item_m, item_v, \
-      item_last, user_rows, item_rows, (const IdT*)users, (const IdT*)items, batch, item_first, ss, h, x0, dot, stash_user, stash_item, ld_stash, err_flag)
-    if (id_type == BR_IDS_I32) { if (wvec == 2) BR_WAVE_LOOKUP(int32_t, 2); else BR_WAVE_LOOKUP(int32_t, 4); }
-    else { if (wvec == 2) BR_WAVE_LOOKUP(int64_t, 2); else BR_WAVE_LOOKUP(int64_t, 4); }
-#undef BR_WAVE_LOOKUP
+    const LookupArgs la{user_tab, user_m, user_v, user_last, item_tab, item_m, item_v, item_last, user_rows, item_rows, users, items, batch, item_first, ss, h,
+                        x0, dot, stash_user, stash_item, ld_stash, err_flag};
+    if (id_type == BR_IDS_I32) { if (wvec == 2) neumf_embed_fwd_deferred_wave_kernel<int32_t, 2><<<wgrid, 256, 0, s>>>(la); else neumf_embed_fwd_deferred_wave_kernel<int32_t, 4><<<wgrid, 256, 0, s>>>(la); }
+    else { if (wvec == 2) neumf_embed_fwd_deferred_wave_kernel<int64_t, 2><<<wgrid, 256, 0, s>>>(la); else neumf_embed_fwd_deferred_wave_kernel<int64_t, 4><<<wgrid, 256, 0, s>>>(la); }
     BR_CHECK_LAUNCH("brNeumfEmbedForwardDeferred(wave)");
     return BR_OK;
   }

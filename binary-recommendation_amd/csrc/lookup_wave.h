@@ -1,0 +1,68 @@
+// One pair of the deferred NeuMF lookup by one wave (gather.hip neumf_embed_fwd_deferred_wave_kernel; also the body of the lookup
+// workgroups of the fused lookup + chunk-sort launch in sparse_opt.hip).
+#pragma once
+#include "common.h"
+#include "rows.h"
+#include "adam_math.h"
+
+namespace br {
+
+struct LookupArgs {
+  const float *user_tab, *user_m, *user_v; const int32_t* user_last;
+  const float *item_tab, *item_m, *item_v; const int32_t* item_last;
+  int64_t user_rows, item_rows;
+  const void *users, *items;
+  int64_t batch; int item_first;
+  const StepStateDev* ss; AdamHp h;
+  float *x0, *dot, *stash_user, *stash_item; int64_t ld_stash; int* err;
+};
+
+// pair b (wave-uniform) of embed_dim = 32 * VEC: a lane owns VEC columns of the fused user row and the same columns of the item row
+template <typename IdT, int VEC>
+__device__ __forceinline__ void lookup_wave_pair(const LookupArgs& a, int64_t b, int lane) {
+  using V = typename VecT<VEC>::type;
+  constexpr int dim = 32 * VEC;
+  constexpr int64_t ld = 2 * dim;
+  const float* __restrict__ user_tab = a.user_tab; const float* __restrict__ item_tab = a.item_tab;
+  const StepStateDev* __restrict__ ss = a.ss;
+  const int col = lane * VEC;                         // column of the fused row: [0, dim) MLP, [dim, 2 dim) MF
+  int64_t u = load_id((const IdT*)a.users, b), i = load_id((const IdT*)a.items, b);
+  const bool uok = (uint64_t)u < (uint64_t)a.user_rows, iok = (uint64_t)i < (uint64_t)a.item_rows;
+  if ((!uok || !iok) && a.err && lane == 0) *a.err = 1;
+  if (!uok) u = 0;
+  if (!iok) i = 0;
+  const uint32_t t = ss->step;                        // the step being computed: rows must include steps <= t-1
+  const uint32_t lu = (uint32_t)a.user_last[u], li = (uint32_t)a.item_last[i];
+  const int64_t uo = u * ld + col, io = i * ld + col;
+  V ur = vload<VEC>(user_tab + uo), ir = vload<VEC>(item_tab + io);
+  V um = vzero<VEC>(), uv = vzero<VEC>(), im = vzero<VEC>(), iv = vzero<VEC>();
+  if (lu + 1 < t) { um = vload<VEC>(a.user_m + uo); uv = vload<VEC>(a.user_v + uo); }
+  if (li + 1 < t) { im = vload<VEC>(a.item_m + io); iv = vload<VEC>(a.item_v + io); }
+  if (li + 1 < t) adam_replay_uniform(ir, im, iv, li, t - 1, ss, a.h);
+  if (lu + 1 < t) adam_replay_uniform(ur, um, uv, lu, t - 1, ss, a.h);
+  if (!uok) ur = vzero<VEC>();
+  if (!iok) ir = vzero<VEC>();
+  const bool mlp = lane < 32;
+  const int uoff = a.item_first ? dim : 0, ioff = a.item_first ? 0 : dim;
+  vstore<VEC>(mlp ? a.x0 + b * ld + uoff + col : a.stash_user + b * a.ld_stash + (col - dim), ur);
+  vstore<VEC>(mlp ? a.x0 + b * ld + ioff + col : a.stash_item + b * a.ld_stash + (col - dim), ir);
+  // GMF dot of the MF halves in the row-group form's order: partial of four columns by a chain of fused multiply-adds, then the xor tree
+  float s;
+  if constexpr (VEC == 4) {
+    s = 0.f + vdot(ur, ir);
+    s += __shfl_xor(s, 16, 64);
+  } else {
+    static_assert(VEC == 2, "wave lookup: embed_dim 64 or 128");
+    const float e = __builtin_fmaf(ur.y, ir.y, ur.x * ir.x);
+    const float prev = __shfl_up(e, 1, 64);          // odd lanes: the first two columns of their group of four
+    s = 0.f + __builtin_fmaf(ur.y, ir.y, __builtin_fmaf(ur.x, ir.x, prev));
+    s += __shfl_xor(s, 16, 64);
+  }
+  s += __shfl_xor(s, 8, 64);
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 2, 64);
+  if constexpr (VEC == 4) s += __shfl_xor(s, 1, 64);
+  if (lane == 63) a.dot[b] = s;
+}
+
+}  // namespace br

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "dense.h"
 #include "finalize.h"
+#include "lookup_wave.h"
 
 #include <vector>
 
@@ -252,7 +253,10 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   // instead of beside it - rocprofv3 timeline, ROCm 7.2 - which put ~70 us of launch-bound sort passes on the
   // critical path; behind the lookup they overlap the MLP.)
   const bool build_index = train && (ph & BR_PH_INDEX);
-  const bool aux_index = build_index && s->aux_stream && (ph & BR_PH_FWD1);
+  // the chunk sorts inside the lookup's own launch (no fork / join): the single-GPU deferred step at the benchmarked shapes
+  const bool fused_index = build_index && deferred && (ph & BR_PH_FWD1) && (ph & BR_PH_EMBED) &&
+                           br::lookup_with_index_supported(D, B, s->user_rows, s->item_rows, 2 * D, s->x0, s->g_user + D, s->g_item + D);
+  const bool aux_index = build_index && !fused_index && s->aux_stream && (ph & BR_PH_FWD1);
   bool joined = !aux_index;
   const int64_t n_dstat = (int64_t)BR_STAT_REPLICAS * (4 * n1 + 4 * n2);
   // (a host that runs the embedding exchange itself - no EMBED bit - advanced the state before its lookup)
@@ -292,7 +296,14 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       hipError_t e = hipMemsetAsync(s->dstat, 0, sizeof(double) * (size_t)(BR_STAT_REPLICAS * (4 * n1 + 4 * n2)), hs);
       if (e != hipSuccess) { br::set_error("brNeumfStepRun: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
     }
-    if ((ph & BR_PH_EMBED) && deferred && train)
+    if (fused_index) {
+      br::AdamHp lh = br::make_hp(0.0, s->beta1, s->beta2, s->adam_eps);
+      const br::LookupArgs la{s->user_tab, s->user_m, s->user_v, s->user_last, s->item_tab, s->item_m, s->item_v, s->item_last, s->user_rows, s->item_rows,
+                              s->users, s->items, B, s->item_first, reinterpret_cast<const br::StepStateDev*>(s->step_state), lh, s->x0, s->dot,
+                              s->g_user + D, s->g_item + D, 2 * D, s->err_flag};
+      const br::IndexPairArgs ix{s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes};
+      RUN(BR_TAG_INDEX_USER, br::lookup_with_index(la, D, s->id_type, ix, stream));     // (its first launch is retagged EMBED_FWD)
+    } else if ((ph & BR_PH_EMBED) && deferred && train)
       RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForwardDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->item_tab, s->item_m, s->item_v, s->item_last,
                               s->user_rows, s->item_rows, s->users, s->items, s->id_type, D, B, s->item_first, s->step_state, s->beta1, s->beta2,
                               s->adam_eps, s->x0, s->dot, s->g_user + D, s->g_item + D, 2 * D, s->err_flag, stream));
@@ -362,7 +373,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
       RUN(BR_TAG_EMBED_BWD, brNeumfEmbedBackward(s->user_tab + D, s->item_tab + D, 2 * D, 2 * D, s->user_rows, s->item_rows, s->users, s->items, s->id_type, D,
                                B, s->item_first, nullptr, s->ddot, nullptr, nullptr, s->g_user + D, s->g_item + D, 2 * D, 0, stream));
   }
-  if (build_index && !aux_index) {
+  if (build_index && !aux_index && !fused_index) {
     RUN(BR_TAG_INDEX_USER, brRowIndexBuildPair(s->users, s->user_rows, s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes,
                                                s->items, s->item_rows, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes, s->id_type, B, stream));
   }

@@ -11,6 +11,7 @@
 #include "rows.h"
 #include "adam_math.h"
 #include "finalize.h"
+#include "lookup_wave.h"
 #include "dense.h"
 
 #include <algorithm>
@@ -631,14 +632,15 @@ struct IdxJob {
 };
 struct IdxJobs { IdxJob j[2]; };
 
+// chunk `chunk` of id stream `which` by the calling workgroup of kSortThreads threads
 template <typename IdT, int kChunk, int kSortThreads>
-__global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, int64_t n) {
+__device__ __forceinline__ void chunk_sort_block(const IdxJobs& jobs, int64_t n, int chunk, int which) {
   constexpr int IPT = kChunk / kSortThreads;
   using Sort = hipcub::BlockRadixSort<uint32_t, kSortThreads, IPT, uint32_t>;
   __shared__ typename Sort::TempStorage tmp;
-  const IdxJob& job = jobs.j[blockIdx.y];
+  const IdxJob& job = jobs.j[which];
   const IdT* ids = (const IdT*)job.ids;
-  const int64_t base = (int64_t)blockIdx.x * kChunk + threadIdx.x * IPT;
+  const int64_t base = (int64_t)chunk * kChunk + threadIdx.x * IPT;
   uint32_t k[IPT], p[IPT];
 #pragma unroll
   for (int q = 0; q < IPT; ++q) {
@@ -651,6 +653,27 @@ __global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, 
 #pragma unroll
   for (int q = 0; q < IPT; ++q)
     if (base + q < n) { job.ck[base + q] = k[q]; job.cp[base + q] = p[q]; }
+}
+template <typename IdT, int kChunk, int kSortThreads>
+__global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, int64_t n) {
+  chunk_sort_block<IdT, kChunk, kSortThreads>(jobs, n, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// The deferred NeuMF lookup and the chunk sorts of the step's two id streams in ONE launch of 1024-thread workgroups: the first
+// 2 * n_chunks workgroups each sort a chunk (they start first and run ~37 us on 16 CUs), the rest are lookup workgroups of 16 waves =
+// 16 pairs that flow around them.  As a launch of their own on a side stream the sorts needed a fork and a join in the step's
+// hipGraph (~10 us each on the main branch, ROCm 7.2) and stretched the lookup they ran beside; the chunk-rank launch follows on the
+// same stream.  LDS: the sort's image is reserved by every workgroup (two per CU = 32 waves: the lookup's full occupancy anyway).
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(kThreadsL) void lookup_sort_kernel(const LookupArgs a, IdxJobs jobs, int64_t n, int n_chunks) {
+  const int n_sort = 2 * n_chunks;
+  if ((int)blockIdx.x < n_sort) {
+    chunk_sort_block<IdT, kChunkL, kThreadsL>(jobs, n, (int)blockIdx.x % n_chunks, (int)blockIdx.x / n_chunks);
+    return;
+  }
+  const int64_t b = ((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (b >= a.batch) return;
+  lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
 }
 
 template <typename IdT, int kChunk>
@@ -792,6 +815,40 @@ extern "C" int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sor
   }
   const int rc = brRowIndexBuild(ids_a, id_type, n, upper_a, sorted_ids_a, sorted_pos_a, ws_a, ws_a_bytes, stream);
   return rc != BR_OK ? rc : brRowIndexBuild(ids_b, id_type, n, upper_b, sorted_ids_b, sorted_pos_b, ws_b, ws_b_bytes, stream);
+}
+
+static bool wave_rows_enabled();
+// neumf_step.cpp: lookup + both dedup indexes on one stream (lookup_sort_kernel, then the chunk-rank launch).  supported(): the wave
+// lookup's shapes, the large-chunk sort's range, BR_FUSED_SORT != 0.
+bool br::lookup_with_index_supported(int dim, int64_t n, int64_t upper_a, int64_t upper_b, int64_t ld_stash, const void* x0, const void* stash_a,
+                                     const void* stash_b) {
+  static const bool on = [] { const char* e = getenv("BR_FUSED_SORT"); return !(e && e[0] == '0'); }();
+  const int wvec = dim / 32;
+  return on && wave_rows_enabled() && dim % 32 == 0 && (wvec == 2 || wvec == 4) && ld_stash % wvec == 0 &&
+         ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(stash_a) | reinterpret_cast<uintptr_t>(stash_b)) & (4 * wvec - 1)) == 0 &&
+         n > kChunkSwitchN && rank_path_ok(n, upper_a) && rank_path_ok(n, upper_b);
+}
+int br::lookup_with_index(const LookupArgs& la, int dim, int id_type, const IndexPairArgs& ix, brStream stream) {
+  const int64_t n = la.batch;
+  BR_CHECK_ARG(ix.sorted_ids_a && ix.sorted_ids_b && ix.sorted_pos_a && ix.sorted_pos_b && ix.ws_a && ix.ws_b, "lookup_with_index: null pointer");
+  const int64_t need = brRowIndexWorkspaceBytes(n, id_type);
+  if (ix.ws_a_bytes < need || ix.ws_b_bytes < need) { set_error("lookup_with_index: workspace < required %lld", (long long)need); return BR_ERR_WORKSPACE; }
+  IdxJobs jobs;
+  jobs.j[0] = make_job(la.users, ix.sorted_ids_a, ix.sorted_pos_a, ix.ws_a, n, la.user_rows);
+  jobs.j[1] = make_job(la.items, ix.sorted_ids_b, ix.sorted_pos_b, ix.ws_b, n, la.item_rows);
+  const int n_chunks = (int)ceil_div(n, kChunkL);
+  const unsigned grid = (unsigned)(2 * n_chunks + ceil_div(n, kThreadsL / 64));
+  hipStream_t s = (hipStream_t)stream;
+  const int wvec = dim / 32;
+  if (id_type == BR_IDS_I32) { if (wvec == 2) lookup_sort_kernel<int32_t, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); else lookup_sort_kernel<int32_t, 4><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); }
+  else { if (wvec == 2) lookup_sort_kernel<int64_t, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); else lookup_sort_kernel<int64_t, 4><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); }
+  BR_CHECK_LAUNCH("lookup_with_index(lookup + sort)");
+  probe_split(BR_TAG_EMBED_FWD, s);
+  const dim3 g2((unsigned)ceil_div(n, 256), 2);
+  if (id_type == BR_IDS_I32) chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
+  else chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
+  BR_CHECK_LAUNCH("lookup_with_index(rank)");
+  return BR_OK;
 }
 
 extern "C" int64_t brSegmentScratchFloats(int64_t n, int dim) { return ceil_div(n > 0 ? n : 1, kSegBlock) * (int64_t)dim; }
