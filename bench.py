@@ -592,7 +592,11 @@ def main():
         # the deferred tables must be flushed at least every BR_ALPHA_RING-8 steps: run up to that point and
         # time the flush a long job pays there (worst case: every row replays a full ring of steps)
         period = eng.ALPHA_RING - 8
-        run_steps(eng, batches, max(0, period - 1 - (eng.t - eng._flush_t)), row0, batch_total)
+        todo = max(0, period - 1 - (eng.t - eng._flush_t))
+        while todo > 0:        # in slices: ~1000 graph launches queued at once stalled rocprofv3's --pmc pass on the fork-free graph
+            run_steps(eng, batches, min(64, todo), row0, batch_total)
+            torch.cuda.synchronize()
+            todo -= 64
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.flush()
