@@ -29,7 +29,7 @@ f, w = first("fetch/**/*counter_collection.csv"), first("write/**/*counter_colle
 if f and w:
     fa, wa = counter_avg(f), counter_avg(w)
     for k in fa:
-        if "br::" not in k: continue
+        if "br::" not in k and "lookup_sort" not in k and "chunk_" not in k: continue
         # the sweep kernel runs on two table sizes: keep the largest-grid launches separately
         fv, wv = fa[k].get("FETCH_SIZE", []), wa.get(k, {}).get("WRITE_SIZE", [])
         if not fv: continue
