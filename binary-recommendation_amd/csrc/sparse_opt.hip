@@ -974,7 +974,7 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   // rows of 64 / 128 / 256 floats: one wave per row (deferred tables only with the lookup's replayed theta at hand)
   const int wvec = dim / 64;
   if (wave_rows_enabled() && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ldmin >= wvec && th_min >= wvec && all_stashed) {
-    constexpr int kStrip = 4;
+    static const int strip = [] { const char* e = getenv("BR_ADAM_STRIP"); return e ? atoi(e) : 4; }();      // knob: 2, 4 (default), 8 - measured at the bench config: 92 / 85 / 115 us with riders
     AdamRiders rd;
     rd.kf.total = 0; rd.kf.blocks[0] = rd.kf.blocks[1] = rd.kf.blocks[2] = 0; rd.kf.a = KeepArgs{};
     rd.n_final = 0;
@@ -984,12 +984,13 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     }
     if (fin) { rd.fin = *fin; rd.n_final = (int)ceil_div(fin->n, 64); } else { rd.fin = FinalArgs{}; }
     rd.total = rd.kf.total + rd.n_final;
-    rd.rows_x = (int)ceil_div(n, 4 * kStrip);
+    const int S = (strip == 2 || strip == 8) && wvec <= 2 ? strip : 4;
+    rd.rows_x = (int)ceil_div(n, 4 * S);
     const unsigned wgrid = (unsigned)((int64_t)rd.rows_x * n_jobs + rd.total);
-    if (id_type == BR_IDS_I32)
-      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int32_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss, rd)));
-    else
-      BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<int64_t, VEC, kStrip><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss, rd)));
+#define BR_ADAM_WAVE(IdT, S_) BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<IdT, VEC, S_><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss, rd)))
+    if (id_type == BR_IDS_I32) { if (S == 2) BR_ADAM_WAVE(int32_t, 2); else if (S == 8) BR_ADAM_WAVE(int32_t, 8); else BR_ADAM_WAVE(int32_t, 4); }
+    else { if (S == 2) BR_ADAM_WAVE(int64_t, 2); else if (S == 8) BR_ADAM_WAVE(int64_t, 8); else BR_ADAM_WAVE(int64_t, 4); }
+#undef BR_ADAM_WAVE
     BR_CHECK_LAUNCH("brAdamRowsSorted(wave)");
     if (fin_done) *fin_done = fin != nullptr;
     return BR_OK;
