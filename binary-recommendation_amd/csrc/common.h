@@ -20,6 +20,9 @@ struct StepStateDev {
   double pow_b1, pow_b2;             // beta1^step, beta2^step (running products: no pow() on the step's critical path)
   float alpha_hist[BR_ALPHA_RING];   // alpha_j at [j & (BR_ALPHA_RING-1)] for the last BR_ALPHA_RING steps
 };
+// arguments of the step-state advance (step += 1, alpha_t, ring entry, the step's double scratch zeroed): a launch of its own
+// (brStepStateAdvance) or one extra workgroup of the chunk-rank launch (neumf_step.cpp defer_advance)
+struct StepAdvance { StepStateDev* st = nullptr; double lr = 0, b1 = 0, b2 = 0; double* zero = nullptr; int64_t n_zero = 0; };
 const StepStateDev* current_step_state();
 void set_current_step_state(const StepStateDev* p);
 void probe_split(int first_tag, hipStream_t s);   // launch probe of the step driver (neumf_step.cpp), a no-op unless a record is open

@@ -49,7 +49,7 @@ struct IndexPairArgs {
   void* sorted_ids_b; int32_t* sorted_pos_b; void* ws_b; int64_t ws_b_bytes;
 };
 bool lookup_with_index_supported(int dim, int64_t n, int64_t upper_a, int64_t upper_b, int64_t ld_stash, const void* x0, const void* stash_a, const void* stash_b);
-int lookup_with_index(const LookupArgs& la, int dim, int id_type, const IndexPairArgs& ix, brStream stream);
+int lookup_with_index(const LookupArgs& la, int dim, int id_type, const IndexPairArgs& ix, brStream stream, const StepAdvance* adv = nullptr);
 
 int dense_backward_fused(const BwdArgs& a, hipStream_t s);    // BR_ERR_UNSUPPORTED when the LDS image does not fit
 int dense_bwd_fused_grid(int64_t batch);                      // workgroups = slabs written

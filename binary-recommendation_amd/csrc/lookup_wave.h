@@ -15,6 +15,7 @@ struct LookupArgs {
   int64_t batch; int item_first;
   const StepStateDev* ss; AdamHp h;
   float *x0, *dot, *stash_user, *stash_item; int64_t ld_stash; int* err;
+  uint32_t step_add = 0;      // 1: the step state is advanced BEHIND this launch (by the chunk-rank launch): the step being computed is ss->step + 1
 };
 
 // pair b (wave-uniform) of embed_dim = 32 * VEC: a lane owns VEC columns of the fused user row and the same columns of the item row
@@ -31,7 +32,7 @@ __device__ __forceinline__ void lookup_wave_pair(const LookupArgs& a, int64_t b,
   if ((!uok || !iok) && a.err && lane == 0) *a.err = 1;
   if (!uok) u = 0;
   if (!iok) i = 0;
-  const uint32_t t = ss->step;                        // the step being computed: rows must include steps <= t-1
+  const uint32_t t = ss->step + a.step_add;           // the step being computed: rows must include steps <= t-1
   const uint32_t lu = (uint32_t)a.user_last[u], li = (uint32_t)a.item_last[i];
   const int64_t uo = u * ld + col, io = i * ld + col;
   V ur = vload<VEC>(user_tab + uo), ir = vload<VEC>(item_tab + io);

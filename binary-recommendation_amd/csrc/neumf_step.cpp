@@ -260,7 +260,11 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
   bool joined = !aux_index;
   const int64_t n_dstat = (int64_t)BR_STAT_REPLICAS * (4 * n1 + 4 * n2);
   // (a host that runs the embedding exchange itself - no EMBED bit - advanced the state before its lookup)
-  if ((ph & BR_PH_FWD1) && (ph & BR_PH_EMBED) && train && s->step_state)
+  // fused_index and no keep-bit launch at the top of the step (planes prefetched, or no dropout): the chunk-rank launch advances the
+  // state behind the lookup (which then computes its step as ss->step + 1) - one launch less in the chain
+  const bool need_advance = (ph & BR_PH_FWD1) && (ph & BR_PH_EMBED) && train && s->step_state;
+  const bool defer_advance = need_advance && fused_index && (s->dropout <= 0.f || s->keep_ready);
+  if (need_advance && !defer_advance)
     RUN(BR_TAG_STEP_STATE, brStepStateAdvance(s->step_state, s->lr, s->beta1, s->beta2, s->dstat, n_dstat, stream));
   // dropout keep-bit planes of the three sites [2D | n1 | n2], filled once per step (after the step counter advanced)
   uint32_t *keep0 = nullptr, *keep1 = nullptr, *keep2 = nullptr;
@@ -302,7 +306,13 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
                               s->users, s->items, B, s->item_first, reinterpret_cast<const br::StepStateDev*>(s->step_state), lh, s->x0, s->dot,
                               s->g_user + D, s->g_item + D, 2 * D, s->err_flag};
       const br::IndexPairArgs ix{s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes};
-      RUN(BR_TAG_INDEX_USER, br::lookup_with_index(la, D, s->id_type, ix, stream));     // (its first launch is retagged EMBED_FWD)
+      br::LookupArgs la2 = la;
+      br::StepAdvance adv;
+      if (defer_advance) {
+        la2.step_add = 1;
+        adv.st = reinterpret_cast<br::StepStateDev*>(s->step_state); adv.lr = s->lr; adv.b1 = s->beta1; adv.b2 = s->beta2; adv.zero = s->dstat; adv.n_zero = n_dstat;
+      }
+      RUN(BR_TAG_INDEX_USER, br::lookup_with_index(la2, D, s->id_type, ix, stream, defer_advance ? &adv : nullptr));     // (its first launch is retagged EMBED_FWD)
     } else if ((ph & BR_PH_EMBED) && deferred && train)
       RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForwardDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->item_tab, s->item_m, s->item_v, s->item_last,
                               s->user_rows, s->item_rows, s->users, s->items, s->id_type, D, B, s->item_first, s->step_state, s->beta1, s->beta2,

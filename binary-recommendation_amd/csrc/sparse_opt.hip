@@ -559,20 +559,21 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ gt
 
 // top of a training step: step += 1, alpha_t (thread 0), and the step's double scratch zeroed (all threads) -
 // one launch instead of a memset node plus a kernel
-__global__ __launch_bounds__(256) void step_state_advance_kernel(StepStateDev* st, double lr, double b1, double b2,
-                                                                  double* __restrict__ zero, int64_t n_zero) {
-  for (int64_t i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0.0;
+__device__ __forceinline__ void step_state_advance_block(const StepAdvance& a) {
+  for (int64_t i = threadIdx.x; i < a.n_zero; i += blockDim.x) a.zero[i] = 0.0;
   if (threadIdx.x == 0) {
+    StepStateDev* st = a.st;
     const uint32_t t = st->step + 1;
-    const double p1 = st->pow_b1 * b1, p2 = st->pow_b2 * b2;
-    const float a = (float)(lr * sqrt(1.0 - p2) / (1.0 - p1));
+    const double p1 = st->pow_b1 * a.b1, p2 = st->pow_b2 * a.b2;
+    const float al = (float)(a.lr * sqrt(1.0 - p2) / (1.0 - p1));
     st->step = t;
     st->pow_b1 = p1;
     st->pow_b2 = p2;
-    st->alpha_t = a;
-    st->alpha_hist[t & (BR_ALPHA_RING - 1)] = a;
+    st->alpha_t = al;
+    st->alpha_hist[t & (BR_ALPHA_RING - 1)] = al;
   }
 }
+__global__ __launch_bounds__(256) void step_state_advance_kernel(StepAdvance a) { step_state_advance_block(a); }
 
 template <typename IdT>
 __global__ __launch_bounds__(256) void stage_batch_kernel(IdT* __restrict__ du, IdT* __restrict__ di, float* __restrict__ dy,
@@ -676,8 +677,14 @@ __global__ __launch_bounds__(kThreadsL) void lookup_sort_kernel(const LookupArgs
   lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
 }
 
+// adv.st != NULL: the grid has one extra column of workgroups, whose y = 0 member advances the step state (nothing in this launch reads it;
+// the lookup in front computed its step as ss->step + 1, everything behind sees the advanced state) - one launch less per step
 template <typename IdT, int kChunk>
-__global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n, int n_chunks) {
+__global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n, int n_chunks, const StepAdvance adv) {
+  if (adv.st && blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.y == 0) step_state_advance_block(adv);
+    return;
+  }
   const IdxJob& job = jobs.j[blockIdx.y];
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
@@ -726,11 +733,11 @@ static int index_build_rank(IdxJobs& jobs, int n_jobs, int id_type, int64_t n, h
   const int n_chunks = (int)ceil_div(n, large ? kChunkL : kChunkS);
   const dim3 g1((unsigned)n_chunks, (unsigned)n_jobs), g2((unsigned)ceil_div(n, 256), (unsigned)n_jobs);
   if (id_type == BR_IDS_I32) {
-    if (large) { chunk_sort_kernel<int32_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
-    else { chunk_sort_kernel<int32_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int32_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    if (large) { chunk_sort_kernel<int32_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks, StepAdvance{}); }
+    else { chunk_sort_kernel<int32_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int32_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks, StepAdvance{}); }
   } else {
-    if (large) { chunk_sort_kernel<int64_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
-    else { chunk_sort_kernel<int64_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int64_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks); }
+    if (large) { chunk_sort_kernel<int64_t, kChunkL, kThreadsL><<<g1, kThreadsL, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks, StepAdvance{}); }
+    else { chunk_sort_kernel<int64_t, kChunkS, kThreadsS><<<g1, kThreadsS, 0, s>>>(jobs, n); probe_split(BR_TAG_INDEX_SORT, s); chunk_rank_kernel<int64_t, kChunkS><<<g2, 256, 0, s>>>(jobs, n, n_chunks, StepAdvance{}); }
   }
   BR_CHECK_LAUNCH("brRowIndexBuild");
   return BR_OK;
@@ -828,7 +835,7 @@ bool br::lookup_with_index_supported(int dim, int64_t n, int64_t upper_a, int64_
          ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(stash_a) | reinterpret_cast<uintptr_t>(stash_b)) & (4 * wvec - 1)) == 0 &&
          n > kChunkSwitchN && rank_path_ok(n, upper_a) && rank_path_ok(n, upper_b);
 }
-int br::lookup_with_index(const LookupArgs& la, int dim, int id_type, const IndexPairArgs& ix, brStream stream) {
+int br::lookup_with_index(const LookupArgs& la, int dim, int id_type, const IndexPairArgs& ix, brStream stream, const StepAdvance* adv) {
   const int64_t n = la.batch;
   BR_CHECK_ARG(ix.sorted_ids_a && ix.sorted_ids_b && ix.sorted_pos_a && ix.sorted_pos_b && ix.ws_a && ix.ws_b, "lookup_with_index: null pointer");
   const int64_t need = brRowIndexWorkspaceBytes(n, id_type);
@@ -844,9 +851,10 @@ int br::lookup_with_index(const LookupArgs& la, int dim, int id_type, const Inde
   else { if (wvec == 2) lookup_sort_kernel<int64_t, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); else lookup_sort_kernel<int64_t, 4><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); }
   BR_CHECK_LAUNCH("lookup_with_index(lookup + sort)");
   probe_split(BR_TAG_EMBED_FWD, s);
-  const dim3 g2((unsigned)ceil_div(n, 256), 2);
-  if (id_type == BR_IDS_I32) chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
-  else chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks);
+  const StepAdvance av = adv ? *adv : StepAdvance{};
+  const dim3 g2((unsigned)(ceil_div(n, 256) + (av.st ? 1 : 0)), 2);
+  if (id_type == BR_IDS_I32) chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks, av);
+  else chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks, av);
   BR_CHECK_LAUNCH("lookup_with_index(rank)");
   return BR_OK;
 }
@@ -1173,7 +1181,9 @@ extern "C" int64_t brStepStateBytes(void) { return (int64_t)sizeof(StepStateDev)
 
 extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, double* zero, int64_t n_zero, brStream stream) {
   BR_CHECK_ARG(step_state != nullptr && n_zero >= 0 && (zero || n_zero == 0), "brStepStateAdvance: bad args");
-  step_state_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>((StepStateDev*)step_state, lr, beta1, beta2, zero, n_zero);
+  StepAdvance a;
+  a.st = (StepStateDev*)step_state; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.zero = zero; a.n_zero = n_zero;
+  step_state_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a);
   BR_CHECK_LAUNCH("brStepStateAdvance");
   return BR_OK;
 }

@@ -370,3 +370,36 @@ def test_graph_resident_probe_times_a_kernel_inside_the_replay(dev):
     for k in ("user", "item"):      # (same launches; the BatchNorm column sums are double atomics, so not bit for bit)
         _close(probed.fused[k].cpu().numpy(), plain.fused[k].cpu().numpy(), "table " + k, rtol=2e-6, atol_frac=1e-6)
     _close(probed.theta.buf.cpu().numpy(), plain.theta.buf.cpu().numpy(), "theta", rtol=2e-6, atol_frac=1e-6)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_lookup_sort_step_is_bit_equal_to_the_sweep(dev, graph):
+    """Batches above 16 384 take the fork-free step: the chunk sorts ride in the lookup's launch (lookup_sort_kernel) and, once the
+    dropout planes are prefetched, the chunk-rank launch advances the step state behind the lookup (which computes its step as
+    ss->step + 1).  Against the sweep engine (plain lookup, dedup sorts on the aux stream, a step-state launch of its own): tables and
+    moments bit for bit over steps with lags, a ragged batch (eager path in graph mode) and duplicate-heavy ids."""
+    B, U, I = 20000, 30000, 7000
+    sw, de = _two_engines(dev, B, U, I, dim=64)
+    if graph:
+        de.enable_graph(B)
+    rng = np.random.default_rng(21)
+    td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
+    for step in range(7):
+        n = B if step != 3 else 17000          # 17 000 > 16 384: the fused launch on the eager path as well
+        uu, ii = rng.integers(0, U, n), rng.integers(0, I, n)
+        uu[:300] = uu[0]
+        if step % 2:
+            uu[1000:9000] = rng.integers(0, 500, 8000)      # rows touched again after a short lag
+        yy = (rng.random(n) < 0.3).astype(np.float32)
+        for e in (sw, de):
+            e.train_step(td(uu, torch.int32), td(ii, torch.int32), td(yy, torch.float32))
+    torch.cuda.synchronize()
+    de.check_ids()
+    assert de.t == sw.t == 7 and int(de.step_state[0].item()) == 7
+    if graph:      # alpha_t is computed on the device in double by the replayed step, on the host by the eager one: an fp32 ulp of alpha
+        de.flush(); sw.flush()
+        for k in ("user", "item"):
+            _close(de.fused[k].cpu().numpy(), sw.fused[k].cpu().numpy(), "table " + k, rtol=2e-6, atol_frac=1e-6)
+            _close(de.fused_v[k].cpu().numpy(), sw.fused_v[k].cpu().numpy(), "v " + k, rtol=2e-6, atol_frac=1e-6)
+    else:
+        _assert_same_state(sw, de)
