@@ -11,8 +11,10 @@ for f in files:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 names = [r[2] for r in rows]
-# a step starts at step_state_advance_kernel
-starts = [i for i, n in enumerate(names) if "step_state_advance" in n]
+# a step starts at its staging launch (stage_batch_kernel; builds whose chain still has a step_state_advance_kernel of its own: there)
+starts = [i for i, n in enumerate(names) if "stage_batch_kernel" in n]
+if len(starts) < 40:
+    starts = [i for i, n in enumerate(names) if "step_state_advance" in n]
 want = int(sys.argv[2]) if len(sys.argv) > 2 else -30     # which step (index into starts)
 i0, i1 = starts[want], starts[want + 1]
 t0 = rows[i0][0]
