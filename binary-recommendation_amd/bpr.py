@@ -178,15 +178,24 @@ class BPREngine:
                 self._ev[1 + k].record(self._side[k])
         if self.deferred:
             hp = (self.BETA1, self.BETA2, self.EPS)
-            ru = ops.gather_rows_deferred(U, self.user_m, self.user_v, self.user_last, users, self.step_state, *hp, out=self.r_user[:B], err_flag=self.err)
-            ri = ops.gather_rows_deferred(I, self.item_m, self.item_v, self.item_last, ids2, self.step_state, *hp, out=self.r_item[:2 * B], err_flag=self.err)
+            pair = self.dim in (64, 128, 256)       # one-wave-per-row shapes: both tables served / updated by one launch each
+            if pair:
+                ru, ri = ops.gather_rows_deferred_pair(U, self.user_m, self.user_v, self.user_last, users, self.r_user[:B],
+                                                       I, self.item_m, self.item_v, self.item_last, ids2, self.r_item[:2 * B], self.step_state, *hp, err_flag=self.err)
+            else:
+                ru = ops.gather_rows_deferred(U, self.user_m, self.user_v, self.user_last, users, self.step_state, *hp, out=self.r_user[:B], err_flag=self.err)
+                ri = ops.gather_rows_deferred(I, self.item_m, self.item_v, self.item_last, ids2, self.step_state, *hp, out=self.r_item[:2 * B], err_flag=self.err)
             ar = self.pos_b[:B]
             ops.bpr_forward_backward(ru, ri, ar, ar, self.pos_b[B:2 * B], 1.0 / bt, self.loss_slots, self.g_user[:B], gi, self.per_triplet[:B], self.err)
             main.wait_event(self._ev[1]); main.wait_event(self._ev[2])
             # the gathered rows ARE the tables' rows replayed to step t-1: the optimizer takes theta from them and replays m, v only
-            ops.adam_rows_sorted_deferred(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], self.dim, self.step_state, *hp,
-                                          replayed=ru)
-            ops.adam_rows_sorted_deferred(I, self.item_m, self.item_v, self.item_last, self.item_index, gi, self.dim, self.step_state, *hp, replayed=ri)
+            if pair:
+                ops.adam_rows_sorted_deferred_pair_replayed(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], ru,
+                                                            I, self.item_m, self.item_v, self.item_last, self.item_index, gi, ri, 0, self.step_state, *hp)
+            else:
+                ops.adam_rows_sorted_deferred(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], self.dim, self.step_state, *hp,
+                                              replayed=ru)
+                ops.adam_rows_sorted_deferred(I, self.item_m, self.item_v, self.item_last, self.item_index, gi, self.dim, self.step_state, *hp, replayed=ri)
             return
         pos, neg = ids2[:B], ids2[B:]
         ops.bpr_forward_backward(U, I, users, pos, neg, 1.0 / bt, self.loss_slots, self.g_user[:B], gi,

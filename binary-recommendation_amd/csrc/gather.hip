@@ -246,14 +246,15 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_wave_kernel(
 
 // two deferred tables of one geometry served by ONE launch (blockIdx.y): a row-sharded owner's user and item shard - each gather alone
 // is a chain of dependent round trips per row and leaves HBM half idle
-struct GatherDefJob { const float* table; const float* M; const float* Vv; const int32_t* last; int64_t rows; const void* ids; float* out; };
+struct GatherDefJob { const float* table; const float* M; const float* Vv; const int32_t* last; int64_t rows; const void* ids; float* out; int64_t n; };
 struct GatherDefJobs { GatherDefJob j[2]; };
 template <typename IdT, int VEC>
-__global__ __launch_bounds__(256) void gather_rows_deferred_wave_pair_kernel(GatherDefJobs jobs, int64_t n, const StepStateDev* __restrict__ ss, AdamHp h,
+__global__ __launch_bounds__(256) void gather_rows_deferred_wave_pair_kernel(GatherDefJobs jobs, const StepStateDev* __restrict__ ss, AdamHp h,
                                                                               int64_t ld_out, int* err) {
   using V = typename VecT<VEC>::type;
   constexpr int dim = 64 * VEC;
   const GatherDefJob& jb = jobs.j[blockIdx.y];
+  const int64_t n = jb.n;
   const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (b >= n) return;
   const int lane = (int)(threadIdx.x & 63);
@@ -571,31 +572,32 @@ extern "C" int brGatherRowsDeferred(const float* table, const float* m, const fl
 
 extern "C" int brGatherRowsDeferredPair(const float* table_a, const float* m_a, const float* v_a, const int32_t* last_a, int64_t rows_a, const void* ids_a,
                                         float* out_a, const float* table_b, const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b,
-                                        const void* ids_b, float* out_b, int dim, int id_type, int64_t n, const void* step_state, double beta1,
+                                        const void* ids_b, float* out_b, int dim, int id_type, int64_t n, int64_t n_b, const void* step_state, double beta1,
                                         double beta2, double eps, int64_t ld_out, int* err_flag, brStream stream) {
+  if (n_b == 0) n_b = n;
   BR_CHECK_ARG(table_a && m_a && v_a && last_a && ids_a && out_a && table_b && m_b && v_b && last_b && ids_b && out_b && step_state && rows_a > 0 && rows_b > 0 &&
-                   n >= 0 && ld_out >= dim, "brGatherRowsDeferredPair: bad args");
+                   n >= 0 && n_b >= 0 && ld_out >= dim, "brGatherRowsDeferredPair: bad args");
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brGatherRowsDeferredPair: bad id_type");
-  if (n == 0) return BR_OK;
+  if (n == 0 && n_b == 0) return BR_OK;
   const int wvec = dim / 64;
   const bool wave_ok = dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ld_out % wvec == 0 &&
                        ((reinterpret_cast<uintptr_t>(out_a) | reinterpret_cast<uintptr_t>(out_b)) & (4 * wvec - 1)) == 0;
   if (!wave_ok) {      // other row widths: the two single-table launches
     const int rc = brGatherRowsDeferred(table_a, m_a, v_a, last_a, rows_a, dim, ids_a, id_type, n, step_state, beta1, beta2, eps, out_a, ld_out, err_flag, stream);
     if (rc != BR_OK) return rc;
-    return brGatherRowsDeferred(table_b, m_b, v_b, last_b, rows_b, dim, ids_b, id_type, n, step_state, beta1, beta2, eps, out_b, ld_out, err_flag, stream);
+    return brGatherRowsDeferred(table_b, m_b, v_b, last_b, rows_b, dim, ids_b, id_type, n_b, step_state, beta1, beta2, eps, out_b, ld_out, err_flag, stream);
   }
   GatherDefJobs J;
-  J.j[0] = GatherDefJob{table_a, m_a, v_a, last_a, rows_a, ids_a, out_a};
-  J.j[1] = GatherDefJob{table_b, m_b, v_b, last_b, rows_b, ids_b, out_b};
+  J.j[0] = GatherDefJob{table_a, m_a, v_a, last_a, rows_a, ids_a, out_a, n};
+  J.j[1] = GatherDefJob{table_b, m_b, v_b, last_b, rows_b, ids_b, out_b, n_b};
   const AdamHp h = make_hp(0.0, beta1, beta2, eps);
   const StepStateDev* ss = (const StepStateDev*)step_state;
-  const dim3 grid((unsigned)ceil_div(n, 4), 2);
+  const dim3 grid((unsigned)ceil_div(n > n_b ? n : n_b, 4), 2);
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32)
-    BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_pair_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(J, n, ss, h, ld_out, err_flag)));
+    BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_pair_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(J, ss, h, ld_out, err_flag)));
   else
-    BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_pair_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(J, n, ss, h, ld_out, err_flag)));
+    BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_pair_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(J, ss, h, ld_out, err_flag)));
   BR_CHECK_LAUNCH("brGatherRowsDeferredPair");
   return BR_OK;
 }

@@ -134,13 +134,15 @@ struct SegJob {                // one table's gradient source for the partials
   const float* g1; int64_t ldg1;
   float* part;                 // [ceil(n / kSegBlock)][dim]
   const float* sc1 = nullptr;  // per-position factor of g1 rows, or null (last: positional initialisers of the other users stay valid)
+  int64_t n = 0;               // this job's positions when the jobs of a launch differ in length (0: the launch's n)
 };
 struct SegJobs { SegJob j[2]; };
 
 template <typename IdT, int VEC>
-__global__ __launch_bounds__(256) void segment_partials_kernel(SegJobs jobs, int64_t n, int dim, int chunks, int lpr_log2, int split) {
+__global__ __launch_bounds__(256) void segment_partials_kernel(SegJobs jobs, int64_t n_launch, int dim, int chunks, int lpr_log2, int split) {
   using V = typename VecT<VEC>::type;
   const SegJob& jb = jobs.j[blockIdx.y];
+  const int64_t n = jb.n ? jb.n : n_launch;
   const IdT* __restrict__ sid = (const IdT*)jb.sid;
   const int32_t* __restrict__ spos = jb.spos;
   const int lpr = 1 << lpr_log2;
@@ -202,6 +204,7 @@ struct AdamRowsJob {
   // repeating the lookup's sqrt / rcp chain on theta: same bits (the lookup ran adam_replay on the same stored row).
   const float* th0 = nullptr; int64_t ldt0 = 0;
   const float* th1 = nullptr; int64_t ldt1 = 0;
+  int64_t n = 0;              // this job's positions when the two jobs of a launch differ in length (wave kernel only; 0: the launch's n)
 };
 struct AdamRowsJobs { AdamRowsJob j[2]; };
 
@@ -319,7 +322,7 @@ struct AdamRiders {
 };
 
 template <typename IdT, int VEC, int S>
-__global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, int64_t n, int split, AdamHp h, const StepStateDev* __restrict__ ss,
+__global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, int64_t n_launch, int split, AdamHp h, const StepStateDev* __restrict__ ss,
                                                               const AdamRiders rd) {
   using V = typename VecT<VEC>::type;
   constexpr int dim = 64 * VEC;
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, 
   }
   const int job = (int)(rb / rd.rows_x);
   const AdamRowsJob& jb = jobs.j[job];
+  const int64_t n = jb.n ? jb.n : n_launch;
   const int64_t base = ((rb - (int64_t)job * rd.rows_x) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * S;
   if (base >= n) return;
   const IdT* __restrict__ sid = (const IdT*)jb.sid;
@@ -925,6 +929,7 @@ struct AdamRowsArgs {      // one table's host-side arguments
   float* seg_ws;
   const float* hi_scale = nullptr;     // per-position factor of the row_grads_hi rows
   const float* th_lo = nullptr; const float* th_hi = nullptr; int64_t ld_th = 0;   // replayed theta by position (AdamRowsJob::th0 / th1)
+  int64_t n = 0;              // positions of this table when the tables of a launch differ in length (wave kernel only)
 };
 
 // BR_WAVE_ROWS=0: keep the row-group kernels (A/B runs)
@@ -941,8 +946,8 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
   if (n == 0) return BR_OK;
   AdamRowsJobs jobs;
   SegJob segs[2];
-  bool with_partials = true, all_stashed = true;
-  int64_t ldmin = 4, th_min = 4;
+  bool with_partials = true, all_stashed = true, per_job_n = false;
+  int64_t ldmin = 4, th_min = 4, n_max = n;
   for (int q = 0; q < n_jobs; ++q) {
     AdamRowsArgs t = a[q];
     BR_CHECK_ARG(t.table && t.m && t.v && t.sorted_ids && t.sorted_pos && t.row_grads && dim >= 1 && t.table_rows > 0, "brAdamRowsSorted: bad args");
@@ -963,15 +968,21 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     } else if (t.last) {
       all_stashed = false;
     }
-    segs[q] = SegJob{t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws, t.hi_scale};
+    segs[q] = SegJob{t.sorted_ids, t.sorted_pos, t.row_grads, t.ldg, t.row_grads_hi, t.ldg_hi, t.seg_ws, t.hi_scale, t.n};
+    jobs.j[q].n = t.n;
+    if (t.n > n_max) n_max = t.n;
+    per_job_n = per_job_n || (t.n != 0 && t.n != n);
     with_partials = with_partials && t.seg_ws != nullptr;
   }
   if (n_jobs == 1) jobs.j[1] = jobs.j[0];
   if (!with_partials)
     for (int q = 0; q < 2; ++q) jobs.j[q].part = nullptr;     // all tables or none
   const RowGeom g = row_geom_ld(dim, ldmin);
+  const int wvec0 = dim / 64;
+  const bool wave_ok = wave_rows_enabled() && dim % 64 == 0 && (wvec0 == 1 || wvec0 == 2 || wvec0 == 4) && ldmin >= wvec0 && th_min >= wvec0 && all_stashed;
+  BR_CHECK_ARG(!per_job_n || wave_ok, "brAdamRowsSorted: tables of different lengths in one launch need the one-wave-per-row shapes");
   if (with_partials) {
-    const int rc = launch_partials(segs, n_jobs, id_type, n, dim, g, split, (hipStream_t)stream);
+    const int rc = launch_partials(segs, n_jobs, id_type, n_max, dim, g, split, (hipStream_t)stream);
     if (rc != BR_OK) return rc;
     probe_split(BR_TAG_SEG_PARTIALS, (hipStream_t)stream);
   }
@@ -993,7 +1004,7 @@ static int adam_rows_launch(const AdamRowsArgs* a, int n_jobs, int dim, int id_t
     if (fin) { rd.fin = *fin; rd.n_final = (int)ceil_div(fin->n, 64); } else { rd.fin = FinalArgs{}; }
     rd.total = rd.kf.total + rd.n_final;
     const int S = (strip == 2 || strip == 8) && wvec <= 2 ? strip : 4;
-    rd.rows_x = (int)ceil_div(n, 4 * S);
+    rd.rows_x = (int)ceil_div(n_max, 4 * S);
     const unsigned wgrid = (unsigned)((int64_t)rd.rows_x * n_jobs + rd.total);
 #define BR_ADAM_WAVE(IdT, S_) BR_DISPATCH_VEC(wvec, (adam_rows_wave_kernel<IdT, VEC, S_><<<wgrid, 256, 0, s>>>(jobs, n, split, h, ss, rd)))
     if (id_type == BR_IDS_I32) { if (S == 2) BR_ADAM_WAVE(int32_t, 2); else if (S == 8) BR_ADAM_WAVE(int32_t, 8); else BR_ADAM_WAVE(int32_t, 4); }
@@ -1073,16 +1084,21 @@ extern "C" int brAdamRowsSortedPairReplayed(float* table_a, float* m_a, float* v
                                             float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
                                             const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, int32_t* last_b,
                                             const float* replayed_b, int64_t ld_replayed,
-                                            int dim, int id_type, int64_t n, int split, const void* step_state,
+                                            int dim, int id_type, int64_t n, int64_t n_b, int split, const void* step_state,
                                             double beta1, double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream) {
   BR_CHECK_ARG(last_a && last_b && step_state, "brAdamRowsSortedPairReplayed: last arrays / step_state missing");
-  BR_CHECK_ARG(grads_hi_a && grads_hi_b && split >= 1 && split < dim, "brAdamRowsSortedPairReplayed: both gradient halves and 1 <= split < dim required");
-  BR_CHECK_ARG(replayed_a && replayed_b && ld_replayed >= dim, "brAdamRowsSortedPairReplayed: replayed rows missing or ld < dim");
+  BR_CHECK_ARG((grads_hi_a == nullptr) == (grads_hi_b == nullptr), "brAdamRowsSortedPairReplayed: gradient halves for both tables or neither");
+  if (!grads_hi_a) { split = dim; grads_hi_a = grads_a; grads_hi_b = grads_b; ldg_hi_a = ldg_a; ldg_hi_b = ldg_b; }     // one source: the whole row is the low part
+  BR_CHECK_ARG(split >= 1 && split <= dim, "brAdamRowsSortedPairReplayed: split out of range");
+  BR_CHECK_ARG(replayed_a && replayed_b && ld_replayed >= dim && n >= 0 && n_b >= 0, "brAdamRowsSortedPairReplayed: replayed rows missing, ld < dim or n < 0");
+  if (n_b == 0) n_b = n;
+  if (n == 0 && n_b == 0) return BR_OK;
   AdamRowsArgs a[2] = {{table_a, m_a, v_a, rows_a, sorted_ids_a, sorted_pos_a, grads_a, ldg_a, grads_hi_a, ldg_hi_a, nullptr, last_a, seg_ws_a},
                        {table_b, m_b, v_b, rows_b, sorted_ids_b, sorted_pos_b, grads_b, ldg_b, grads_hi_b, ldg_hi_b, nullptr, last_b, seg_ws_b}};
-  a[0].th_lo = replayed_a; a[0].th_hi = replayed_a + split; a[0].ld_th = ld_replayed;
-  a[1].th_lo = replayed_b; a[1].th_hi = replayed_b + split; a[1].ld_th = ld_replayed;
-  return adam_rows_launch(a, 2, dim, id_type, n, split, 0.0, beta1, beta2, eps, (const StepStateDev*)step_state, stream);
+  a[0].th_lo = replayed_a; a[0].th_hi = replayed_a + (split < dim ? split : 0); a[0].ld_th = ld_replayed;
+  a[1].th_lo = replayed_b; a[1].th_hi = replayed_b + (split < dim ? split : 0); a[1].ld_th = ld_replayed;
+  if (n_b != n) { a[0].n = n; a[1].n = n_b; }
+  return adam_rows_launch(a, 2, dim, id_type, n > n_b ? n : n_b, split, 0.0, beta1, beta2, eps, (const StepStateDev*)step_state, stream);
 }
 
 int br::adam_rows_pair_keep(const AdamPairCall& c, const KeepArgs* keep, brStream stream, const FinalArgs* fin, bool* fin_done) {

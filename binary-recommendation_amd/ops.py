@@ -112,12 +112,12 @@ def gather_rows_deferred_pair(tab_a, m_a, v_a, last_a, ids_a, out_a, tab_b, m_b,
                               err_flag=None):
     """gather_rows_deferred on two tables of one geometry in one launch (brGatherRowsDeferredPair)."""
     ta, ty = _ids(ids_a, "ids_a"); tb, tyb = _ids(ids_b, "ids_b")
-    n, dim = ta.shape[0], tab_a.shape[1]
-    if ty != tyb or tb.shape[0] != n or tab_b.shape[1] != dim or out_a.stride(0) != out_b.stride(0) or out_a.shape[0] < n or out_b.shape[0] < n:
-        raise ValueError("gather_rows_deferred_pair: the two gathers must share id type, length, dim and output stride")
+    n, nb, dim = ta.shape[0], tb.shape[0], tab_a.shape[1]
+    if ty != tyb or tab_b.shape[1] != dim or out_a.stride(0) != out_b.stride(0) or out_a.shape[0] < n or out_b.shape[0] < nb:
+        raise ValueError("gather_rows_deferred_pair: the two gathers must share id type, dim and output stride")
     check(_lib.load().brGatherRowsDeferredPair(_f32(tab_a, "table_a").data_ptr(), m_a.data_ptr(), v_a.data_ptr(), last_a.data_ptr(), tab_a.shape[0], ta.data_ptr(),
                                                _f32(out_a, "out_a").data_ptr(), _f32(tab_b, "table_b").data_ptr(), m_b.data_ptr(), v_b.data_ptr(), last_b.data_ptr(),
-                                               tab_b.shape[0], tb.data_ptr(), _f32(out_b, "out_b").data_ptr(), dim, ty, n, step_state.data_ptr(), beta1, beta2, eps,
+                                               tab_b.shape[0], tb.data_ptr(), _f32(out_b, "out_b").data_ptr(), dim, ty, n, nb, step_state.data_ptr(), beta1, beta2, eps,
                                                out_a.stride(0), _p(err_flag), _stream()), "brGatherRowsDeferredPair")
     return out_a, out_b
 
@@ -141,19 +141,22 @@ def adam_rows_sorted_deferred(table, m, v, last, index, row_grads, ldg, step_sta
 
 def adam_rows_sorted_deferred_pair_replayed(tab_a, m_a, v_a, last_a, idx_a, g_a, rep_a, tab_b, m_b, v_b, last_b, idx_b, g_b, rep_b, split, step_state,
                                             beta1=0.9, beta2=0.999, eps=1e-7):
-    """two deferred tables of one geometry in ONE launch (brAdamRowsSortedPairReplayed): g_x = (n, dim) row gradients by position
-    ([0, split) | [split, dim) read as two halves), rep_x = the rows as this step's deferred gather wrote them, same positions."""
-    dim, n = tab_a.shape[1], idx_a.n
-    if idx_b.n != n or tab_b.shape[1] != dim or g_a.stride(0) != g_b.stride(0) or rep_a.stride(0) != rep_b.stride(0):
-        raise ValueError("adam_rows_sorted_deferred_pair_replayed: the two tables must share dim, positions and strides")
+    """two deferred tables of one row width in ONE launch (brAdamRowsSortedPairReplayed): g_x = (n_x, dim) row gradients by position
+    (split > 0: [0, split) | [split, dim) read as two halves of the same rows; split = 0: one source), rep_x = the rows as this step's
+    deferred gather wrote them, same positions.  The two indexes may differ in length (one wave per row shapes: dim 64 / 128 / 256)."""
+    dim = tab_a.shape[1]
+    if tab_b.shape[1] != dim or g_a.stride(0) != g_b.stride(0) or rep_a.stride(0) != rep_b.stride(0) or idx_a.id_type != idx_b.id_type:
+        raise ValueError("adam_rows_sorted_deferred_pair_replayed: the two tables must share dim, id type and strides")
     ld, ldr = g_a.stride(0), rep_a.stride(0)
+    hi_a = g_a.data_ptr() + 4 * split if split else None
+    hi_b = g_b.data_ptr() + 4 * split if split else None
     check(_lib.load().brAdamRowsSortedPairReplayed(
         tab_a.data_ptr(), m_a.data_ptr(), v_a.data_ptr(), tab_a.shape[0], idx_a.sorted_ids.data_ptr(), idx_a.sorted_pos.data_ptr(),
-        g_a.data_ptr(), ld, g_a.data_ptr() + 4 * split, ld, last_a.data_ptr(), _f32(rep_a, "rep_a").data_ptr(),
+        g_a.data_ptr(), ld, hi_a, ld, last_a.data_ptr(), _f32(rep_a, "rep_a").data_ptr(),
         tab_b.data_ptr(), m_b.data_ptr(), v_b.data_ptr(), tab_b.shape[0], idx_b.sorted_ids.data_ptr(), idx_b.sorted_pos.data_ptr(),
-        g_b.data_ptr(), ld, g_b.data_ptr() + 4 * split, ld, last_b.data_ptr(), _f32(rep_b, "rep_b").data_ptr(), ldr,
-        dim, idx_a.id_type, n, split, step_state.data_ptr(), beta1, beta2, eps, idx_a.seg_ws(dim).data_ptr(), idx_b.seg_ws(dim).data_ptr(),
-        _stream()), "brAdamRowsSortedPairReplayed")
+        g_b.data_ptr(), ld, hi_b, ld, last_b.data_ptr(), _f32(rep_b, "rep_b").data_ptr(), ldr,
+        dim, idx_a.id_type, idx_a.n, idx_b.n if idx_b.n != idx_a.n else 0, split if split else dim, step_state.data_ptr(), beta1, beta2, eps,
+        idx_a.seg_ws(dim).data_ptr(), idx_b.seg_ws(dim).data_ptr(), _stream()), "brAdamRowsSortedPairReplayed")
 
 
 def row_dot(a, b, out=None):

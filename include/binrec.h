@@ -511,10 +511,11 @@ int brNeumfEmbedForwardDeferred(const float* user_tab, const float* user_m, cons
 int brGatherRowsDeferred(const float* table, const float* m, const float* v, const int32_t* last, int64_t table_rows, int dim,
                          const void* ids, int id_type, int64_t n, const void* step_state, double beta1, double beta2,
                          double eps, float* out, int64_t ld_out, int* err_flag, brStream stream);
-/* the same for two tables of one geometry (dim, n, ld_out) in ONE launch: a row-sharded owner serves its user and its item shard */
+/* the same for two tables of one geometry (dim, ld_out) in ONE launch: a row-sharded owner serves its user and its item shard
+ * (n_b != 0: ids_b has n_b entries instead of n) */
 int brGatherRowsDeferredPair(const float* table_a, const float* m_a, const float* v_a, const int32_t* last_a, int64_t rows_a, const void* ids_a,
                              float* out_a, const float* table_b, const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b,
-                             const void* ids_b, float* out_b, int dim, int id_type, int64_t n, const void* step_state, double beta1,
+                             const void* ids_b, float* out_b, int dim, int id_type, int64_t n, int64_t n_b, const void* step_state, double beta1,
                              double beta2, double eps, int64_t ld_out, int* err_flag, brStream stream);
 /* B1 of the GMF dot on the MF rows the deferred forward stashed, in place: (u_b, i_b) -> (ddot_b i_b, ddot_b u_b). */
 int brMfGradInplace(float* stash_user, float* stash_item, int64_t ld, const float* ddot, int64_t batch, int dim, brStream stream);
@@ -545,14 +546,15 @@ int brAdamRowsSortedPair(float* table_a, float* m_a, float* v_a, int64_t rows_a,
                          double beta1, double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream);
 /* brAdamRowsSortedPair on deferred tables, handed the rows as the step's gathers replayed them (see brAdamRowsSortedDeferredReplayed):
  * replayed_x + pos * ld_replayed = the full row (dim floats) of position pos of table x.  A row-sharded owner updates its user and its
- * item shard with this one launch (both streams have the same number of slots under the fixed-capacity exchange). */
+ * item shard with this one launch (both streams have the same number of slots under the fixed-capacity exchange).  n_b != 0: table b has
+ * n_b positions instead of n (bpr.py: B user positions, 2B [pos | neg] item positions); grads_hi_* both NULL: one gradient source per table. */
 int brAdamRowsSortedPairReplayed(float* table_a, float* m_a, float* v_a, int64_t rows_a, const void* sorted_ids_a, const int32_t* sorted_pos_a,
                                  const float* grads_a, int64_t ldg_a, const float* grads_hi_a, int64_t ldg_hi_a, int32_t* last_a,
                                  const float* replayed_a,
                                  float* table_b, float* m_b, float* v_b, int64_t rows_b, const void* sorted_ids_b, const int32_t* sorted_pos_b,
                                  const float* grads_b, int64_t ldg_b, const float* grads_hi_b, int64_t ldg_hi_b, int32_t* last_b,
                                  const float* replayed_b, int64_t ld_replayed,
-                                 int dim, int id_type, int64_t n, int split, const void* step_state,
+                                 int dim, int id_type, int64_t n, int64_t n_b, int split, const void* step_state,
                                  double beta1, double beta2, double eps, float* seg_ws_a, float* seg_ws_b, brStream stream);
 int brAdamFlush(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim, const void* step_state,
                 double beta1, double beta2, double eps, brStream stream);
