@@ -19,6 +19,7 @@ struct BwdArgs {
   const float* i_mean; const float* i_rstd; double* in_sums;   // BN carried by the input: producer's backward sums (IBN)
   float* gx; int64_t ldgx;                      // may be null (first layer of a tower whose input needs no gradient)
   float* slabs; int64_t slab_elems; int64_t db_off;   // slab of workgroup b: slabs + b*slab_elems; db at +db_off (< 0: not written)
+  float* zero = nullptr; int64_t zero_n = 0;          // floats the launch clears first (slabs beyond its grid, which the reduction still reads)
 };
 
 // dense_fwd.hip: brDropoutKeepBits for the step (resolved step counter + step_add)

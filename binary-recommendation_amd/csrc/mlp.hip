@@ -876,12 +876,13 @@ extern "C" int brDenseBackward(const float* gy, int64_t ldgy, const float* y, in
     br::BwdArgs a{gy, ldgy, y, ldy, x, ldx, W, batch, Ka, N, act, out_mean, out_rstd, out_gamma, bn_sums, inv_batch, in_scale, in_shift,
                   keep, kw, inv_keep, in_mean, in_rstd, in_bn_sums, gx, ldgx, dW_slabs, slab_elems, (int64_t)K * N};
     const int fg = br::dense_bwd_fused_grid(batch);
-    if (fg < n_slabs) {     // the slab count is sized for the two-kernel path: unused slabs must read as zeros
-      hipError_t e = hipMemsetAsync(dW_slabs + (int64_t)fg * slab_elems, 0, sizeof(float) * (size_t)(n_slabs - fg) * (size_t)slab_elems, s);
-      if (e != hipSuccess) { br::set_error("brDenseBackward: memset: %s", hipGetErrorString(e)); return BR_ERR_HIP; }
+    if (fg < n_slabs) {     // the slab count is sized for the two-kernel path: unused slabs must read as zeros (cleared by the launch itself)
+      a.zero = dW_slabs + (int64_t)fg * slab_elems;
+      a.zero_n = (int64_t)(n_slabs - fg) * slab_elems;
     }
     int rc = br::dense_backward_fused(a, s);
     if (rc != BR_OK || Kb == 0) return rc;
+    a.zero = nullptr; a.zero_n = 0;
     // second K-half of a K > 128 layer: dz is formed again (identically); dW rows / gx columns / keep words of that half; db done
     a.x = x + Ka; a.W = W + (int64_t)Ka * N; a.K = Kb;
     if (in_scale) { a.scale = in_scale + Ka; a.shift = in_shift + Ka; }
