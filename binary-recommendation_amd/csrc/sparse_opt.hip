@@ -92,7 +92,7 @@ __device__ __forceinline__ int64_t seg_walk(typename VecT<VEC>::type& acc, const
   return j;
 }
 
-template <typename IdT, int VEC>
+template <typename IdT, int VEC, int W = 1>
 __device__ __forceinline__ void seg_acc_from(typename VecT<VEC>::type& acc, const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n,
                                              int64_t i, int64_t j, IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc,
                                              const float* __restrict__ part, int pdim);
@@ -107,16 +107,19 @@ __device__ __forceinline__ typename VecT<VEC>::type seg_acc(const IdT* __restric
   return acc;
 }
 
-// the rest of a head's sum from position j on (everything in [i, j) is already in acc, in order)
-template <typename IdT, int VEC>
+// the rest of a head's sum from position j on (everything in [i, j) is already in acc, in order); W = positions requested together by the
+// one-by-one part of the walk (same additions in the same order)
+template <typename IdT, int VEC, int W>
 __device__ __forceinline__ void seg_acc_from(typename VecT<VEC>::type& acc, const IdT* __restrict__ sid, const int32_t* __restrict__ spos, int64_t n,
                                              int64_t i, int64_t j, IdT row, const float* __restrict__ g, int64_t ldg, const float* __restrict__ sc,
                                              const float* __restrict__ part, int pdim) {
   using V = typename VecT<VEC>::type;
   const int64_t own_end = part ? ((i / kSegBlock + 1) * kSegBlock < n ? (i / kSegBlock + 1) * kSegBlock : n) : n;
-  // (W = 1 here: the optimizer launches that inline this are bound by HBM latency at 8 waves / SIMD - the registers of a batched walk
-  //  cost them more on ordinary batches than they save on hot ids; the long runs are cut to <= 63 positions by the partials)
-  j = seg_walk<IdT, VEC, 1>(acc, sid, spos, j, own_end, row, g, ldg, sc);
+  // (W = 1 in the row-group launches: they are bound by HBM latency at 8 waves / SIMD - the registers of a batched walk cost them more
+  //  on ordinary batches than they save on hot ids; the long runs are cut to <= 63 positions by the partials.  The one-wave-per-row
+  //  kernel walks four at a time: its ids / positions are scalar loads, and a Zipf batch is full of runs of 5 - 60 positions whose
+  //  heads otherwise pay three dependent round trips per position)
+  j = seg_walk<IdT, VEC, W>(acc, sid, spos, j, own_end, row, g, ldg, sc);
   if (part && j == own_end) {
     // one partial per later block of the run, four at a time (same order of additions)
     for (; j + 3 * kSegBlock < n && sid[j + 3 * kSegBlock] == row; j += 4 * kSegBlock) {
@@ -163,6 +166,55 @@ __global__ __launch_bounds__(256) void segment_partials_kernel(SegJobs jobs, int
     (void)seg_walk<IdT, VEC, 8>(acc, sid, spos, i + 1, end, row, g, ldg, sc);
     vstore<VEC>(jb.part + b * dim + col, acc);
   }
+}
+
+// The same partials with one WAVE per 64-block, for rows of 64 * VEC floats: lane l holds the id and the position of sorted position
+// 64 b + l (one coalesced round trip for the whole block instead of a dependent id -> position -> row chain per 8 positions), the run's
+// length is a ballot, and the rows are requested eight at a time by position (readlane) and added in position order - the order
+// seg_walk adds them in.  On a Zipf(1.05) batch ~70 % of the blocks continue a run: 40 us in the row-group form.
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void segment_partials_wave_kernel(SegJobs jobs, int64_t n_launch, int split) {
+  using V = typename VecT<VEC>::type;
+  constexpr int dim = 64 * VEC;
+  const SegJob& jb = jobs.j[blockIdx.y];
+  const int64_t n = jb.n ? jb.n : n_launch;
+  const IdT* __restrict__ sid = (const IdT*)jb.sid;
+  const int32_t* __restrict__ spos = jb.spos;
+  const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + 1;   // block 0 starts at a head
+  const int64_t i = b * kSegBlock;
+  if (i >= n) return;
+  const int lane = (int)(threadIdx.x & 63);
+  const int64_t q = i + lane < n ? i + lane : n - 1;
+  const IdT my_id = sid[q];
+  const int32_t my_pos = spos[q];
+  const IdT row = sid[i];
+  if (sid[i - 1] != row) return;                            // a head starts here: nobody reads this block's partial
+  // positions of the block that belong to the run: the leading lanes whose id is `row`
+  const uint64_t same = __builtin_amdgcn_ballot_w64(i + lane < n && my_id == row);
+  const int L = same == ~0ull ? 64 : __builtin_ctzll(~same);
+  const int col = lane * VEC;
+  const bool lo = col < split;
+  const float* __restrict__ gp = lo ? jb.g0 + col : jb.g1 + (col - split);
+  const int64_t ldg = lo ? jb.ldg0 : jb.ldg1;
+  const float* __restrict__ sc = jb.sc1;
+  V acc = vzero<VEC>();
+  for (int j0 = 0; j0 < L; j0 += 8) {
+    V v[8];
+    float scl[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t pos = (int64_t)__builtin_amdgcn_readlane(my_pos, (j0 + e) & 63);     // (past L: a row of the block, loaded and dropped)
+      v[e] = vload<VEC>(gp + pos * ldg);
+      scl[e] = (sc && !lo) ? sc[pos] : 1.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (j0 + e >= L) break;
+      const V t = lo ? v[e] : vmul(v[e], scl[e]);            // grow(): the MF halves are scaled as they are read
+      acc = (j0 + e == 0) ? t : vadd(acc, t);
+    }
+  }
+  vstore<VEC>(jb.part + b * dim + col, acc);
 }
 
 template <typename IdT, int VEC>
@@ -427,7 +479,7 @@ __global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, 
       if (open) acc = vadd(acc, g[f]);
     }
     if (open && base + S < n)
-      seg_acc_from<IdT, VEC>(acc, sid, spos, n, i, base + S, id[e], (const float*)gp, ldg, lo ? nullptr : (const float*)sc, jb.part ? jb.part + col : nullptr, dim);
+      seg_acc_from<IdT, VEC, 4>(acc, sid, spos, n, i, base + S, id[e], (const float*)gp, ldg, lo ? nullptr : (const float*)sc, jb.part ? jb.part + col : nullptr, dim);
     // deferred: the g = 0 steps (seen, t-1] of the moments (adam_decay's first two products; theta came replayed)
     V mm = m[e], vv = v[e], tt = th[e];
     for (uint32_t j = seen[e] + 1; j < t; ++j) { mm = vmul(mm, h.b1); vv = vmul(vv, h.b2); }
@@ -871,6 +923,16 @@ static int launch_partials(const SegJob* jobs, int n_jobs, int id_type, int64_t 
   if (blocks <= 0) return BR_OK;
   SegJobs J;
   for (int q = 0; q < 2; ++q) J.j[q] = jobs[q < n_jobs ? q : 0];
+  const int wvec = dim / 64;
+  if (wave_rows_enabled() && dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && g.vec >= wvec) {     // (g.vec: the widest vector the sources' strides honour)
+    const dim3 wgrid((unsigned)ceil_div(blocks, 4), (unsigned)n_jobs);
+    if (id_type == BR_IDS_I32)
+      BR_DISPATCH_VEC(wvec, (segment_partials_wave_kernel<int32_t, VEC><<<wgrid, 256, 0, s>>>(J, n, split)));
+    else
+      BR_DISPATCH_VEC(wvec, (segment_partials_wave_kernel<int64_t, VEC><<<wgrid, 256, 0, s>>>(J, n, split)));
+    BR_CHECK_LAUNCH("segment partials (wave)");
+    return BR_OK;
+  }
   const dim3 grid((unsigned)ceil_div(blocks, 256 >> g.lpr_log2), (unsigned)n_jobs);
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(g.vec, (segment_partials_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(J, n, dim, g.chunks, g.lpr_log2, split)));
