@@ -184,11 +184,22 @@ def bpr_leg(dev, U, I, F, B, seed):
             one()
         ms = loop_ms(one)
         e.check_ids()
+        ms_graph = None
+        if impl == "deferred" and opt == "adam_dense":
+            # the same step replayed as one hipGraph (BPREngine.enable_graph): the eager step is a dozen launches from the Python host
+            try:
+                e.enable_graph(B)
+                ms_graph = loop_ms(one)
+                e.check_ids()
+            except Exception as exc:  # noqa: BLE001
+                log(f"BPR graph capture failed: {type(exc).__name__}: {exc}")
         u, p, n = trip[0]
         uu = int(torch.unique(u).numel()) + int(torch.unique(torch.cat([p, n])).numel())
         # 3 rows in, 3 row gradients out and in again, touched rows of table + m + v read and written; the sweep: every row of both tables
         alg = B * 3 * F * 4 * 3 + (6 * 4 * F * (U + I) if impl == "sweep" and opt == "adam_dense" else uu * 6 * 4 * F)
         out[name] = {"ms_per_step": ms, "triplets_per_s": B / ms * 1e3, "algorithmic_bytes_per_step": alg, "frac_of_hbm_peak": alg / ms * 1e-6 / HBM_PEAK_GBPS}
+        if ms_graph is not None:
+            out[name]["hipgraph_replay"] = {"ms_per_step": ms_graph, "triplets_per_s": B / ms_graph * 1e3}
         del e
         torch.cuda.empty_cache()
     out["adam_dense"]["note"] = "Keras' non-lazy Adam by per-row deferred replay (bit-equal to adam_dense_sweep, tests/test_gpu_twotower_bpr.py)"
