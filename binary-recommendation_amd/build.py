@@ -36,10 +36,10 @@ def sources() -> list[str]:
 def _digest(paths: list[str]) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
-        h.update(p.encode())
-        with open(p, "rb") as f:
+        h.update(os.path.basename(p).encode())     # (not the absolute path: the tree is copied to another root on the GPU box, where a
+        with open(p, "rb") as f:                   #  path-dependent digest made every build() there recompile all sources)
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(f for f in FLAGS if not os.path.isabs(f)).encode())
     return h.hexdigest()
 
 

@@ -1276,8 +1276,9 @@ extern "C" int brStepStateSet(void* step_state, uint32_t step, double lr, double
   const double tt = step > 0 ? (double)step : 1.0;
   h.alpha_t = (float)(lr * sqrt(1.0 - pow(beta2, tt)) / (1.0 - pow(beta1, tt)));
   // pageable source: hipMemcpyAsync returns after the copy has been staged, `h` may leave scope
-  if (hipMemcpyAsync(step_state, &h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
-    set_error("brStepStateSet: copy failed");
+  const hipError_t ce = hipMemcpyAsync(step_state, &h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (ce != hipSuccess) {
+    set_error("brStepStateSet: copy failed: %s", hipGetErrorString(ce));
     return BR_ERR_HIP;
   }
   (void)hipStreamSynchronize((hipStream_t)stream);
