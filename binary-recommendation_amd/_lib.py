@@ -128,6 +128,10 @@ def load():
         raise BinrecError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+    # torch first: its wheel carries its own libamdhip64.so, and the process must end up with ONE HIP runtime.  Loaded after torch, our
+    # library's NEEDED libamdhip64 resolves to the copy torch already mapped; loaded before it, the system copy under /opt/rocm comes in
+    # as a second runtime and every HIP call from this library fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (restype, argtypes, _names) in _protos.items():
