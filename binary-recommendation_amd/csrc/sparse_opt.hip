@@ -117,7 +117,7 @@ __device__ __forceinline__ void seg_acc_from(typename VecT<VEC>::type& acc, cons
   const int64_t own_end = part ? ((i / kSegBlock + 1) * kSegBlock < n ? (i / kSegBlock + 1) * kSegBlock : n) : n;
   // (W = 1 in the row-group launches: they are bound by HBM latency at 8 waves / SIMD - the registers of a batched walk cost them more
   //  on ordinary batches than they save on hot ids; the long runs are cut to <= 63 positions by the partials.  The one-wave-per-row
-  //  kernel walks four at a time: its ids / positions are scalar loads, and a Zipf batch is full of runs of 5 - 60 positions whose
+  //  kernel walks eight at a time: its ids / positions are scalar loads, and a Zipf batch is full of runs of 5 - 60 positions whose
   //  heads otherwise pay three dependent round trips per position)
   j = seg_walk<IdT, VEC, W>(acc, sid, spos, j, own_end, row, g, ldg, sc);
   if (part && j == own_end) {
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, 
       if (open) acc = vadd(acc, g[f]);
     }
     if (open && base + S < n)
-      seg_acc_from<IdT, VEC, 4>(acc, sid, spos, n, i, base + S, id[e], (const float*)gp, ldg, lo ? nullptr : (const float*)sc, jb.part ? jb.part + col : nullptr, dim);
+      seg_acc_from<IdT, VEC, 8>(acc, sid, spos, n, i, base + S, id[e], (const float*)gp, ldg, lo ? nullptr : (const float*)sc, jb.part ? jb.part + col : nullptr, dim);
     // deferred: the g = 0 steps (seen, t-1] of the moments (adam_decay's first two products; theta came replayed)
     V mm = m[e], vv = v[e], tt = th[e];
     for (uint32_t j = seen[e] + 1; j < t; ++j) { mm = vmul(mm, h.b1); vv = vmul(vv, h.b2); }
