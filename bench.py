@@ -78,7 +78,42 @@ def read_probe(lib):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
-def make_batches(n, B, U, I, dev, seed, zipf):
+def seed_steady_state(eng, uniq_u, uniq_i, since_flush, t0):
+    """--steady-state-lags: put the deferred tables into the state of a LONG run without running it.  In a long run every row carries
+    moments and sits some steps behind the step counter: a row comes up in a step with probability p = unique rows per step / rows,
+    so its lag is geometric with mean 1 / p - 1 (191 steps for the 12.5 M-row user shard of config 5 at 65 536 pairs per step) - capped
+    by the engine's periodic flush, `since_flush` steps ago here.  A short cycle of batches cannot produce that state (a 25-batch cycle
+    caps every lag at 25 and leaves most rows at m = v = 0: profiles/r02/bench_config5_shard_r02.json).  Seeds: m, v of every row from a
+    gradient scale of 1e-6 (|g| of a batch-mean loss at this batch size), last[row] = t0 - 1 - lag, the step state (alpha ring
+    included) at step t0.  -> what was seeded, for the bench line."""
+    _lib = importlib.import_module("binary-recommendation_amd._lib")
+    ops = importlib.import_module("binary-recommendation_amd.ops")
+    lib, cfg, info = _lib.load(), eng.cfg, {}
+    assert eng.deferred and t0 > since_flush >= 0 and t0 >= eng.ALPHA_RING
+    gen = torch.Generator(device=eng.device).manual_seed(777)
+    for k, uniq in (("user", uniq_u), ("item", uniq_i)):
+        rows = eng.fused[k].shape[0]
+        gsc = torch.empty_like(eng.fused[k]).normal_(0.0, 1e-6, generator=gen)
+        eng.fused_m[k].copy_(gsc).mul_(1.0 - cfg.beta1)
+        eng.fused_v[k].copy_(gsc).square_().mul_(1.0 - cfg.beta2)
+        del gsc
+        p = min(1.0, uniq / rows)
+        lag = torch.empty(rows, device=eng.device, dtype=torch.float32).geometric_(p, generator=gen).sub_(1.0).clamp_(max=float(since_flush))
+        eng.last[k].copy_((t0 - 1 - lag).to(torch.int32))
+        info[k] = {"rows": rows, "p_touch_per_step": p, "mean_lag": float(lag.mean().item()), "frac_capped_by_flush": float((lag >= since_flush).float().mean().item())}
+        del lag
+    # the alpha ring of the last BR_ALPHA_RING steps: set the state RING steps back and advance it to t0 (1024 one-block launches)
+    _lib.check(lib.brStepStateSet(eng.step_state.data_ptr(), t0 - eng.ALPHA_RING, cfg.lr, cfg.beta1, cfg.beta2, ops._stream()), "brStepStateSet")
+    for _ in range(eng.ALPHA_RING):
+        _lib.check(lib.brStepStateAdvance(eng.step_state.data_ptr(), cfg.lr, cfg.beta1, cfg.beta2, None, 0, ops._stream()), "brStepStateAdvance")
+    torch.cuda.synchronize()
+    eng.t, eng._flush_t, eng._stale = t0, t0 - since_flush, True
+    info.update({"t0": t0, "steps_since_flush": since_flush, "replay": cfg.replay,
+                 "note": "lags geometric with mean rows / unique rows per step - 1, capped by the last flush; every row carries moments"})
+    return info
+
+
+def make_batches(n, B, U, I, dev, seed, zipf, idt=torch.int32):
     g = torch.Generator(device="cpu").manual_seed(seed)
     out = []
     for _ in range(n):
@@ -89,7 +124,7 @@ def make_batches(n, B, U, I, dev, seed, zipf):
             users = torch.randint(0, U, (B,), generator=g)
             items = torch.randint(0, I, (B,), generator=g)
         labels = (torch.rand(B, generator=g) < 0.25).float()   # 1 pos : 3 neg (NeuMFModel.py:102)
-        out.append((users.int().to(dev), items.int().to(dev), labels.to(dev)))
+        out.append((users.to(idt).to(dev), items.to(idt).to(dev), labels.to(dev)))
     return out
 
 
@@ -316,6 +351,12 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the gather / Zipf / BPR / TwoTower legs")
     ap.add_argument("--cycle", type=int, default=256, help="distinct synthetic batches cycled (the tables are primed with one pass over them)")
     ap.add_argument("--profile-steps", type=int, default=10, help="graph mode: eager steps probed per kernel before the timed region")
+    ap.add_argument("--int64", action="store_true", help="int64 ids (config 5: 100 M users)")
+    ap.add_argument("--steady-state-lags", action="store_true",
+                    help="single GPU, deferred tables: seed every row with moments and a lag from the long-run distribution instead of priming with the "
+                         "batch cycle (seed_steady_state) - the state a table far larger than steps x batch is in after a long run")
+    ap.add_argument("--since-flush", type=int, default=700, help="--steady-state-lags: steps since the engine's last periodic flush (caps the lags)")
+    ap.add_argument("--replay", default=None, choices=["fast", "exact"], help="form of the deferred replay (NeuMFConfig.replay; default fast)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -357,15 +398,16 @@ def main():
     row0 = rank * B
 
     impl = args.dense_impl or "deferred"
+    idt = torch.int64 if args.int64 else torch.int32
 
     def build(optimizer, dense_impl=impl):
         # N > 1: per-replica BatchNorm = what the reference's MirroredStrategy does with a plain BatchNormalization
         # [TF-sem] (and no BatchNorm collective in the step); --sync-bn makes the statistics global
-        cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl, sync_bn=args.sync_bn)
+        cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl, sync_bn=args.sync_bn, replay=args.replay)
         if ctx is None:
-            return neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=1)
+            return neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=1, id_dtype=idt)
         # fixed-capacity exchange (no host sync in the step) for uniform ids; Zipf heads overflow 1.25 x batch / world slots per peer
-        return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1, exchange="exact" if args.zipf else "padded")
+        return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1, id_dtype=idt, exchange="exact" if args.zipf else "padded")
 
     log(f"building engine: {U} users x {I} items, dim {D}, batch {B}/GPU, world {world}, {args.optimizer}")
     eng = build(args.optimizer)
@@ -373,7 +415,7 @@ def main():
     # distinct batches cycled.  Long enough that (almost) every row of the tables comes up within a pass: the deferred kernels' replay work per
     # step is the number of rows that carry moments - a 32-batch cycle reaches 88 % of 1 M users and flatters the step by ~4 %
     n_batches = max(1, args.cycle)
-    batches = make_batches(n_batches, B, U, I, dev, 1234 + rank, args.zipf)
+    batches = make_batches(n_batches, B, U, I, dev, 1234 + rank, args.zipf, idt)
 
     # ---- per-kernel table, then the timed region.
     #      single GPU (default): (1) an eager pass with a HIP event pair around every launch of the step driver, the dedup sorts kept
@@ -435,7 +477,13 @@ def main():
     # warm-up outside the probe, at least one pass over the batch cycle: the tables are then in the state of a RUNNING job (every row of
     # the cycle carries moments and a lag).  On fresh tables (m = v = 0) the deferred kernels skip their replay arithmetic and look
     # ~30 % faster than they are in steady state.
-    prime = max(args.warmup, n_batches if deferred_mode else 0)
+    seeded = None
+    if args.steady_state_lags:
+        if not (deferred_mode and ctx is None):
+            raise SystemExit("--steady-state-lags: single GPU, adam_dense by deferred replay")
+        seeded = seed_steady_state(eng, uniq_u, uniq_i, args.since_flush, 4 * eng.ALPHA_RING)
+        log(f"steady-state lags seeded: user mean lag {seeded['user']['mean_lag']:.1f}, item {seeded['item']['mean_lag']:.1f} steps")
+    prime = max(args.warmup, n_batches if (deferred_mode and seeded is None) else 0)
     run_steps(eng, batches, prime, row0, batch_total)
     pyprobe = None
     eager_profile = None
@@ -602,7 +650,7 @@ def main():
         except Exception as exc:  # noqa: BLE001
             log(f"whole-step graph leg failed: {exc}")
             eng.disable_graph()
-    if deferred_mode and ctx is None:
+    if deferred_mode and ctx is None and seeded is None:
         # the deferred tables must be flushed at least every BR_ALPHA_RING-8 steps: run up to that point and
         # time the flush a long job pays there (worst case: every row replays a full ring of steps)
         period = eng.ALPHA_RING - 8
@@ -665,7 +713,7 @@ def main():
         legs["gather"] = gather_leg(ops, dev, args.users, args.items, D, B, 99)
         torch.cuda.empty_cache()
         log("legs: zipf")
-        zb = make_batches(n_batches, B, U, I, dev, 4321, True)
+        zb = make_batches(n_batches, B, U, I, dev, 4321, True, idt)
         ez = build(args.optimizer)
         run_steps(ez, zb, len(zb), row0, batch_total)       # one pass over the cycle: steady state, as for the headline
         ez.enable_graph(B)
@@ -701,7 +749,7 @@ def main():
                        "global_batch": batch_total, "parallelism": "single GPU" if ctx is None else f"row-sharded tables x{world} + dp{world}, {'global' if args.sync_bn else 'per-replica'} BatchNorm",
                        "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
             "roofline": roofline, "cpu_baseline": cpu, "legs": legs, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
-            "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i},
+            "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i}, "steady_state_lags": seeded,
             "launch_mode": ((f"hipGraph replay of the whole step, one graph per step; {dom_key} bracketed by event-record nodes inside every 4th replay (a HIP event pair each)"
                              if graph_exec is not None else f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)") if use_graph
                             else "eager launches (brNeumfStepRun)"),

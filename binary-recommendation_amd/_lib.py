@@ -86,6 +86,7 @@ def parse_enums(path: str = HEADER) -> dict:
     return out
 
 
+_DEBUG_SYNC = os.environ.get("BR_DEBUG_SYNC", "0") not in ("", "0")
 _lib = None
 _protos = None
 _probe = None   # optional callable pair (before(name, args), after(name, args)) — bench.py's HIP-event timing
@@ -107,6 +108,21 @@ class _Lib:
 
     @staticmethod
     def _wrap(name, fn):
+        if _DEBUG_SYNC:
+            # BR_DEBUG_SYNC=1: every entry point is named on stderr before it runs and the device is synchronised behind it, so an
+            # asynchronous GPU fault (which otherwise surfaces at some later, unrelated host sync) ends the process right after the line
+            # that names the launch that caused it.  Diagnostic mode: serialises the host with the GPU.
+            def call_sync(*args):
+                import sys
+                import torch
+                sys.stderr.write(f"[binrec] {name}\n"); sys.stderr.flush()
+                rc = fn(*args)
+                if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize()
+                return rc
+            call_sync.__name__ = name
+            return call_sync
+
         def call(*args):
             p = _probe
             if p is None:

@@ -24,8 +24,11 @@ class BPREngine:
     BETA1, BETA2, EPS = 0.9, 0.999, 1e-7
 
     def __init__(self, num_users: int, num_items: int, num_factor: int, device, max_batch: int, lr: float = 1e-3,
-                 optimizer: str = "adam_dense", id_dtype=torch.int32, init_seed: int = 0, dense_impl: str = "deferred"):
+                 optimizer: str = "adam_dense", id_dtype=torch.int32, init_seed: int = 0, dense_impl: str = "deferred", replay: str | None = None):
         assert optimizer in ("adam_dense", "adam_lazy") and dense_impl in ("deferred", "sweep")
+        import os
+        self.replay = os.environ.get("BR_REPLAY", "fast") if replay is None else replay      # NeuMFConfig.replay: form of the deferred replay
+        assert self.replay in ("fast", "exact")
         self.device, self.max_batch, self.lr, self.optimizer, self.id_dtype = torch.device(device), int(max_batch), lr, optimizer, id_dtype
         self.dim = int(num_factor)
         self.deferred = optimizer == "adam_dense" and dense_impl == "deferred"
@@ -46,7 +49,7 @@ class BPREngine:
         if self.deferred:
             self.user_last = torch.zeros(self._user.shape[0], dtype=torch.int32, device=dev)
             self.item_last = torch.zeros(self._item.shape[0], dtype=torch.int32, device=dev)
-            self.step_state = torch.zeros(_lib.load().brStepStateBytes() // 4, dtype=torch.int32, device=dev)
+            self.step_state = ops.new_step_state(dev, self.BETA1, self.BETA2, self.EPS, self.replay)
             _lib.check(_lib.load().brStepStateSet(self.step_state.data_ptr(), 0, lr, self.BETA1, self.BETA2, ops._stream()), "brStepStateSet")
             self.r_user = torch.empty(B, self.dim, device=dev)            # rows as of the previous step (replayed in registers)
             self.r_item = torch.empty(2 * B, self.dim, device=dev)
@@ -141,18 +144,26 @@ class BPREngine:
         users = torch.zeros(B, dtype=self.id_dtype, device=self.device)
         ids2 = self.item_ids[:2 * B]
         ids2.zero_()
-        # every kernel runs once outside a capture first (code objects load on first launch); the model state is put back afterwards
-        keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state_dict().items()}
+        # every kernel runs once outside a capture first (code objects load on first launch); the model state is put back afterwards.
+        # The dry run's ids are all 0: it moves row 0 of each table and nothing else (deferred tables) - that row, with its moments and
+        # `last`, is what is kept.  NOT state_dict(): that flushes, and a flush in the middle of a run resets every row's lag (and, with the
+        # fast replay, is no longer bit-neutral: one catch-up over (s, t] and two over (s, u], (u, t] round differently).
+        z = torch.zeros(1, dtype=torch.long, device=self.device)
+        keep = [(t, t[z].clone()) for t in (self._user, self.user_m, self.user_v, self.user_last, self._item, self.item_m, self.item_v, self.item_last)]
         keep_loss = self.loss_slots.clone()
+
+        def restore():
+            for t, row in keep:
+                t[z] = row
+            self.loss_slots.copy_(keep_loss)
+            _lib.check(_lib.load().brStepStateSet(self.step_state.data_ptr(), self.t, self.lr, self.BETA1, self.BETA2, ops._stream()), "brStepStateSet")
         self._step_body(users, ids2, B, B)
         torch.cuda.synchronize(self.device)
-        self.load_state_dict(keep)
-        self.loss_slots.copy_(keep_loss)
+        restore()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._step_body(users, ids2, B, B)
-        self.load_state_dict(keep)              # (the capture executes nothing; this re-syncs the device step counter after the dry run)
-        self.loss_slots.copy_(keep_loss)
+        restore()                               # (the capture executes nothing; this re-syncs the device step counter after the dry run)
         self._graph = {"batch": B, "users": users, "graph": g}
 
     def disable_graph(self):

@@ -114,6 +114,134 @@ __device__ __forceinline__ void adam_replay_uniform(V& th, V& m, V& v, uint32_t 
   }
 }
 
+// ---- fast replay (StepStateDev::fast, include/binrec.h BR_REPLAY_FAST) --------------------------------------------------------------
+// The same recurrence in a cheaper form.  For the g = 0 steps v_j = b2^j v exactly, so sqrt(v_j) = c^j sqrt(v) with c = sqrt(b2) and
+// d_j = sqrt(v_j) + eps obeys d_j = c d_{j-1} + eps (1 - c): one v_sqrt per row visit instead of one per step.  1 / d_j comes from
+// 1 / d_{j-1} by one Newton step r <- r (2 - d r): d_j / d_{j-1} lies in [c, 1], so the guess is off by <= 1 - c = 5e-4 and the
+// result by its square, 2.5e-7 - the error class of the v_rcp_f32 the exact form uses, and no quarter-rate op in the loop
+// (measured, tools/diag/replay_bench.cpp: 0.015 against 0.027 ns per row of 128 floats and step).  m decays by b1 per step: after
+// `trunc` steps the remaining updates of theta are below one ulp of the first (7 (b1 / c)^trunc / (1 - b1 / c) <= 2^-23, 192 steps at
+// the Keras defaults), so theta is replayed over min(lag, trunc) steps only, and the moments of the whole lag are one product each
+// with b^lag from the tables in the step state.
+struct FastRp {
+  float c, eps_c;
+  uint32_t trunc;
+};
+__device__ __forceinline__ FastRp fast_rp(const StepStateDev* __restrict__ ss) { return FastRp{ss->sqrt_b2, ss->eps_c, ss->trunc}; }
+
+__device__ __forceinline__ void fast_open(pk2 v, float eps, pk2& d, pk2& r) {
+  d = (pk2){__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)} + eps;
+  r = (pk2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ void fast_open(float v, float eps, float& d, float& r) {
+  d = __builtin_amdgcn_sqrtf(v) + eps;
+  r = __builtin_amdgcn_rcpf(d);
+}
+__device__ __forceinline__ void fast_step(pk2& th, pk2& m, pk2& d, pk2& r, float alpha, float b1, const FastRp& f) {
+  m = m * b1;
+  d = __builtin_elementwise_fma(d, (pk2){f.c, f.c}, (pk2){f.eps_c, f.eps_c});
+  r = r * __builtin_elementwise_fma(-d, r, (pk2){2.f, 2.f});
+  th = __builtin_elementwise_fma(-(m * alpha), r, th);
+}
+__device__ __forceinline__ void fast_step(float& th, float& m, float& d, float& r, float alpha, float b1, const FastRp& f) {
+  m = m * b1;
+  d = __builtin_fmaf(d, f.c, f.eps_c);
+  r = r * __builtin_fmaf(-d, r, 2.f);
+  th = __builtin_fmaf(-(m * alpha), r, th);
+}
+// the replay state of one lane's vector of a row: running theta, running m, d = sqrt(v_j) + eps, r = 1 / d
+template <typename V> struct FastSt;
+template <> struct FastSt<float> {
+  float th, m, d, r;
+  __device__ __forceinline__ void open(float t, float mm, float v, float eps) { th = t; m = mm; fast_open(v, eps, d, r); }
+  __device__ __forceinline__ void step(float a, float b1, const FastRp& f) { fast_step(th, m, d, r, a, b1, f); }
+  __device__ __forceinline__ float theta() const { return th; }
+};
+template <> struct FastSt<float2> {
+  pk2 th, m, d, r;
+  __device__ __forceinline__ void open(float2 t, float2 mm, float2 v, float eps) { th = (pk2){t.x, t.y}; m = (pk2){mm.x, mm.y}; fast_open((pk2){v.x, v.y}, eps, d, r); }
+  __device__ __forceinline__ void step(float a, float b1, const FastRp& f) { fast_step(th, m, d, r, a, b1, f); }
+  __device__ __forceinline__ float2 theta() const { return make_float2(th.x, th.y); }
+};
+template <> struct FastSt<float4> {
+  pk2 th0, m0, d0, r0, th1, m1, d1, r1;
+  __device__ __forceinline__ void open(float4 t, float4 mm, float4 v, float eps) {
+    th0 = (pk2){t.x, t.y}; m0 = (pk2){mm.x, mm.y}; fast_open((pk2){v.x, v.y}, eps, d0, r0);
+    th1 = (pk2){t.z, t.w}; m1 = (pk2){mm.z, mm.w}; fast_open((pk2){v.z, v.w}, eps, d1, r1);
+  }
+  __device__ __forceinline__ void step(float a, float b1, const FastRp& f) { fast_step(th0, m0, d0, r0, a, b1, f); fast_step(th1, m1, d1, r1, a, b1, f); }
+  __device__ __forceinline__ float4 theta() const { return make_float4(th0.x, th0.y, th1.x, th1.y); }
+};
+__device__ __forceinline__ uint32_t pow_index(uint32_t k) { return k < (uint32_t)BR_ALPHA_RING ? k : (uint32_t)BR_ALPHA_RING - 1u; }
+
+// the moments of a row after `lag` g = 0 steps, one product each (every kernel forms them from the STORED m, v this way, so a row's
+// moments do not depend on which kernel caught it up)
+template <typename V>
+__device__ __forceinline__ void fast_moments(V& m, V& v, uint32_t lag, const StepStateDev* __restrict__ ss) {
+  const uint32_t k = pow_index(lag);
+  m = vmul(m, ss->pow1[k]);
+  v = vmul(v, ss->pow2[k]);
+}
+
+// fast form of adam_replay_uniform: steps (from, upto] of theta; m, v are left as stored (fast_moments brings them up).  Eight steps'
+// alphas per scalar load (s_load_dwordx8 from the mirrored ring): with one load per step the loop waits for a scalar-cache round trip
+// in every iteration.
+template <typename V>
+__device__ __forceinline__ void adam_replay_fast_uniform(V& th, const V& m, const V& v, uint32_t from, uint32_t upto, const StepStateDev* __restrict__ ss,
+                                                         const AdamHp& h) {
+  if (__builtin_amdgcn_ballot_w64(!(all_zero(m) && all_zero(v))) == 0) return;
+  const FastRp f = fast_rp(ss);
+  const uint32_t lag = upto - from;
+  const uint32_t end = from + (lag < f.trunc ? lag : f.trunc);           // last step theta is replayed for
+  FastSt<V> st;
+  st.open(th, m, v, h.eps);
+  uint32_t j = from + 1;
+  for (; j + 7 <= end; j += 8) {
+    const float* __restrict__ rp = ss->alpha_hist + (j & (BR_ALPHA_RING - 1));
+    float a8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a8[k] = rp[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st.step(a8[k], h.b1, f);
+  }
+  for (; j <= end; ++j) st.step(ss->alpha_hist[j & (BR_ALPHA_RING - 1)], h.b1, f);
+  th = st.theta();
+}
+// per-lane form (row-group kernels: several rows with different lags per wave; alphas from the ring image in LDS)
+template <typename V>
+__device__ __forceinline__ void adam_replay_fast(V& th, const V& m, const V& v, uint32_t from, uint32_t upto, const float* ring, const FastRp& f,
+                                                 const AdamHp& h) {
+  if (all_zero(m) && all_zero(v)) return;
+  const uint32_t lag = upto - from;
+  const uint32_t end = from + (lag < f.trunc ? lag : f.trunc);
+  FastSt<V> st;
+  st.open(th, m, v, h.eps);
+  for (uint32_t j = from + 1; j <= end; ++j) st.step(ring[j & (BR_ALPHA_RING - 1)], h.b1, f);
+  th = st.theta();
+}
+
+// Replay of steps (from, upto] in the form the step state asks for.  MOMENTS: m and v are brought to step `upto` too (the optimizer
+// and the flush store them; a lookup only needs theta).
+template <bool MOMENTS, typename V>
+__device__ __forceinline__ void adam_catch_up_uniform(V& th, V& m, V& v, uint32_t from, uint32_t upto, const StepStateDev* __restrict__ ss, const AdamHp& h) {
+  if (ss->fast) {
+    adam_replay_fast_uniform(th, m, v, from, upto, ss, h);
+    if (MOMENTS) fast_moments(m, v, upto - from, ss);
+  } else {
+    adam_replay_uniform(th, m, v, from, upto, ss, h);
+  }
+}
+template <bool MOMENTS, typename V>
+__device__ __forceinline__ void adam_catch_up(V& th, V& m, V& v, uint32_t from, uint32_t upto, const float* ring, const StepStateDev* __restrict__ ss,
+                                              const AdamHp& h) {
+  if (ss->fast) {
+    adam_replay_fast(th, m, v, from, upto, ring, fast_rp(ss), h);
+    if (MOMENTS) fast_moments(m, v, upto - from, ss);
+  } else {
+    adam_replay(th, m, v, from, upto, ring, h);
+  }
+}
+
 // whole workgroup: copy the ring into LDS (call before any early return; ends with a barrier)
 __device__ __forceinline__ void stage_alpha_ring(float* lds_ring, const StepStateDev* ss) {
   for (int k = threadIdx.x; k < BR_ALPHA_RING; k += blockDim.x) lds_ring[k] = ss->alpha_hist[k];

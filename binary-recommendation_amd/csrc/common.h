@@ -18,7 +18,14 @@ struct StepStateDev {
   uint32_t step;
   float alpha_t;
   double pow_b1, pow_b2;             // beta1^step, beta2^step (running products: no pow() on the step's critical path)
-  float alpha_hist[BR_ALPHA_RING];   // alpha_j at [j & (BR_ALPHA_RING-1)] for the last BR_ALPHA_RING steps
+  // alpha_j at [j & (BR_ALPHA_RING-1)] for the last BR_ALPHA_RING steps, followed by a mirror of the first BR_RING_MIRROR entries, so that
+  // the BR_RING_MIRROR alphas from any index on are contiguous (the fast replay takes eight steps' alphas in one scalar load)
+  float alpha_hist[BR_ALPHA_RING + BR_RING_MIRROR];
+  // ---- replay form (brStepStateInit; all zero = the exact replay) ----
+  uint32_t fast;                     // 1: fast replay (adam_math.h adam_replay_fast*), 0: the exact chain (bit-equal to the dense sweep)
+  uint32_t trunc;                    // fast: theta is replayed over at most this many steps of a lag (the rest moves it by < 1 ulp of the first step)
+  float sqrt_b2, eps_c;              // sqrt(beta2), eps (1 - sqrt(beta2)): d_j = sqrt(v_j) + eps obeys d_j = sqrt_b2 d_{j-1} + eps_c
+  float pow1[BR_ALPHA_RING], pow2[BR_ALPHA_RING];   // beta1^k, beta2^k (k < BR_ALPHA_RING): the moments of a lag of k steps in one product
 };
 // arguments of the step-state advance (step += 1, alpha_t, ring entry, the step's double scratch zeroed): a launch of its own
 // (brStepStateAdvance) or one extra workgroup of the chunk-rank launch (neumf_step.cpp defer_advance)

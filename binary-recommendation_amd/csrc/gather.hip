@@ -153,13 +153,13 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_deferred_kernel(
     V im = vload<VEC>(item_tab + io), vf = vload<VEC>(item_tab + io + dim);
     if (lu + 1 < t) {
       V m0 = vload<VEC>(user_m + uo), v0 = vload<VEC>(user_v + uo), m1 = vload<VEC>(user_m + uo + dim), v1 = vload<VEC>(user_v + uo + dim);
-      adam_replay(um, m0, v0, lu, t - 1, ring, h);
-      adam_replay(uf, m1, v1, lu, t - 1, ring, h);
+      adam_catch_up<false>(um, m0, v0, lu, t - 1, ring, ss, h);
+      adam_catch_up<false>(uf, m1, v1, lu, t - 1, ring, ss, h);
     }
     if (li + 1 < t) {
       V m0 = vload<VEC>(item_m + io), v0 = vload<VEC>(item_v + io), m1 = vload<VEC>(item_m + io + dim), v1 = vload<VEC>(item_v + io + dim);
-      adam_replay(im, m0, v0, li, t - 1, ring, h);
-      adam_replay(vf, m1, v1, li, t - 1, ring, h);
+      adam_catch_up<false>(im, m0, v0, li, t - 1, ring, ss, h);
+      adam_catch_up<false>(vf, m1, v1, li, t - 1, ring, ss, h);
     }
     if (!uok) { um = vzero<VEC>(); uf = vzero<VEC>(); }
     if (!iok) { im = vzero<VEC>(); vf = vzero<VEC>(); }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_kernel(
     V th = vload<VEC>(table + off);
     if (seen + 1 < t) {
       V m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
-      adam_replay(th, m, v, seen, t - 1, ring, h);
+      adam_catch_up<false>(th, m, v, seen, t - 1, ring, ss, h);
     }
     vstore<VEC>(out + b * ld_out + c * VEC, ok ? th : vzero<VEC>());
   }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_wave_kernel(
   V th = vload<VEC>(table + off);
   if (seen + 1 < t) {
     V m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
-    adam_replay_uniform(th, m, v, seen, t - 1, ss, h);
+    adam_catch_up_uniform<false>(th, m, v, seen, t - 1, ss, h);
   }
   vstore<VEC>(out + b * ld_out + lane * VEC, ok ? th : vzero<VEC>());
 }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_wave_pair_kernel(Gat
   V th = vload<VEC>(jb.table + off);
   if (seen + 1 < t) {
     V m = vload<VEC>(jb.M + off), v = vload<VEC>(jb.Vv + off);
-    adam_replay_uniform(th, m, v, seen, t - 1, ss, h);
+    adam_catch_up_uniform<false>(th, m, v, seen, t - 1, ss, h);
   }
   vstore<VEC>(jb.out + b * ld_out + lane * VEC, ok ? th : vzero<VEC>());
 }

@@ -39,8 +39,8 @@ __device__ __forceinline__ void lookup_wave_pair(const LookupArgs& a, int64_t b,
   V um = vzero<VEC>(), uv = vzero<VEC>(), im = vzero<VEC>(), iv = vzero<VEC>();
   if (lu + 1 < t) { um = vload<VEC>(a.user_m + uo); uv = vload<VEC>(a.user_v + uo); }
   if (li + 1 < t) { im = vload<VEC>(a.item_m + io); iv = vload<VEC>(a.item_v + io); }
-  if (li + 1 < t) adam_replay_uniform(ir, im, iv, li, t - 1, ss, a.h);
-  if (lu + 1 < t) adam_replay_uniform(ur, um, uv, lu, t - 1, ss, a.h);
+  if (li + 1 < t) adam_catch_up_uniform<false>(ir, im, iv, li, t - 1, ss, a.h);
+  if (lu + 1 < t) adam_catch_up_uniform<false>(ur, um, uv, lu, t - 1, ss, a.h);
   if (!uok) ur = vzero<VEC>();
   if (!iok) ir = vzero<VEC>();
   const bool mlp = lane < 32;

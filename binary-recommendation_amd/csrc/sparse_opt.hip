@@ -15,6 +15,7 @@
 #include "dense.h"
 
 #include <algorithm>
+#include <vector>
 #include <math.h>
 #include <stddef.h>
 #include <hipcub/hipcub.hpp>
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void adam_rows_sorted_kernel(AdamRowsJobs jobs
     const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, sid[i], g, ldg, col < split ? nullptr : jb.sc1, jb.part ? jb.part + col : nullptr, dim);
     const int64_t off = row * dim + col;
     V th = vload<VEC>(table + off), m = vload<VEC>(M + off), v = vload<VEC>(Vv + off);
-    if (last && seen + 1 < t) adam_replay(th, m, v, seen, t - 1, ring, h);
+    if (last && seen + 1 < t) adam_catch_up<true>(th, m, v, seen, t - 1, ring, ss, h);
     adam_update(th, m, v, acc, h);
     vstore<VEC>(table + off, th);
     vstore<VEC>(M + off, m);
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, 
     seen_v[e] = *(last ? last + row : (gwi32*)&kZeroI);
   }
   const uint32_t t = last ? ss->step : 0u;
+  const bool fast = last && ss->fast;                          // replay form of the deferred tables (adam_math.h)
   uint32_t seen[S];
 #pragma unroll
   for (int e = 0; e < S; ++e) {                                               // one wait for the whole strip
@@ -482,7 +484,10 @@ __global__ __launch_bounds__(256) void adam_rows_wave_kernel(AdamRowsJobs jobs, 
       seg_acc_from<IdT, VEC, 8>(acc, sid, spos, n, i, base + S, id[e], (const float*)gp, ldg, lo ? nullptr : (const float*)sc, jb.part ? jb.part + col : nullptr, dim);
     // deferred: the g = 0 steps (seen, t-1] of the moments (adam_decay's first two products; theta came replayed)
     V mm = m[e], vv = v[e], tt = th[e];
-    for (uint32_t j = seen[e] + 1; j < t; ++j) { mm = vmul(mm, h.b1); vv = vmul(vv, h.b2); }
+    if (last && seen[e] + 1 < t) {
+      if (fast) fast_moments(mm, vv, t - 1 - seen[e], ss);
+      else for (uint32_t j = seen[e] + 1; j < t; ++j) { mm = vmul(mm, h.b1); vv = vmul(vv, h.b2); }
+    }
     adam_update(tt, mm, vv, acc, h);
     const int64_t off = (int64_t)id[e] * dim + col;
     gvstore<VEC>(tab + off, tt);
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(256) void adam_flush_kernel(float* __restrict__ tab
     V m = vload<VEC>(M + e * VEC), v = vload<VEC>(Vv + e * VEC);
     if (all_zero(m) && all_zero(v)) continue;
     V th = vload<VEC>(table + e * VEC);
-    adam_replay(th, m, v, seen, t, ring, h);
+    adam_catch_up<true>(th, m, v, seen, t, ring, ss, h);
     vstore<VEC>(table + e * VEC, th);
     vstore<VEC>(M + e * VEC, m);
     vstore<VEC>(Vv + e * VEC, v);
@@ -627,6 +632,7 @@ __device__ __forceinline__ void step_state_advance_block(const StepAdvance& a) {
     st->pow_b2 = p2;
     st->alpha_t = al;
     st->alpha_hist[t & (BR_ALPHA_RING - 1)] = al;
+    if ((t & (BR_ALPHA_RING - 1)) < (uint32_t)BR_RING_MIRROR) st->alpha_hist[BR_ALPHA_RING + (t & (BR_ALPHA_RING - 1))] = al;   // the mirror behind the ring's end
   }
 }
 __global__ __launch_bounds__(256) void step_state_advance_kernel(StepAdvance a) { step_state_advance_block(a); }
@@ -1263,6 +1269,40 @@ extern "C" int brStepStateAdvance(void* step_state, double lr, double beta1, dou
   a.st = (StepStateDev*)step_state; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.zero = zero; a.n_zero = n_zero;
   step_state_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a);
   BR_CHECK_LAUNCH("brStepStateAdvance");
+  return BR_OK;
+}
+
+extern "C" int brStepStateInit(void* step_state, double beta1, double beta2, double eps, int replay_mode, brStream stream) {
+  BR_CHECK_ARG(step_state != nullptr, "brStepStateInit: null state");
+  BR_CHECK_ARG(replay_mode == BR_REPLAY_EXACT || replay_mode == BR_REPLAY_FAST, "brStepStateInit: bad replay_mode %d", replay_mode);
+  BR_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 > 0.0 && beta2 < 1.0 && eps >= 0.0, "brStepStateInit: beta1 in [0,1), beta2 in (0,1), eps >= 0");
+  constexpr size_t off = offsetof(StepStateDev, fast);
+  static_assert(offsetof(StepStateDev, pow2) + sizeof(float) * BR_ALPHA_RING == sizeof(StepStateDev), "StepStateDev tail layout");
+  std::vector<StepStateDev> img(1);                            // a host image of the state; only its tail [fast, end) is copied
+  StepStateDev* h = img.data();
+  // the kernels multiply by the fp32 roundings of beta1 / beta2 (AdamHp): the closed forms below are powers of THOSE numbers - over a lag of
+  // 1000 steps pow(0.999, k) and pow((float)0.999, k) are 1.3e-5 apart
+  beta1 = (double)(float)beta1; beta2 = (double)(float)beta2;
+  const double c = sqrt(beta2), rho = beta1 / c;
+  h->fast = replay_mode == BR_REPLAY_FAST ? 1u : 0u;
+  // theta is replayed over the first `trunc` steps of a lag: the steps behind it move theta by at most 7 rho^trunc / (1 - rho) of the first
+  // step's update (alpha_j varies by less than 7x over any lag, m decays by beta1 and 1 / d grows by at most 1 / c per step); below 2^-23
+  // of it they are under one ulp.  A multiple of 8 (the replay takes eight alphas per scalar load); rho >= 1: never truncated.
+  uint32_t trunc = BR_ALPHA_RING;
+  if (rho < 1.0) {
+    const double need = log(ldexp(1.0, -23) * (1.0 - rho) / 7.0) / log(rho);
+    if (need < (double)BR_ALPHA_RING) trunc = (uint32_t)((((int64_t)ceil(need < 1.0 ? 1.0 : need)) + 7) / 8 * 8);
+  }
+  h->trunc = trunc;
+  h->sqrt_b2 = (float)c;
+  h->eps_c = (float)(eps * (1.0 - c));
+  for (int k = 0; k < BR_ALPHA_RING; ++k) { h->pow1[k] = (float)pow(beta1, (double)k); h->pow2[k] = (float)pow(beta2, (double)k); }
+  const hipError_t ce = hipMemcpyAsync((char*)step_state + off, (const char*)h + off, sizeof(StepStateDev) - off, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (ce != hipSuccess) {
+    set_error("brStepStateInit: copy failed: %s", hipGetErrorString(ce));
+    return BR_ERR_HIP;
+  }
+  (void)hipStreamSynchronize((hipStream_t)stream);
   return BR_OK;
 }
 

@@ -42,6 +42,9 @@ class NeuMFConfig:
     dense_impl: str = "deferred"        # how adam_dense reaches the untouched rows: "deferred" = per-row catch-up
                                         # replay (same values, no per-step table sweep; include/binrec.h
                                         # "Deferred dense Adam"), "sweep" = one pass over the table per step
+    replay: str | None = None           # deferred tables: "fast" (default; BR_REPLAY env overrides the default) = the cheaper form of the
+                                        # g = 0 recurrence (include/binrec.h BR_REPLAY_FAST: ~1e-6 of a row's movement off the sweep),
+                                        # "exact" = the sweep's own fp32 operations (tables bit-equal to dense_impl="sweep")
     seed: int = 0x5EED
     sync_bn: bool = True                # data-parallel: batch statistics over the GLOBAL batch
 
@@ -49,6 +52,9 @@ class NeuMFConfig:
         assert self.variant in ("A", "B")
         assert self.optimizer in ("adam_dense", "adam_lazy")
         assert self.dense_impl in ("deferred", "sweep")
+        if self.replay is None:
+            self.replay = os.environ.get("BR_REPLAY", "fast")
+        assert self.replay in ("fast", "exact")
         if self.variant == "A":
             self.hidden = tuple(self.hidden) if self.hidden else (100, 50, 10)
             self.act, self.item_first, self.mf_first, self.loss = "sigmoid", 1, 1, "bce"
@@ -326,7 +332,7 @@ class NeuMFEngine:
     def _alloc_step_state(self, st):
         """device step state (include/binrec.h brStepStateBytes): {step, alpha_t, alpha ring}."""
         if getattr(self, "step_state", None) is None:
-            self.step_state = torch.zeros(_lib.load().brStepStateBytes() // 4, dtype=torch.int32, device=self.device)
+            self.step_state = ops.new_step_state(self.device, self.cfg.beta1, self.cfg.beta2, self.cfg.adam_eps, self.cfg.replay)
         st.lr, st.step_state = self.cfg.lr, self.step_state.data_ptr()
         self._sync_step_state()
 
@@ -428,13 +434,13 @@ class NeuMFEngine:
         self._alloc_step_state(st)
         # every kernel of the step runs once outside a capture first (code objects load on first launch);
         # the model state is put back afterwards
-        keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state_dict().items()}
+        keep = self._snapshot_for_dry_run()
         keep_sums = self.msums.clone()
         self._sync_step_state()
         self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, 0, B)
         self._run(PH["ALL"])
         torch.cuda.synchronize(dev)
-        self.load_state_dict(keep)
+        self._restore_after_dry_run(keep)
         self.msums.copy_(keep_sums)
         del keep
         self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, 0, B)
@@ -469,6 +475,33 @@ class NeuMFEngine:
 
     def disable_graph(self):
         self._graph = None
+
+    def _snapshot_for_dry_run(self):
+        """what enable_graph's dry-run step can change.  Per-step sweep: every table row moves, so the whole (flushed) state.  Deferred /
+        lazy tables: only the rows the static input buffers name move - those rows with their moments and `last`, the dense state and
+        the host counters are kept, NOT flushed: a capture in the middle of a run leaves every other row's lag as it is (state_dict()
+        would flush the tables: 42 GB cloned and every lag reset at config 5's shard size)."""
+        if self.cfg.optimizer == "adam_dense" and not self.deferred:
+            return {"full": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state_dict().items()}}
+        snap = {"rows": {}, "host": (self.t, self._flush_t, self._stale)}
+        for k, ids in (("user", self.in_users), ("item", self.in_items)):
+            idx = torch.unique(ids).long().clamp_(0, self.fused[k].shape[0] - 1)
+            snap["rows"][k] = (idx, self.fused[k][idx], self.fused_m[k][idx], self.fused_v[k][idx], self.last[k][idx] if self.deferred else None)
+        snap["dense"] = [t.clone() for t in (self.theta.buf, self.adam_m.buf, self.adam_v.buf, self.moving_buf)]
+        return snap
+
+    def _restore_after_dry_run(self, snap):
+        if "full" in snap:
+            self.load_state_dict(snap["full"])
+            return
+        for k, (idx, th, m, v, last) in snap["rows"].items():
+            self.fused[k][idx] = th; self.fused_m[k][idx] = m; self.fused_v[k][idx] = v
+            if last is not None:
+                self.last[k][idx] = last
+        for dst, src in zip((self.theta.buf, self.adam_m.buf, self.adam_v.buf, self.moving_buf), snap["dense"]):
+            dst.copy_(src)
+        self.t, self._flush_t, self._stale = snap["host"]
+        self._sync_step_state()
 
     def _sync_step_state(self):
         """device step state := (self.t, alpha_t, beta^t) (after enable_graph / load_state_dict)."""

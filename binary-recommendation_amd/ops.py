@@ -321,6 +321,17 @@ def adagrad_flat(theta, acc, g, lr, eps=1e-7):
                                     theta.numel(), float(lr), float(eps), _stream()), "brAdagradFlat")
 
 
+REPLAY = {"exact": 0, "fast": 1}     # BR_REPLAY_EXACT / BR_REPLAY_FAST
+
+
+def new_step_state(device, beta1=0.9, beta2=0.999, eps=1e-7, replay="fast") -> torch.Tensor:
+    """The device step state of a deferred-Adam engine (brStepStateBytes): zeroed, with the replay form written into it
+    (brStepStateInit: "fast" = the cheaper recurrence, "exact" = the sweep's own operations, bit-equal tables)."""
+    st = torch.zeros(int(_lib.load().brStepStateBytes()) // 4, dtype=torch.int32, device=device)
+    check(_lib.load().brStepStateInit(st.data_ptr(), float(beta1), float(beta2), float(eps), REPLAY[replay], _stream()), "brStepStateInit")
+    return st
+
+
 def adam_alpha(lr: float, t: int, beta1=0.9, beta2=0.999) -> float:
     """[TF-sem] alpha_t = lr*sqrt(1-b2^t)/(1-b1^t) in double on the host."""
     return lr * (1.0 - beta2 ** t) ** 0.5 / (1.0 - beta1 ** t)

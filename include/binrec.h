@@ -478,12 +478,24 @@ typedef struct brNeumfStep {
                          per step inside a hipGraph - but that launch then takes 101 instead of 94 us).  The host sets keep_ready on
                          the next call if that call's step / row0 are the ones prefetched */
 } brNeumfStep;
-/* step_state: device {uint32 step; float alpha_t; float alpha_hist[BR_ALPHA_RING]}, brStepStateBytes() bytes,
- * zero-initialised (or step / alpha_t set by the host after a reload).
+/* step_state: device {uint32 step; float alpha_t; double b1^step, b2^step; float alpha_hist[BR_ALPHA_RING + BR_RING_MIRROR]; replay form},
+ * brStepStateBytes() bytes, zero-initialised (or step / alpha_t set by the host after a reload).
  * Advance: step += 1, alpha_t = alpha_hist[step % BR_ALPHA_RING] = lr*sqrt(1-b2^step)/(1-b1^step) (b^step kept as a
  * running double product), and `zero[0..n_zero)` (the step's double scratch) cleared in the same launch. */
-enum { BR_ALPHA_RING = 1024 };
+enum { BR_ALPHA_RING = 1024, BR_RING_MIRROR = 8 };
 int64_t brStepStateBytes(void);
+/* How the deferred kernels replay a row's pending g = 0 steps (see "Deferred dense Adam" below).  Written into the step state once,
+ * before the first step (host -> device copy, synchronises the stream); a zero-initialised state replays exactly.
+ *   BR_REPLAY_EXACT: step by step with the sweep's own fp32 operations (m *= b1; v *= b2; theta -= alpha_j m / (sqrt(v) + eps)):
+ *                    tables bit-equal to brAdamDenseSweep.
+ *   BR_REPLAY_FAST : the same recurrence in a cheaper form - d_j = sqrt(v_j) + eps advanced as d_j = sqrt(b2) d_{j-1} + eps (1 - sqrt(b2))
+ *                    (one v_sqrt per row visit, none per step), 1 / d_j by one Newton step from 1 / d_{j-1} (relative error
+ *                    (1 - sqrt(b2))^2 = 2.5e-7: what the hardware v_rcp_f32 of the exact form is allowed), theta replayed over at most
+ *                    `trunc` steps of a lag (the steps behind that move it by less than one ulp of the first: m has decayed by b1^trunc),
+ *                    and the moments of a lag of L steps as ONE product each: m b1^L, v b2^L.  Agrees with the exact form to ~1e-6 of
+ *                    a row's movement (tests/test_gpu_neumf.py); no longer bit-equal to the sweep. */
+enum { BR_REPLAY_EXACT = 0, BR_REPLAY_FAST = 1 };
+int brStepStateInit(void* step_state, double beta1, double beta2, double eps, int replay_mode, brStream stream);
 int brStepStateAdvance(void* step_state, double lr, double beta1, double beta2, double* zero, int64_t n_zero, brStream stream);
 /* host -> device: step, alpha_t and the running beta powers for that step (after a reload); synchronises the stream */
 int brStepStateSet(void* step_state, uint32_t step, double lr, double beta1, double beta2, brStream stream);

@@ -67,18 +67,23 @@ def _compact(id_lists, N, rng, n_extra=2000):
     return keep, [np.searchsorted(keep, x) for x in id_lists]
 
 
-NEUMF_CASES = [("uniform", torch.int32, 65536, False, 64, 1_000_000), ("zipf", torch.int32, 65536, False, 64, 1_000_000), ("uniform", torch.int64, 65536, False, 64, 1_000_000),
-               ("uniform", torch.int32, 40000, False, 64, 1_000_000), ("uniform", torch.int32, 65536, True, 64, 1_000_000), ("uniform", torch.int64, 40000, False, 128, 1_000_000),
+K1, M1 = 100_000, 1_000_000
+NEUMF_CASES = [("uniform", torch.int32, 65536, False, 64, M1, K1), ("zipf", torch.int32, 65536, False, 64, M1, K1), ("uniform", torch.int64, 65536, False, 64, M1, K1),
+               ("uniform", torch.int32, 40000, False, 64, M1, K1), ("uniform", torch.int32, 65536, True, 64, M1, K1), ("uniform", torch.int64, 40000, False, 128, M1, K1),
                # a user table of 17 M x 128 floats = 2.18 G elements (8.7 GB, 26 GB with the Adam slots): rows past element 2^31 are
-               # looked up, replayed and updated (config 5's per-GPU shard is 12.5 M x 256 floats = 3.2 G elements)
-               ("uniform", torch.int32, 16384, False, 64, 17_000_000)]
+               # looked up, replayed and updated
+               ("uniform", torch.int32, 16384, False, 64, 17_000_000, K1),
+               # BASELINE config 5's per-GPU shard as it stands on one of the 8 GPUs: 12.5 M x 1.25 M rows of 256 floats (3.2 G + 0.32 G
+               # elements, 42 GB with the Adam slots), int64 ids, batch 65 536: the VEC = 4 wave kernels (lookup, Adam rows, flush) at
+               # element offsets >= 2^31 and byte offsets >= 2^33
+               ("uniform", torch.int64, 65536, False, 128, 12_500_000, 1_250_000)]
 
 
-@pytest.mark.parametrize("kind,idt,B,graph,dim,U", NEUMF_CASES)
-def test_neumf_steps_at_bench_size(dev, kind, idt, B, graph, dim, U):
+@pytest.mark.parametrize("kind,idt,B,graph,dim,U,I", NEUMF_CASES)
+def test_neumf_steps_at_bench_size(dev, kind, idt, B, graph, dim, U, I):
     neumf = _m("neumf")
-    case = f"neumf_{kind}_{'i64' if idt == torch.int64 else 'i32'}_b{B}_d{dim}{'_graph' if graph else ''}" + (f"_u{U}" if U != 1_000_000 else "")
-    I, D, steps = 100_000, dim, 3
+    case = f"neumf_{kind}_{'i64' if idt == torch.int64 else 'i32'}_b{B}_d{dim}{'_graph' if graph else ''}" + (f"_u{U}" if U != M1 else "") + (f"_i{I}" if I != K1 else "")
+    D, steps = dim, 3
     cfg = neumf.NeuMFConfig(variant="A", dim=D, optimizer="adam_dense", dense_impl="deferred", seed=0x1234ABCD5)
     eng = neumf.NeuMFEngine(cfg, U, I, dev, B, id_dtype=idt, init_seed=1)
     rng = np.random.default_rng(17)
@@ -93,6 +98,7 @@ def test_neumf_steps_at_bench_size(dev, kind, idt, B, graph, dim, U):
     if U * 2 * D > (1 << 31):                  # the table's last rows (element offsets >= 2^31) in every step
         for t in range(steps):
             us[t][-256:] = U - 1 - rng.integers(0, 100_000, 256)
+            us[t][-512:-256] = (1 << 31) // (2 * D) + rng.integers(-64, 64, 256)      # rows on either side of element 2^31
         assert (min(int(x[-256:].min()) for x in us) * 2 * D) >= (1 << 31)
     ku, cu = _compact(us, U, rng)
     ki, ci = _compact(its, I, rng)

@@ -91,3 +91,41 @@ def test_two_tower_model_surface(dev):
     topk = tkm.topKRatings(10, model, users, items, "two tower")
     mt = tkm.topKMetrics(topk, pairs, users, items)                           # twoTower.py:241
     assert 0.0 < mt["hitRate"] <= 1.0 and mt["tp"] + mt["fp"] == 400
+
+
+def test_two_tower_step_chain_under_debug_sync(dev):
+    """Regression harness for round 2's one unexplained abort (gpurun_out/t_r2_09.log: SIGABRT at the first host sync after a TwoTower
+    train_step of test_two_tower_model_surface; the runtime's message was lost to pytest's fd-level capture, see pytest.ini and DESIGN.md
+    "The round-2 abort").  The same launch chain at the same shapes (batches of 100 of max_batch 128, embedDim 16, semb 8, Adagrad, then
+    rdZero) runs in a child process under BR_DEBUG_SYNC=1: every C-ABI entry point is named on stderr and the device synchronised behind
+    it, so a fault in ANY launch of the chain ends the child right behind the line that names it.  Asserted: the child finishes, every
+    launch of the chain was reached, the loss falls."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from importlib import import_module
+models = import_module("binary-recommendation_amd.models")
+users = [f"u{k}" for k in range(40)]; items = [f"m{k}" for k in range(25)]
+rng = np.random.default_rng(5)
+pairs = [(users[k], items[(3 * k + rng.integers(0, 2)) % 25]) for k in rng.integers(0, 40, 600)]
+for rd in (False, True):
+    model = models.TwoTowerModel(16, len(items), len(users), "CUSTOMER_ID", "MATERIAL", users, items, semb=8, max_batch=128,
+                                 learningRate=0.1, optimiser="Adagrad", rdZero=rd, resKey="RATING_TYPE")
+    batches = [{"CUSTOMER_ID": [p[0] for p in pairs[s:s + 100]], "MATERIAL": [p[1] for p in pairs[s:s + 100]],
+                "RATING_TYPE": np.ones(len(pairs[s:s + 100]), np.float32)} for s in range(0, 600, 100)]
+    h = model.fit(batches, epochs=5)
+    assert h.history["loss"][-1] < h.history["loss"][0], h.history["loss"]
+print("chain ok")
+"""
+    env = dict(os.environ, BR_DEBUG_SYNC="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    tail = r.stderr[-1500:]
+    assert r.returncode == 0 and "chain ok" in r.stdout, f"child rc={r.returncode}; last launches:\n{tail}"
+    for name in ("brGatherRows", "brDenseForward", "brInBatchSoftmaxLseGradQ", "brInBatchSoftmaxGrad", "brDenseBackward", "brReduceSlabs", "brRowIndexBuild",
+                 "brAdagradRowsSorted", "brAdagradFlat", "brRowDot", "brBceLogits", "brRowDotBackward"):
+        assert f"[binrec] {name}" in r.stderr, name

@@ -24,7 +24,7 @@ def _close(got, ref, name, rtol=RTOL, atol_frac=5e-6):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol_frac * scale, err_msg=name)
 
 
-def _setup(variant, dim, B, dev, U=97, I=53, seed=3, optimizer="adam_lazy", hidden=None, dense_impl="deferred"):
+def _setup(variant, dim, B, dev, U=97, I=53, seed=3, optimizer="adam_lazy", hidden=None, dense_impl="deferred", replay=None):
     ops, neumf = _mods()
     spec = O.NeuMFSpec(variant, dim=dim, hidden=hidden)
     p = O.neumf_init(spec, U, I, seed=seed, dt=np.float32)
@@ -37,7 +37,7 @@ def _setup(variant, dim, B, dev, U=97, I=53, seed=3, optimizer="adam_lazy", hidd
         p[k] = rng.normal(0.4, 0.1, p[k].shape).astype(np.float32)
     for k in ("mv1", "mv2"):
         p[k] = rng.uniform(0.05, 0.3, p[k].shape).astype(np.float32)
-    cfg = neumf.NeuMFConfig(variant=variant, dim=dim, hidden=hidden, optimizer=optimizer, seed=0xABCDEF12345, dense_impl=dense_impl)
+    cfg = neumf.NeuMFConfig(variant=variant, dim=dim, hidden=hidden, optimizer=optimizer, seed=0xABCDEF12345, dense_impl=dense_impl, replay=replay)
     eng = neumf.NeuMFEngine(cfg, U, I, dev, max_batch=B)
     eng.load_numpy_params(p)
     u = rng.integers(0, U, B); i = rng.integers(0, I, B)
@@ -264,7 +264,11 @@ def _two_engines(dev, B, U, I, dim=16):
     """the same model twice: dense Adam by per-step sweep and by deferred replay, both reading alpha_t from
     the device step state (so the two use the same fp32 alpha)."""
     _, sw, spec, cfg, *_ = _setup("A", dim, B, dev, U=U, I=I, optimizer="adam_dense", dense_impl="sweep")
-    _, de, *_ = _setup("A", dim, B, dev, U=U, I=I, optimizer="adam_dense", dense_impl="deferred")
+    # replay="exact": the form of the deferred replay that issues the sweep's own fp32 operations.  The default ("fast", include/binrec.h
+    # BR_REPLAY_FAST) agrees with it to ~1e-6 of a row's movement PER CATCH-UP (tests/test_gpu_sparse_optim.py::test_fast_replay_*), which
+    # two whole training runs cannot show: Adam's m / (sqrt(v) + eps) with eps = 1e-7 amplifies a one-ulp difference of a gradient by
+    # alpha (1 - b1) / eps = 5000 per step, so two runs either agree bit for bit or drift apart within a dozen steps (tools/diag/replay_debug.py)
+    _, de, *_ = _setup("A", dim, B, dev, U=U, I=I, optimizer="adam_dense", dense_impl="deferred", replay="exact")
     sw._alloc_step_state(sw.step_struct)
     return sw, de
 

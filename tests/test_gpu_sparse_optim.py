@@ -188,8 +188,8 @@ def test_row_index_pair_matches_two_builds(dev):
 
 
 @pytest.mark.parametrize("dim,split", [(64, 0), (128, 64), (256, 0), (48, 0)])
-@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
-def test_deferred_adam_with_replayed_rows_is_bit_equal(dev, dim, split, idt):
+@pytest.mark.parametrize("idt,replay", [(torch.int32, "exact"), (torch.int64, "exact"), (torch.int32, "fast")])
+def test_deferred_adam_with_replayed_rows_is_bit_equal(dev, dim, split, idt, replay):
     """brAdamRowsSortedDeferredReplayed (theta taken as the step's deferred gather replayed it, moments-only replay; one wave per
     row on 64 / 128 / 256-float rows, strips of 4 sorted positions) against brAdamRowsSortedDeferred replaying theta itself in the
     row-group kernel: tables, moments and last[] bit-equal over steps with lags, duplicate runs that cross strips and 64-blocks
@@ -203,7 +203,9 @@ def test_deferred_adam_with_replayed_rows_is_bit_equal(dev, dim, split, idt):
     td = lambda a: torch.from_numpy(a.copy()).to(dev)
     th0 = rng.uniform(-0.05, 0.05, size=(rows, dim)).astype(np.float32)
     tabs = [[td(th0), torch.zeros(rows, dim, device=dev), torch.zeros(rows, dim, device=dev), torch.zeros(rows, dtype=torch.int32, device=dev)] for _ in range(2)]
-    ss = torch.zeros(int(lib.brStepStateBytes()), dtype=torch.uint8, device=dev)
+    ss = torch.zeros(int(lib.brStepStateBytes()), dtype=torch.uint8, device=dev)      # (all zero = the exact replay)
+    if replay == "fast":      # both kernels then run the fast form of the replay (adam_math.h): the same fp32 operations per element again
+        ss = ops.new_step_state(dev, b1, b2, 1e-7, "fast")
     _lib.check(lib.brStepStateSet(ss.data_ptr(), 0, lr, b1, b2, ops._stream()), "brStepStateSet")
     idx = ops.RowIndex(n, idt, dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -230,3 +232,157 @@ def test_deferred_adam_with_replayed_rows_is_bit_equal(dev, dim, split, idt):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{name} differs at step {t}"
     assert int(err.item()) == 1
     assert int((tabs[0][3] > 0).sum().item()) > 100 and float(tabs[0][1].abs().max().item()) > 0
+
+
+def _replay_f64(th, m, v, last, upto, ring, b1f, b2f, eps):
+    """Keras' g = 0 recurrence over steps (last[row], upto] in float64, with the fp32 alphas of the device ring and the fp32 roundings of
+    beta1 / beta2 the kernels multiply by: m *= b1 ; v *= b2 ; theta -= alpha_j m / (sqrt(v) + eps)   [TF-sem], SURVEY.md 8a-O1."""
+    th, m, v = th.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    lag = (upto - last).astype(np.int64)
+    for k in range(1, int(lag.max()) + 1):
+        live = (lag >= k)[:, None]
+        a = ring[(last + k) & (len(ring) - 1)].astype(np.float64)[:, None]
+        m = np.where(live, m * b1f, m)
+        v = np.where(live, v * b2f, v)
+        th = np.where(live, th - a * m / (np.sqrt(v) + eps), th)
+    return th, m, v
+
+
+@pytest.mark.parametrize("dim", [64, 128, 256, 48])
+def test_fast_replay_against_exact_replay_and_f64(dev, dim):
+    """The fast form of the deferred replay (include/binrec.h BR_REPLAY_FAST: d_j = sqrt(v_j) + eps by recurrence, 1 / d_j by a Newton
+    step, theta over at most `trunc` steps of a lag, moments by one product with b^lag) against the exact form (the dense sweep's own
+    fp32 operations) and against the recurrence in float64, PER CATCH-UP from identical stored rows - the only place the two forms can
+    be compared (two training runs drift apart through Adam's eps: tests/test_gpu_neumf.py::_two_engines).  Lags 0 .. 1015 at step
+    1500 (the alpha ring has wrapped; trunc = 200 is crossed), sqrt(v) from far below to far above eps, rows nobody has touched
+    (m = v = 0), every kernel that replays: the lookup (brGatherRowsDeferred: one wave per row at 64 / 128 / 256 floats, row groups at
+    48) and the flush (brAdamFlush: theta, m, v).
+    Bounds: |fast - exact| <= 1e-6 of the row's movement in that catch-up + (2 + sqrt(min(lag, trunc))) ulp of theta (the two forms round
+    theta in min(lag, trunc) fmas each: two independent walks);
+    moments 6e-6 relative to the exact form (one product against up to 1015 rounded ones) and 3e-7 to float64; and the fast form is as close to float64 as the exact one."""
+    from importlib import import_module
+    ops = _ops()
+    _lib = import_module("binary-recommendation_amd._lib")
+    lib = _lib.load()
+    rng = np.random.default_rng(100 + dim)
+    rows, lr, b1, b2, eps, T = 4096, 0.005, 0.9, 0.999, 1e-7, 1500
+    lags = np.array([0, 1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 63, 64, 65, 100, 191, 199, 200, 201, 208, 500, 1000, 1015])
+    lag = lags[rng.integers(0, len(lags), rows)]
+    th0 = rng.uniform(-0.05, 0.05, (rows, dim)).astype(np.float32)
+    g = (10.0 ** rng.uniform(-9, -2, (rows, dim)) * rng.choice([-1.0, 1.0], (rows, dim)))
+    decay = rng.uniform(0.05, 1.0, (rows, 1))
+    m0 = ((1 - b1) * g * decay).astype(np.float32)
+    v0 = ((1 - b2) * g * g * decay).astype(np.float32)
+    m0[::17] = 0.0; v0[::17] = 0.0                          # rows nobody has touched
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    states = {}
+    for mode in ("exact", "fast"):
+        ss = ops.new_step_state(dev, b1, b2, eps, mode)
+        for _ in range(T):
+            _lib.check(lib.brStepStateAdvance(ss.data_ptr(), lr, b1, b2, None, 0, ops._stream()), "brStepStateAdvance")
+        states[mode] = ss
+    ring = states["exact"].view(torch.float32)[6:6 + 1024].cpu().numpy()             # alpha_hist behind {step, alpha_t, 2 doubles}
+    assert np.array_equal(ring, states["fast"].view(torch.float32)[6:6 + 1024].cpu().numpy()) and ring.min() > 0
+    assert np.array_equal(states["fast"].view(torch.float32)[6 + 1024:6 + 1032].cpu().numpy(), ring[:8])      # the mirror behind the ring
+    trunc = int(states["fast"][6 + 1032 + 1].item())
+    assert trunc == 200
+    b1f, b2f = float(np.float32(b1)), float(np.float32(b2))
+    ids = torch.arange(rows, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ulp = lambda x: 6e-8 * np.abs(x)
+
+    # ---- lookup: rows as of step T - 1 (nothing written) ----
+    last_g = (T - 1 - lag).astype(np.int32)
+    out = {}
+    for mode in ("exact", "fast"):
+        out[mode] = ops.gather_rows_deferred(td(th0), td(m0), td(v0), td(last_g), ids, states[mode], b1, b2, eps, err_flag=err).cpu().numpy().astype(np.float64)
+    ref, _, _ = _replay_f64(th0, m0, v0, last_g.astype(np.int64), T - 1, ring, b1f, b2f, eps)
+    move = np.abs(ref - th0)
+    walk = (2.0 + np.sqrt(np.minimum(lag, trunc)))[:, None]      # two independent rounding walks of min(lag, trunc) fmas on theta, in ulps
+    bound = 1e-6 * move + walk * ulp(np.maximum(np.abs(ref), np.abs(th0))) + 1e-12
+    r_fx = np.abs(out["fast"] - out["exact"]) / bound
+    assert r_fx.max() <= 1.0, f"lookup: |fast - exact| reaches {r_fx.max():.2f} of the bound (lag {lag[np.unravel_index(r_fx.argmax(), r_fx.shape)[0]]})"
+    e_exact, e_fast = np.abs(out["exact"] - ref), np.abs(out["fast"] - ref)
+    assert (e_fast <= 2 * e_exact + bound).all(), "lookup: the fast form is further from the float64 recurrence than the exact one"
+    assert move.max() > 1e-3 and (lag > trunc).any()      # (both fp32 forms sit a rounding walk of up to 1015 fmas away from float64)
+    assert np.array_equal(out["fast"][::17], th0[::17].astype(np.float64))           # untouched rows: identity, exactly
+
+    # ---- flush: theta, m, v of every row brought to step T ----
+    last_f = (T - lag).astype(np.int32)
+    fl = {}
+    for mode in ("exact", "fast"):
+        t_, m_, v_, l_ = td(th0), td(m0), td(v0), td(last_f)
+        _lib.check(lib.brAdamFlush(t_.data_ptr(), m_.data_ptr(), v_.data_ptr(), l_.data_ptr(), rows, dim, states[mode].data_ptr(), b1, b2, eps, ops._stream()), "brAdamFlush")
+        fl[mode] = [x.cpu().numpy().astype(np.float64) for x in (t_, m_, v_)] + [l_.cpu().numpy()]
+        assert (fl[mode][3] == T).all()
+    rt, rm, rv = _replay_f64(th0, m0, v0, last_f.astype(np.int64), T, ring, b1f, b2f, eps)
+    move = np.abs(rt - th0)
+    bound = 1e-6 * move + walk * ulp(np.maximum(np.abs(rt), np.abs(th0))) + 1e-12
+    assert (np.abs(fl["fast"][0] - fl["exact"][0]) / bound).max() <= 1.0
+    assert (np.abs(fl["fast"][0] - rt) <= 2 * np.abs(fl["exact"][0] - rt) + bound).all()
+    for k, name, r in ((1, "m", rm), (2, "v", rv)):
+        # exact: up to 1015 rounded products (a rounding walk: sqrt(1015) x 3e-8, ~4.5 sigma over 500 K elements); fast: ONE product with the
+        # fp32 rounding of b^lag - two roundings away from float64
+        np.testing.assert_allclose(fl["fast"][k], fl["exact"][k], rtol=6e-6, atol=1e-37, err_msg=name + " fast vs exact")
+        np.testing.assert_allclose(fl["fast"][k], r, rtol=3e-7, atol=1e-37, err_msg=name + " fast vs float64")
+    assert int(err.item()) == 0
+
+
+@pytest.mark.parametrize("dim,replay", [(128, "fast"), (128, "exact"), (48, "fast")])
+def test_deferred_tables_track_the_sweep_under_given_gradients(dev, dim, replay):
+    """Keras' non-lazy sparse Adam over 1100 steps with GIVEN per-step row gradients (independent of the tables, so no feedback through a
+    network and no chaotic growth of ulp differences): a swept table (brAdamRowsSorted + brAdamDenseSweep: every row every step) against a
+    deferred one (brGatherRowsDeferred -> brAdamRowsSortedDeferred(replayed) per step, brAdamFlush when the alpha ring is about to wrap and
+    at the end).  Exact replay: bit-equal.  Fast replay (the default of the engines): theta within 2e-6 of the row's PATH LENGTH (each
+    catch-up contributes <= 1e-6 of its movement, test above) + 16 ulp, moments 1e-5 relative (closed-form decay feeds the next update
+    of a touched row: errors add, they do not grow)."""
+    from importlib import import_module
+    ops = _ops()
+    _lib = import_module("binary-recommendation_amd._lib")
+    lib = _lib.load()
+    rng = np.random.default_rng(7 + dim)
+    rows, n, lr, b1, b2, eps, steps = 3000, 96, 0.005, 0.9, 0.999, 1e-7, 1100
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    th0 = rng.uniform(-0.05, 0.05, (rows, dim)).astype(np.float32)
+    sw = [td(th0), torch.zeros(rows, dim, device=dev), torch.zeros(rows, dim, device=dev)]
+    mark = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    de = [td(th0), torch.zeros(rows, dim, device=dev), torch.zeros(rows, dim, device=dev), torch.zeros(rows, dtype=torch.int32, device=dev)]
+    ss = ops.new_step_state(dev, b1, b2, eps, replay)
+    idx = ops.RowIndex(n, torch.int32, dev)
+    path = torch.zeros(rows, dim, device=dev, dtype=torch.float64)
+    prev = sw[0].clone()
+    ring_steps = 1024 - 8
+    flushed_at = 0
+    def flush(t):
+        _lib.check(lib.brAdamFlush(de[0].data_ptr(), de[1].data_ptr(), de[2].data_ptr(), de[3].data_ptr(), rows, dim, ss.data_ptr(), b1, b2, eps, ops._stream()), "brAdamFlush")
+    for t in range(1, steps + 1):
+        if t - flushed_at >= ring_steps:
+            flush(t - 1); flushed_at = t - 1
+        _lib.check(lib.brStepStateAdvance(ss.data_ptr(), lr, b1, b2, None, 0, ops._stream()), "brStepStateAdvance")
+        ids = rng.integers(0, rows, size=n)
+        ids[:8] = 7                                     # a row touched every step
+        ids[8:12] = rng.integers(0, 30, 4)              # rows touched every few steps
+        ids = np.where(ids >= rows - 200, 0, ids) if t % 2 else ids      # the last 200 rows only every other step at most
+        idd = td(ids.astype(np.int32))
+        g = td((10.0 ** rng.uniform(-7, -3, (n, dim)) * rng.choice([-1.0, 1.0], (n, dim))).astype(np.float32))
+        idx.build(idd, rows)
+        alpha = float(ss.view(torch.float32)[1].item())      # the swept table steps with the device's fp32 alpha_t, as the deferred one does
+        ops.adam_rows_sorted(sw[0], sw[1], sw[2], idx, g, dim, alpha, b1, b2, eps, mark=mark)
+        ops.adam_dense_sweep(sw[0], sw[1], sw[2], alpha, b1, b2, eps, mark=mark)
+        rep = ops.gather_rows_deferred(de[0], de[1], de[2], de[3], idd, ss, b1, b2, eps)
+        ops.adam_rows_sorted_deferred(*de, idx, g, dim, ss, b1, b2, eps, replayed=rep)
+        path += (sw[0] - prev).abs().double()
+        prev.copy_(sw[0])
+    flush(steps)
+    torch.cuda.synchronize()
+    a, b = sw[0].double(), de[0].double()
+    if replay == "exact":
+        assert torch.equal(sw[0], de[0]) and torch.equal(sw[1], de[1]) and torch.equal(sw[2], de[2])
+        return
+    bound = 2e-6 * path + 16 * 6e-8 * torch.maximum(a.abs(), td(th0).double().abs()) + 1e-12
+    ratio = ((a - b).abs() / bound).max().item()
+    assert ratio <= 1.0, f"theta: |sweep - deferred(fast)| reaches {ratio:.2f} of the bound"
+    # (m = b1 m + (1 - b1) g cancels where the new gradient opposes the old moment: absolute floor at 1e-7 of the largest moment)
+    np.testing.assert_allclose(de[1].cpu().numpy(), sw[1].cpu().numpy(), rtol=1e-5, atol=1e-7 * float(sw[1].abs().max().item()))
+    np.testing.assert_allclose(de[2].cpu().numpy(), sw[2].cpu().numpy(), rtol=1e-5, atol=1e-37)
+    assert float(path.max().item()) > 0.05 and int((de[3] == steps).all().item()) == 1

@@ -186,7 +186,7 @@ def test_bpr_deferred_adam_is_bit_equal_to_the_sweep(dev):
     bpr = _m("bpr")
     g = torch.Generator().manual_seed(4)
     U, I, F, B = 400, 150, 16, 128
-    a = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="deferred", init_seed=3)
+    a = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="deferred", init_seed=3, replay="exact")      # (the fast form: test_gpu_sparse_optim.py)
     b = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="sweep", init_seed=3)
     assert a.deferred and not b.deferred and torch.equal(a.user, b.user)
     draw = lambda N: torch.randint(0, N, (B,), generator=g).int().to(dev)
@@ -199,7 +199,7 @@ def test_bpr_deferred_adam_is_bit_equal_to_the_sweep(dev):
             assert torch.equal(a.user, b.user) and torch.equal(a.item, b.item), t
             assert torch.equal(a.user_m, b.user_m) and torch.equal(a.item_v, b.item_v), t
         if t == 40:                                            # reload into a fresh deferred engine and carry on
-            c = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="deferred", init_seed=99)
+            c = bpr.BPREngine(U, I, F, dev, B, optimizer="adam_dense", dense_impl="deferred", init_seed=99, replay="exact")
             c.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.state_dict().items()})
             a = c
     a.check_ids(); b.check_ids()
