@@ -270,10 +270,18 @@ def twotower_leg(ops, dev, U, I, E, S, B, seed):
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "timing": mode}}
 
 
+_CURSOR = {}
+
+
 def run_steps(eng, batches, n, row0, batch_total, arm=None):
+    """n steps over the batch cycle, CONTINUING where the last call on this cycle stopped: every leg of a run then sees batches in cycle
+    order (restarting at batch 0 per call replayed the same ~20 batches in every leg - their rows came back with lags of a few steps
+    while the seeded long-run state of --steady-state-lags sat untouched in the rest of the table)."""
     nb = len(batches)
+    c0 = _CURSOR.get(id(batches), 0)
+    _CURSOR[id(batches)] = c0 + n
     for s in range(n):
-        u, i, y = batches[s % nb]
+        u, i, y = batches[(c0 + s) % nb]
         if arm is not None:
             arm(s)              # points the graph's event-record nodes at this replay's event pair (brProbeGraphArm)
         eng.train_step(u, i, y, row0=row0, batch_total=batch_total)
@@ -483,6 +491,9 @@ def main():
             raise SystemExit("--steady-state-lags: single GPU, adam_dense by deferred replay")
         seeded = seed_steady_state(eng, uniq_u, uniq_i, args.since_flush, 4 * eng.ALPHA_RING)
         log(f"steady-state lags seeded: user mean lag {seeded['user']['mean_lag']:.1f}, item {seeded['item']['mean_lag']:.1f} steps")
+        need = 3 * args.warmup + 2 * args.steps + args.profile_steps + 8
+        if need > n_batches:
+            log(f"WARNING: the legs of this run take ~{need} steps but the cycle has {n_batches} batches: repeated batches come back with lags of a few steps")
     prime = max(args.warmup, n_batches if (deferred_mode and seeded is None) else 0)
     run_steps(eng, batches, prime, row0, batch_total)
     pyprobe = None

@@ -126,6 +126,10 @@ extern "C" int brProbeGraphRead(int slot, float* ms) {
 
 // a call that launches two kernels splits its record: what ran so far is retagged `first_tag`, the rest keeps the call's tag
 void br::probe_split(int first_tag, hipStream_t s) {
+  if (g_gp.open) {        // graph-resident probe of a two-kernel call's FIRST launch (the lookup of the fused lookup + rank call): it ends here
+    g_gp.open = false;
+    (void)capture_record(s, g_gp.ph1, g_gp.ends);
+  }
   if (!g_probe.open) return;
   const int tag = g_probe.tag[g_probe.n];
   g_probe.tag[g_probe.n] = first_tag;
@@ -312,7 +316,9 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
         la2.step_add = 1;
         adv.st = reinterpret_cast<br::StepStateDev*>(s->step_state); adv.lr = s->lr; adv.b1 = s->beta1; adv.b2 = s->beta2; adv.zero = s->dstat; adv.n_zero = n_dstat;
       }
-      RUN(BR_TAG_INDEX_USER, br::lookup_with_index(la2, D, s->id_type, ix, stream, defer_advance ? &adv : nullptr));     // (its first launch is retagged EMBED_FWD)
+      // (its first launch is retagged EMBED_FWD by probe_split; under capture with EMBED_FWD selected the record nodes bracket that launch)
+      const int ltag = (g_gp.sel == BR_TAG_EMBED_FWD && capturing(hs)) ? BR_TAG_EMBED_FWD : BR_TAG_INDEX_USER;
+      RUN(ltag, br::lookup_with_index(la2, D, s->id_type, ix, stream, defer_advance ? &adv : nullptr));
     } else if ((ph & BR_PH_EMBED) && deferred && train)
       RUN(BR_TAG_EMBED_FWD, brNeumfEmbedForwardDeferred(s->user_tab, s->user_m, s->user_v, s->user_last, s->item_tab, s->item_m, s->item_v, s->item_last,
                               s->user_rows, s->item_rows, s->users, s->items, s->id_type, D, B, s->item_first, s->step_state, s->beta1, s->beta2,
