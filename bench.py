@@ -414,8 +414,8 @@ def main():
         cfg = neumf.NeuMFConfig(variant=args.variant, dim=D, optimizer=optimizer, seed=20261004, dense_impl=dense_impl, sync_bn=args.sync_bn, replay=args.replay)
         if ctx is None:
             return neumf.NeuMFEngine(cfg, U, I, dev, B, init_seed=1, id_dtype=idt)
-        # fixed-capacity exchange (no host sync in the step) for uniform ids; Zipf heads overflow 1.25 x batch / world slots per peer
-        return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1, id_dtype=idt, exchange="exact" if args.zipf else "padded")
+        # fixed-capacity exchange (no host sync in the step; duplicate ids are merged before they travel, so Zipf heads fit too)
+        return par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=1, id_dtype=idt, exchange="padded")
 
     log(f"building engine: {U} users x {I} items, dim {D}, batch {B}/GPU, world {world}, {args.optimizer}")
     eng = build(args.optimizer)

@@ -12,7 +12,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "binrec.h")
-LIB_PATH = os.path.join(HERE, "libbinrec_hip.so")
+LIB_PATH = os.environ.get("BR_LIB_PATH") or os.path.join(HERE, "libbinrec_hip.so")     # BR_LIB_PATH: a diagnostic build of the same ABI (tools/diag)
 
 _SCALARS = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,

@@ -54,6 +54,15 @@ void probe_mark(hipStream_t s);                   // "the launch this call is ta
 
 constexpr int kWave = 64;
 
+// Segmented arrays of the row-sharded exchange: both id streams of a step travel in ONE all-to-all buffer laid out
+// [peer][stream][cap] (parallel.py PaddedExchange), so logical position t = peer * cap + j of stream k sits at element
+// (peer * 2 + k) * cap + j = seg_phys(t, cap, 2 * cap, k * cap).  seg_len == 0: contiguous.
+__device__ __host__ __forceinline__ int64_t seg_phys(int64_t t, int64_t seg_len, int64_t seg_stride, int64_t seg_off) {
+  if (seg_len <= 0) return t;
+  const int64_t q = t / seg_len;
+  return q * seg_stride + seg_off + (t - q * seg_len);
+}
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // id load: int32 or int64 storage, identity when ids == nullptr.

@@ -26,6 +26,11 @@ namespace br {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#ifdef BR_ABLATE_MFMA      // timing experiment, see dense_fwd.hip
+#define BR_ABLATE_KEEP(c) (c)
+#else
+#define BR_ABLATE_KEEP(c) true
+#endif
 constexpr int kBwdThreads = 512;
 constexpr int kBwdRows = 64;             // rows per tile
 constexpr int kBwdRep = BR_STAT_REPLICAS;
@@ -250,11 +255,11 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16b(dz[j].x, b[w].x, acc[w]);
 #pragma unroll
-            for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16b(dz[j].y, b[w].y, acc[w]);
+            for (int w = 0; w < WMAX; ++w) if (w < Wn && BR_ABLATE_KEEP((j & 1) == 0)) acc[w] = mfma16b(dz[j].y, b[w].y, acc[w]);
 #pragma unroll
-            for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16b(dz[j].z, b[w].z, acc[w]);
+            for (int w = 0; w < WMAX; ++w) if (w < Wn && BR_ABLATE_KEEP(false)) acc[w] = mfma16b(dz[j].z, b[w].z, acc[w]);
 #pragma unroll
-            for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16b(dz[j].w, b[w].w, acc[w]);
+            for (int w = 0; w < WMAX; ++w) if (w < Wn && BR_ABLATE_KEEP(false)) acc[w] = mfma16b(dz[j].w, b[w].w, acc[w]);
             if (kt0 == 0 && has_next) load_gy_j(j);                    // next tile's gy / y: two loads behind every MFMA block of the first pass
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           if (s + 1 < kBwdRows / 4) fetch(s + 1, n0, n1, nb);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
+            if (!BR_ABLATE_KEEP((s & 7) == 0 || (s & 7) == 3 || (s & 7) == 6)) continue;
             acc[0][nt] = mfma16b(a0, bq[nt], acc[0][nt]);
             if (2 * q + 1 < KT) acc[1][nt] = mfma16b(a1, bq[nt], acc[1][nt]);
           }

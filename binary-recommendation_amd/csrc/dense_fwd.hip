@@ -32,6 +32,13 @@ namespace br {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kRep = BR_STAT_REPLICAS;
+// tools/diag/build_ablate.sh (-DBR_ABLATE_MFMA): a TIMING experiment that issues 3 of every 8 MFMAs (wrong results) - the matrix-pipe time a
+// 6-product bf16 emulation of the fp32 product would have; never defined in the library build
+#ifdef BR_ABLATE_MFMA
+#define BR_ABLATE_KEEP(c) (c)
+#else
+#define BR_ABLATE_KEEP(c) true
+#endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -353,11 +360,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
 #pragma unroll
         for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].x, bc[w].x, acc[w]);
 #pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].y, bc[w].y, acc[w]);
+        for (int w = 0; w < WMAX; ++w) if (w < Wn && BR_ABLATE_KEEP((j & 1) == 0)) acc[w] = mfma16(av[j].y, bc[w].y, acc[w]);
 #pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].z, bc[w].z, acc[w]);
+        for (int w = 0; w < WMAX; ++w) if (w < Wn && BR_ABLATE_KEEP(false)) acc[w] = mfma16(av[j].z, bc[w].z, acc[w]);
 #pragma unroll
-        for (int w = 0; w < WMAX; ++w) if (w < Wn) acc[w] = mfma16(av[j].w, bc[w].w, acc[w]);
+        for (int w = 0; w < WMAX; ++w) if (w < Wn && BR_ABLATE_KEEP(false)) acc[w] = mfma16(av[j].w, bc[w].w, acc[w]);
         __builtin_amdgcn_sched_barrier(0);
       }
       BR_STAMP(5 + 2 * (nt0 / 4));       // pass MFMAs issued

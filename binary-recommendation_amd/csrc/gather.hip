@@ -43,6 +43,27 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a, int dim,
   }
 }
 
+// out[p] = table[ids[p]] at the physical positions p = seg_phys(b) of a segmented id array (the owner side of the row-sharded exchange
+// on tables without deferred Adam), up to two tables of one row width per launch (blockIdx.y)
+struct GatherSegJob { const float* table; int64_t rows; const void* ids; float* out; int64_t seg_off; };
+struct GatherSegJobs { GatherSegJob j[2]; };
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void gather_rows_seg_kernel(GatherSegJobs jobs, int dim, int chunks, int lpr_log2, int64_t n, int64_t seg_len, int64_t seg_stride,
+                                                               int64_t ld_out, int* err) {
+  const GatherSegJob& jb = jobs.j[blockIdx.y];
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (b >= n) return;
+  const int64_t p = seg_phys(b, seg_len, seg_stride, jb.seg_off);
+  const int64_t id = load_id((const IdT*)jb.ids, p);
+  const bool ok = (uint64_t)id < (uint64_t)jb.rows;
+  if (!ok && err && lir == 0) *err = 1;
+  for (int c = lir; c < chunks; c += lpr)
+    vstore<VEC>(jb.out + p * ld_out + c * VEC, ok ? vload<VEC>(jb.table + id * dim + c * VEC) : vzero<VEC>());
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                        float* __restrict__ out, int dim, int chunks,
@@ -86,7 +107,7 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_kernel(
     const float* __restrict__ user_mf, const float* __restrict__ item_mf, int64_t ldu, int64_t ldi,
     int64_t user_rows, int64_t item_rows, const IdT* __restrict__ users, const IdT* __restrict__ items,
     int dim, int chunks, int lpr_log2, int64_t batch, int item_first, float* __restrict__ x0,
-    float* __restrict__ dot, int* err) {
+    float* __restrict__ dot, int* err, float* __restrict__ stash_user, float* __restrict__ stash_item, int64_t ld_stash) {
   using V = typename VecT<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,6 +129,10 @@ __global__ __launch_bounds__(256) void neumf_embed_fwd_kernel(
     if (live) {
       vstore<VEC>(xrow + uoff + c * VEC, um);
       vstore<VEC>(xrow + ioff + c * VEC, im);
+      if (stash_user) {      // the MF rows by batch position: the backward forms ddot * partner row from them (brSegmentSumToSlotsPair)
+        vstore<VEC>(stash_user + b * ld_stash + c * VEC, uf);
+        vstore<VEC>(stash_item + b * ld_stash + c * VEC, vf);
+      }
     }
     s += vdot(uf, vf);
   }
@@ -246,8 +271,8 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_wave_kernel(
 
 // two deferred tables of one geometry served by ONE launch (blockIdx.y): a row-sharded owner's user and item shard - each gather alone
 // is a chain of dependent round trips per row and leaves HBM half idle
-struct GatherDefJob { const float* table; const float* M; const float* Vv; const int32_t* last; int64_t rows; const void* ids; float* out; int64_t n; };
-struct GatherDefJobs { GatherDefJob j[2]; };
+struct GatherDefJob { const float* table; const float* M; const float* Vv; const int32_t* last; int64_t rows; const void* ids; float* out; int64_t n; int64_t seg_off = 0; };
+struct GatherDefJobs { GatherDefJob j[2]; int64_t seg_len = 0, seg_stride = 0; };      // segmented ids / outputs: common.h seg_phys
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void gather_rows_deferred_wave_pair_kernel(GatherDefJobs jobs, const StepStateDev* __restrict__ ss, AdamHp h,
                                                                               int64_t ld_out, int* err) {
@@ -255,8 +280,9 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_wave_pair_kernel(Gat
   constexpr int dim = 64 * VEC;
   const GatherDefJob& jb = jobs.j[blockIdx.y];
   const int64_t n = jb.n;
-  const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (b >= n) return;
+  b = seg_phys(b, jobs.seg_len, jobs.seg_stride, jb.seg_off);
   const int lane = (int)(threadIdx.x & 63);
   int64_t r = load_id((const IdT*)jb.ids, b);
   const bool ok = (uint64_t)r < (uint64_t)jb.rows;
@@ -471,22 +497,34 @@ extern "C" int brNeumfEmbedForward(const float* user_mlp, const float* item_mlp,
                                    const float* item_mf, int64_t ld_user, int64_t ld_item, int64_t user_rows,
                                    int64_t item_rows, const void* users, const void* items, int id_type, int dim,
                                    int64_t batch, int item_first, float* x0, float* dot, int* err_flag, brStream stream) {
+  return brNeumfEmbedForwardStash(user_mlp, item_mlp, user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, users, items, id_type, dim, batch, item_first, x0, dot,
+                                  nullptr, nullptr, 0, err_flag, stream);
+}
+
+extern "C" int brNeumfEmbedForwardStash(const float* user_mlp, const float* item_mlp, const float* user_mf,
+                                        const float* item_mf, int64_t ld_user, int64_t ld_item, int64_t user_rows,
+                                        int64_t item_rows, const void* users, const void* items, int id_type, int dim,
+                                        int64_t batch, int item_first, float* x0, float* dot, float* stash_user, float* stash_item, int64_t ld_stash,
+                                        int* err_flag, brStream stream) {
   BR_CHECK_ARG(user_mlp && item_mlp && user_mf && item_mf && x0 && dot, "brNeumfEmbedForward: null pointer");
+  BR_CHECK_ARG((stash_user == nullptr) == (stash_item == nullptr) && (!stash_user || ld_stash >= dim), "brNeumfEmbedForwardStash: both stashes (ld >= dim) or neither");
   BR_CHECK_ARG(dim >= 1 && batch >= 0 && user_rows > 0 && item_rows > 0, "brNeumfEmbedForward: bad sizes");
   BR_CHECK_ARG(ld_user >= dim && ld_item >= dim, "brNeumfEmbedForward: row strides < dim");
   BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brNeumfEmbedForward: bad id_type");
   if (batch == 0) return BR_OK;
-  const RowGeom g = row_geom_ld(dim, (ld_user % 4 == 0 && ld_item % 4 == 0) ? 4 : (ld_user % 2 == 0 && ld_item % 2 == 0) ? 2 : 1);
+  const bool st4 = !stash_user || (ld_stash % 4 == 0 && ((reinterpret_cast<uintptr_t>(stash_user) | reinterpret_cast<uintptr_t>(stash_item)) & 15) == 0);
+  const bool st2 = !stash_user || (ld_stash % 2 == 0 && ((reinterpret_cast<uintptr_t>(stash_user) | reinterpret_cast<uintptr_t>(stash_item)) & 7) == 0);
+  const RowGeom g = row_geom_ld(dim, (ld_user % 4 == 0 && ld_item % 4 == 0 && st4) ? 4 : (ld_user % 2 == 0 && ld_item % 2 == 0 && st2) ? 2 : 1);
   const unsigned grid = grid_for_rows(batch, g.lpr_log2);
   hipStream_t s = (hipStream_t)stream;
   if (id_type == BR_IDS_I32) {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(
                                user_mlp, item_mlp, user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int32_t*)users,
-                               (const int32_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag)));
+                               (const int32_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag, stash_user, stash_item, ld_stash)));
   } else {
     BR_DISPATCH_VEC(g.vec, (neumf_embed_fwd_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(
                                user_mlp, item_mlp, user_mf, item_mf, ld_user, ld_item, user_rows, item_rows, (const int64_t*)users,
-                               (const int64_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag)));
+                               (const int64_t*)items, dim, g.chunks, g.lpr_log2, batch, item_first, x0, dot, err_flag, stash_user, stash_item, ld_stash)));
   }
   BR_CHECK_LAUNCH("brNeumfEmbedForward");
   return BR_OK;
@@ -599,6 +637,55 @@ extern "C" int brGatherRowsDeferredPair(const float* table_a, const float* m_a, 
   else
     BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_pair_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(J, ss, h, ld_out, err_flag)));
   BR_CHECK_LAUNCH("brGatherRowsDeferredPair");
+  return BR_OK;
+}
+
+extern "C" int brGatherRowsDeferredPairSeg(const float* table_a, const float* m_a, const float* v_a, const int32_t* last_a, int64_t rows_a, const float* table_b,
+                                           const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b, const void* ids, float* out, int dim,
+                                           int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b,
+                                           const void* step_state, double beta1, double beta2, double eps, int64_t ld_out, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(table_a && m_a && v_a && last_a && table_b && m_b && v_b && last_b && ids && out && step_state && rows_a > 0 && rows_b > 0 && n >= 0 && ld_out >= dim,
+               "brGatherRowsDeferredPairSeg: bad args");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brGatherRowsDeferredPairSeg: bad id_type");
+  BR_CHECK_ARG(seg_len >= 1 && seg_stride >= seg_len && seg_off_a >= 0 && seg_off_b >= 0, "brGatherRowsDeferredPairSeg: bad segment geometry");
+  if (n == 0) return BR_OK;
+  const int wvec = dim / 64;
+  BR_CHECK_ARG(dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ld_out % wvec == 0 && (reinterpret_cast<uintptr_t>(out) & (4 * wvec - 1)) == 0,
+               "brGatherRowsDeferredPairSeg: rows of 64 / 128 / 256 floats (one wave per row)");
+  GatherDefJobs J;
+  J.j[0] = GatherDefJob{table_a, m_a, v_a, last_a, rows_a, ids, out, n, seg_off_a};
+  J.j[1] = GatherDefJob{table_b, m_b, v_b, last_b, rows_b, ids, out, n, seg_off_b};
+  J.seg_len = seg_len; J.seg_stride = seg_stride;
+  const AdamHp h = make_hp(0.0, beta1, beta2, eps);
+  const StepStateDev* ss = (const StepStateDev*)step_state;
+  const dim3 grid((unsigned)ceil_div(n, 4), 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_pair_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(J, ss, h, ld_out, err_flag)));
+  else
+    BR_DISPATCH_VEC(wvec, (gather_rows_deferred_wave_pair_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(J, ss, h, ld_out, err_flag)));
+  BR_CHECK_LAUNCH("brGatherRowsDeferredPairSeg");
+  return BR_OK;
+}
+
+extern "C" int brGatherRowsPairSeg(const float* table_a, int64_t rows_a, const float* table_b, int64_t rows_b, const void* ids, float* out, int dim, int id_type,
+                                   int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b, int64_t ld_out, int* err_flag,
+                                   brStream stream) {
+  BR_CHECK_ARG(table_a && table_b && ids && out && rows_a > 0 && rows_b > 0 && n >= 0 && dim >= 1 && ld_out >= dim, "brGatherRowsPairSeg: bad args");
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brGatherRowsPairSeg: bad id_type");
+  BR_CHECK_ARG(seg_len >= 1 && seg_stride >= seg_len && seg_off_a >= 0 && seg_off_b >= 0, "brGatherRowsPairSeg: bad segment geometry");
+  if (n == 0) return BR_OK;
+  const RowGeom g = row_geom_ld(dim, (ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 4 : (ld_out % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) ? 2 : 1);
+  GatherSegJobs J;
+  J.j[0] = GatherSegJob{table_a, rows_a, ids, out, seg_off_a};
+  J.j[1] = GatherSegJob{table_b, rows_b, ids, out, seg_off_b};
+  const dim3 grid(grid_for_rows(n, g.lpr_log2), 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(g.vec, (gather_rows_seg_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(J, dim, g.chunks, g.lpr_log2, n, seg_len, seg_stride, ld_out, err_flag)));
+  else
+    BR_DISPATCH_VEC(g.vec, (gather_rows_seg_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(J, dim, g.chunks, g.lpr_log2, n, seg_len, seg_stride, ld_out, err_flag)));
+  BR_CHECK_LAUNCH("brGatherRowsPairSeg");
   return BR_OK;
 }
 

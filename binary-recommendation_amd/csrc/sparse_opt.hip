@@ -692,7 +692,11 @@ struct IdxJob {
   uint32_t* cp;       // [n] their positions
   uint32_t upper;     // ids are valid in [0, upper)
   int end_bit;
+  // segmented id arrays (brRowIndexBuildPairSeg): logical position t sits at element seg_phys(t) of `ids`, and the index carries
+  // that PHYSICAL position (the optimizer reads gradient rows by it); seg_len == 0: contiguous
+  int64_t seg_len = 0, seg_stride = 0, seg_off = 0;
 };
+
 struct IdxJobs { IdxJob j[2]; };
 
 // chunk `chunk` of id stream `which` by the calling workgroup of kSortThreads threads
@@ -708,9 +712,10 @@ __device__ __forceinline__ void chunk_sort_block(const IdxJobs& jobs, int64_t n,
 #pragma unroll
   for (int q = 0; q < IPT; ++q) {
     const int64_t e = base + q;
-    const int64_t id = e < n ? (int64_t)ids[e] : -1;
+    const int64_t pe = seg_phys(e, job.seg_len, job.seg_stride, job.seg_off);
+    const int64_t id = e < n ? (int64_t)ids[pe] : -1;
     k[q] = e < n ? (((uint64_t)id < (uint64_t)job.upper) ? (uint32_t)id : job.upper) : job.upper + 1u;   // padding sorts last
-    p[q] = (uint32_t)e;
+    p[q] = (uint32_t)pe;
   }
   Sort(tmp).Sort(k, p, 0, job.end_bit);
 #pragma unroll
@@ -805,7 +810,7 @@ static int index_build_rank(IdxJobs& jobs, int n_jobs, int id_type, int64_t n, h
   return BR_OK;
 }
 static IdxJob make_job(const void* ids, void* sorted_ids, int32_t* sorted_pos, void* workspace, int64_t n, int64_t upper) {
-  IdxJob j;
+  IdxJob j{};
   j.ids = ids; j.sorted_ids = sorted_ids; j.sorted_pos = sorted_pos;
   j.ck = (uint32_t*)workspace;
   j.cp = (uint32_t*)((char*)workspace + align256(n * 4));
@@ -884,6 +889,29 @@ extern "C" int brRowIndexBuildPair(const void* ids_a, int64_t upper_a, void* sor
   }
   const int rc = brRowIndexBuild(ids_a, id_type, n, upper_a, sorted_ids_a, sorted_pos_a, ws_a, ws_a_bytes, stream);
   return rc != BR_OK ? rc : brRowIndexBuild(ids_b, id_type, n, upper_b, sorted_ids_b, sorted_pos_b, ws_b, ws_b_bytes, stream);
+}
+
+// The same pair of indexes over SEGMENTED id arrays: both streams of a row-sharded step arrive in ONE all-to-all buffer laid out
+// [source rank][stream][cap] (parallel.py PaddedExchange), so stream k's logical position t = src * cap + j sits at element
+// (src * 2 + k) * cap + j.  sorted_pos holds that physical element index: the owner's optimizer reads the received gradient rows (same
+// layout, one buffer for both streams) by it.  Stable in logical = physical order.
+extern "C" int brRowIndexBuildPairSeg(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
+                                      const void* ids_b, int64_t upper_b, void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes,
+                                      int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brRowIndexBuildPairSeg: bad id_type");
+  BR_CHECK_ARG(seg_len >= 1 && seg_stride >= seg_len && seg_off_a >= 0 && seg_off_b >= 0, "brRowIndexBuildPairSeg: bad segment geometry");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(ids_a && ids_b && sorted_ids_a && sorted_ids_b && sorted_pos_a && sorted_pos_b && ws_a && ws_b, "brRowIndexBuildPairSeg: null pointer");
+  BR_CHECK_ARG(rank_path_ok(n, upper_a) && rank_path_ok(n, upper_b) && seg_phys(n - 1, seg_len, seg_stride, seg_off_a > seg_off_b ? seg_off_a : seg_off_b) < ((int64_t)1 << 31),
+               "brRowIndexBuildPairSeg: n <= %lld positions and id bounds < 2^31 - 2", (long long)kRankMaxN);
+  const int64_t need = brRowIndexWorkspaceBytes(n, id_type);
+  if (ws_a_bytes < need || ws_b_bytes < need) { set_error("brRowIndexBuildPairSeg: workspace < required %lld", (long long)need); return BR_ERR_WORKSPACE; }
+  IdxJobs jobs;
+  jobs.j[0] = make_job(ids_a, sorted_ids_a, sorted_pos_a, ws_a, n, upper_a);
+  jobs.j[1] = make_job(ids_b, sorted_ids_b, sorted_pos_b, ws_b, n, upper_b);
+  jobs.j[0].seg_len = jobs.j[1].seg_len = seg_len; jobs.j[0].seg_stride = jobs.j[1].seg_stride = seg_stride;
+  jobs.j[0].seg_off = seg_off_a; jobs.j[1].seg_off = seg_off_b;
+  return index_build_rank(jobs, 2, id_type, n, (hipStream_t)stream);
 }
 
 static bool wave_rows_enabled();
@@ -969,6 +997,74 @@ extern "C" int brSegmentSumRows(const void* sorted_ids, int id_type, const int32
     BR_DISPATCH_VEC(g.vec, (segment_sum_kernel<int64_t, VEC><<<grid, 256, 0, s>>>((const int64_t*)sorted_ids, sorted_pos, n, row_grads,
                                                                                    ldg, dim, g.chunks, g.lpr_log2, out_rows, head_flag, seg_ws)));
   BR_CHECK_LAUNCH("brSegmentSumRows");
+  return BR_OK;
+}
+
+// ---- requester side of the row-sharded exchange: per-unique-id gradient sums laid into the send slots -------------------------------
+// One row group per sorted position of the (owner, id)-sorted index of brShardDedupPlanPair; a head sums its run (two-level order,
+// as everywhere) straight from the step's gradient sources - columns [0, split) from g0 (the MLP half of dx0), [split, dim) from g1
+// times sc1[position] (the partner's stashed MF row times ddot) - and stores the sum at row slot[position of the head] of the merged
+// slot buffer.  Heads whose id found no slot (capacity overflow, id out of range: slot < 0) store nothing.
+struct SlotSumJob {
+  const void* sid; const int32_t* spos; const int32_t* slot;
+  const float* g0; const float* g1; const float* part;
+};
+struct SlotSumJobs { SlotSumJob j[2]; };
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void segment_sum_to_slots_kernel(SlotSumJobs jobs, int64_t n, int64_t ldg0, int64_t ldg1, const float* __restrict__ sc1, int dim,
+                                                                    int chunks, int lpr_log2, int split, float* __restrict__ out) {
+  using V = typename VecT<VEC>::type;
+  const SlotSumJob& jb = jobs.j[blockIdx.y];
+  const IdT* __restrict__ sid = (const IdT*)jb.sid;
+  const int32_t* __restrict__ spos = jb.spos;
+  const int lpr = 1 << lpr_log2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = tid >> lpr_log2;
+  const int lir = (int)(tid & (lpr - 1));
+  if (i >= n) return;
+  if (!segment_head(sid, i)) return;
+  const int64_t sl = (int64_t)jb.slot[spos[i]];
+  if (sl < 0) return;
+  const IdT row = sid[i];
+  for (int c = lir; c < chunks; c += lpr) {
+    const int col = c * VEC;
+    const bool lo = col < split;
+    const float* g = lo ? jb.g0 + col : jb.g1 + (col - split);
+    const V acc = seg_acc<IdT, VEC>(sid, spos, n, i, row, g, lo ? ldg0 : ldg1, lo ? nullptr : sc1, jb.part ? jb.part + col : nullptr, dim);
+    vstore<VEC>(out + sl * dim + col, acc);
+  }
+}
+
+extern "C" int brSegmentSumToSlotsPair(const void* sorted_ids_a, const int32_t* sorted_pos_a, const int32_t* slot_a, const float* g0_a, const float* g1_a,
+                                       const void* sorted_ids_b, const int32_t* sorted_pos_b, const int32_t* slot_b, const float* g0_b, const float* g1_b,
+                                       int64_t ldg0, int64_t ldg1, const float* hi_scale, int id_type, int64_t n, int dim, int split, float* out_slots,
+                                       float* seg_ws_a, float* seg_ws_b, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brSegmentSumToSlotsPair: bad id_type");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(sorted_ids_a && sorted_pos_a && slot_a && g0_a && sorted_ids_b && sorted_pos_b && slot_b && g0_b && out_slots && dim >= 1, "brSegmentSumToSlotsPair: null pointer");
+  if (!g1_a || !g1_b) { split = dim; g1_a = g0_a; g1_b = g0_b; ldg1 = ldg0; hi_scale = nullptr; }
+  BR_CHECK_ARG(split >= 1 && split <= dim && ldg0 >= split && ldg1 >= dim - split, "brSegmentSumToSlotsPair: bad split / strides");
+  BR_CHECK_ARG((seg_ws_a == nullptr) == (seg_ws_b == nullptr), "brSegmentSumToSlotsPair: seg_ws for both streams or neither");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(g0_a) | reinterpret_cast<uintptr_t>(g1_a) | reinterpret_cast<uintptr_t>(g0_b) | reinterpret_cast<uintptr_t>(g1_b) |
+                       reinterpret_cast<uintptr_t>(out_slots);
+  const int64_t lm = (ldg0 % 4 == 0 && ldg1 % 4 == 0 && split % 4 == 0 && dim % 4 == 0 && (al & 15) == 0) ? 4
+                     : (ldg0 % 2 == 0 && ldg1 % 2 == 0 && split % 2 == 0 && dim % 2 == 0 && (al & 7) == 0) ? 2 : 1;
+  const RowGeom g = row_geom_ld(dim, lm);
+  hipStream_t s = (hipStream_t)stream;
+  if (seg_ws_a) {
+    const SegJob segs[2] = {SegJob{sorted_ids_a, sorted_pos_a, g0_a, ldg0, g1_a, ldg1, seg_ws_a, hi_scale}, SegJob{sorted_ids_b, sorted_pos_b, g0_b, ldg0, g1_b, ldg1, seg_ws_b, hi_scale}};
+    const int rc = launch_partials(segs, 2, id_type, n, dim, g, split, s);
+    if (rc != BR_OK) return rc;
+  }
+  SlotSumJobs J;
+  J.j[0] = SlotSumJob{sorted_ids_a, sorted_pos_a, slot_a, g0_a, g1_a, seg_ws_a};
+  J.j[1] = SlotSumJob{sorted_ids_b, sorted_pos_b, slot_b, g0_b, g1_b, seg_ws_b};
+  const dim3 grid((unsigned)ceil_div(n, 256 >> g.lpr_log2), 2);
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(g.vec, (segment_sum_to_slots_kernel<int32_t, VEC><<<grid, 256, 0, s>>>(J, n, ldg0, ldg1, hi_scale, dim, g.chunks, g.lpr_log2, split, out_slots)));
+  else
+    BR_DISPATCH_VEC(g.vec, (segment_sum_to_slots_kernel<int64_t, VEC><<<grid, 256, 0, s>>>(J, n, ldg0, ldg1, hi_scale, dim, g.chunks, g.lpr_log2, split, out_slots)));
+  BR_CHECK_LAUNCH("brSegmentSumToSlotsPair");
   return BR_OK;
 }
 

@@ -68,9 +68,9 @@ def raise_if_flag(flag: torch.Tensor, what="embedding id"):
     v = int(flag.item())
     if v != 0:
         flag.zero_()
-        if v & 2:      # BR_ERRFLAG_CAPACITY (brShardPadPair)
-            raise RuntimeError("row-sharded exchange: more rows for one owner than the fixed per-peer capacity; raise exchange_capacity "
-                               "(ids this skewed need > 1.25 x batch / world slots) or use exchange='exact'")
+        if v & 2:      # BR_ERRFLAG_CAPACITY (brShardDedupPlanPair)
+            raise RuntimeError("row-sharded exchange: more DISTINCT ids for one owner than the fixed per-peer capacity in a step (the surplus ids "
+                               "were dropped from that step: zeros in the forward, no gradient); raise exchange_capacity or use exchange='exact'")
         raise IndexError(f"{what} out of range")
 
 
@@ -175,18 +175,23 @@ def row_dot_backward(a, b, dout, da=None, db=None):
     return da, db
 
 
-def neumf_embed_forward(user_mlp, item_mlp, user_mf, item_mf, users, items, item_first, x0, dot, err_flag=None):
-    """Tables may be separate (row stride = dim) or column views of fused [rows][mlp|mf] allocations."""
+def neumf_embed_forward(user_mlp, item_mlp, user_mf, item_mf, users, items, item_first, x0, dot, err_flag=None, stash=None):
+    """Tables may be separate (row stride = dim) or column views of fused [rows][mlp|mf] allocations.
+    stash = (stash_user, stash_item): (B, dim) views of one row stride that receive the two MF rows of every pair (brNeumfEmbedForwardStash)."""
     u, ut = _ids(users, "users"); i, it = _ids(items, "items")
     id_type = _same_id_type(ut, it)
     dim = user_mlp.shape[1]
     batch = x0.shape[0]
     if user_mlp.stride(0) != user_mf.stride(0) or item_mlp.stride(0) != item_mf.stride(0):
         raise ValueError("mlp/mf tables of one stream must share a row stride")
-    check(_lib.load().brNeumfEmbedForward(user_mlp.data_ptr(), item_mlp.data_ptr(), user_mf.data_ptr(), item_mf.data_ptr(),
-                                          user_mlp.stride(0), item_mlp.stride(0), user_mlp.shape[0], item_mlp.shape[0],
-                                          _p(u), _p(i), id_type, dim, batch, int(item_first), _f32(x0, "x0").data_ptr(),
-                                          _f32(dot, "dot").data_ptr(), _p(err_flag), _stream()), "brNeumfEmbedForward")
+    su, si = stash if stash is not None else (None, None)
+    if su is not None and (su.stride(0) != si.stride(0) or su.shape[0] < batch or si.shape[0] < batch):
+        raise ValueError("stashes must share a row stride and hold the batch")
+    check(_lib.load().brNeumfEmbedForwardStash(user_mlp.data_ptr(), item_mlp.data_ptr(), user_mf.data_ptr(), item_mf.data_ptr(),
+                                               user_mlp.stride(0), item_mlp.stride(0), user_mlp.shape[0], item_mlp.shape[0],
+                                               _p(u), _p(i), id_type, dim, batch, int(item_first), _f32(x0, "x0").data_ptr(),
+                                               _f32(dot, "dot").data_ptr(), _p(su), _p(si), su.stride(0) if su is not None else 0, _p(err_flag), _stream()),
+          "brNeumfEmbedForwardStash")
 
 
 def neumf_embed_backward(user_mf, item_mf, users, items, item_first, dx0, ddot, g_user_mf, g_item_mf,
@@ -264,6 +269,39 @@ def row_index_build_pair(idx_a: RowIndex, ids_a, upper_a: int, idx_b: RowIndex, 
     check(_lib.load().brRowIndexBuildPair(ta.data_ptr(), int(upper_a), idx_a.sorted_ids.data_ptr(), idx_a.sorted_pos.data_ptr(), idx_a.ws.data_ptr(), idx_a.ws_bytes,
                                           tb.data_ptr(), int(upper_b), idx_b.sorted_ids.data_ptr(), idx_b.sorted_pos.data_ptr(), idx_b.ws.data_ptr(), idx_b.ws_bytes,
                                           ty, n, _stream()), "brRowIndexBuildPair")
+
+
+def row_index_build_pair_seg(idx_a: RowIndex, upper_a: int, idx_b: RowIndex, upper_b: int, ids, n: int, seg):
+    """both owner-side dedup indexes over the merged id array of the row-sharded exchange ([source][stream][cap]; seg = (seg_len,
+    seg_stride, offset a, offset b)): n logical positions per stream, sorted_pos = physical element index (brRowIndexBuildPairSeg)."""
+    t, ty = _ids(ids, "ids")
+    if ty != idx_a.id_type or ty != idx_b.id_type or n > min(idx_a.capacity, idx_b.capacity):
+        raise ValueError("row_index_build_pair_seg: dtype / capacity mismatch")
+    idx_a.n = idx_b.n = n
+    check(_lib.load().brRowIndexBuildPairSeg(t.data_ptr(), int(upper_a), idx_a.sorted_ids.data_ptr(), idx_a.sorted_pos.data_ptr(), idx_a.ws.data_ptr(), idx_a.ws_bytes,
+                                             t.data_ptr(), int(upper_b), idx_b.sorted_ids.data_ptr(), idx_b.sorted_pos.data_ptr(), idx_b.ws.data_ptr(), idx_b.ws_bytes,
+                                             ty, n, *[int(v) for v in seg], _stream()), "brRowIndexBuildPairSeg")
+
+
+def gather_rows_deferred_pair_seg(tab_a, m_a, v_a, last_a, tab_b, m_b, v_b, last_b, ids, out, n, seg, step_state, beta1=0.9, beta2=0.999, eps=1e-7, err_flag=None):
+    """owner-side lookup of both streams of the merged exchange buffer on deferred tables, one launch: out[p] = row ids[p] of the stream's
+    table (as of step - 1) at every physical slot p."""
+    t, ty = _ids(ids, "ids")
+    dim = tab_a.shape[1]
+    check(_lib.load().brGatherRowsDeferredPairSeg(_f32(tab_a, "table_a").data_ptr(), m_a.data_ptr(), v_a.data_ptr(), last_a.data_ptr(), tab_a.shape[0],
+                                                  _f32(tab_b, "table_b").data_ptr(), m_b.data_ptr(), v_b.data_ptr(), last_b.data_ptr(), tab_b.shape[0], t.data_ptr(),
+                                                  _f32(out, "out").data_ptr(), dim, ty, n, *[int(v) for v in seg], step_state.data_ptr(), beta1, beta2, eps,
+                                                  out.stride(0), _p(err_flag), _stream()), "brGatherRowsDeferredPairSeg")
+    return out
+
+
+def gather_rows_pair_seg(tab_a, tab_b, ids, out, n, seg, err_flag=None):
+    """the same on plain tables (brGatherRowsPairSeg)."""
+    t, ty = _ids(ids, "ids")
+    check(_lib.load().brGatherRowsPairSeg(_f32(tab_a, "table_a").data_ptr(), tab_a.shape[0], _f32(tab_b, "table_b").data_ptr(), tab_b.shape[0], t.data_ptr(),
+                                          _f32(out, "out").data_ptr(), tab_a.shape[1], ty, n, *[int(v) for v in seg], out.stride(0), _p(err_flag), _stream()),
+          "brGatherRowsPairSeg")
+    return out
 
 
 def segment_sum_rows(index: RowIndex, row_grads, dim=None, ldg=None, out=None, head_flag=None, two_level=True):

@@ -195,72 +195,71 @@ class ShardExchange:
 
 
 class PaddedExchange:
-    """Both id streams of a NeuMF step with a FIXED number of slots per peer (brShardPadPair): the three all-to-alls per stream
-    have equal static splits, every buffer is allocated once, and nothing about the step is read back by the host - the step's
-    launches and collectives are enqueued without a sync (the exact exchange above needs the per-peer row counts on the host
-    before it can post its first all-to-all).  Pad slots carry the owner's spare table row (gradient 0).  More rows for one owner
-    than `cap` sets a device flag that the engine's check_ids() turns into an error (uniform ids at batch 65 536 / 8 ranks sit
-    20 sigma below the default 1.25 x batch / world; ids as skewed as Zipf(1.05) need a larger factor or the exact exchange)."""
+    """Both id streams of a NeuMF step through ONE all-to-all per phase, duplicate ids merged, a FIXED number of slots per peer
+    (brShardDedupPlanPair): ids out, rows back, row gradients out = 3 collectives per step (+ the dense all-reduce), every split equal
+    and static, every buffer allocated once, nothing about the step read back by the host - the launches and collectives of a step
+    are enqueued without a sync and can be captured into a hipGraph (the exact exchange above needs the per-peer row counts on the
+    host before it can post its first all-to-all).
+    Layout of every exchanged buffer: [peer][stream: user | item][cap] slots (ids: one id per slot; rows / gradients: `dim` floats
+    per slot).  An owner serves each DISTINCT id of a batch once (a Zipf batch with one id on thousands of positions costs one slot);
+    the requester sums the row gradients of an id's positions (ordered, two-level) into its slot before they travel.  Pad slots
+    carry the owner's spare table row (gradient 0).  More than `cap` distinct ids of one stream for one owner: the surplus ids get
+    no slot - the step reads zeros for them and sends no gradient, nothing collides - and a device flag that the engine's
+    check_ids() turns into an error (cap = 1.25 x batch / world: uniform ids at batch 65 536 / 8 ranks sit 20 sigma below it, skewed
+    ids further still; only a batch whose DISTINCT ids crowd onto one owner can overflow)."""
 
     def __init__(self, ctx: DistCtx, max_batch: int, id_dtype, device, total_rows, dim: int, factor: float = 1.25):
         from . import _lib, ops
         W = ctx.world
         self.ctx, self.W, self.dim, self.id_dtype, self.total_rows = ctx, W, int(dim), id_dtype, tuple(int(r) for r in total_rows)
         cap = max_batch if W == 1 else min(max_batch, (int(max_batch / W * factor) + 64) // 64 * 64)
-        self.cap, self.n_slots = cap, W * cap
+        self.cap, self.n_slots = cap, W * cap                 # slots per stream; the merged buffers hold 2 * n_slots
         self.id_type = ops.I64 if id_dtype == torch.int64 else ops.I32
         e = lambda n, dt: torch.empty(n, dtype=dt, device=device)
-        B, S = max_batch, self.n_slots
-        self.dest, self.sdest, self.send = [e(B, id_dtype) for _ in range(2)], [e(B, id_dtype) for _ in range(2)], [e(B, id_dtype) for _ in range(2)]
-        self.order, self.inv = [e(B, torch.int32) for _ in range(2)], [e(B, torch.int32) for _ in range(2)]
-        self.counts = [torch.zeros(W, dtype=torch.int64, device=device) for _ in range(2)]
+        B, S = max_batch, 2 * self.n_slots
+        self.keys, self.skeys = [e(B, id_dtype) for _ in range(2)], [e(B, id_dtype) for _ in range(2)]
+        self.spos, self.urank, self.slot = ([e(B, torch.int32) for _ in range(2)] for _ in range(3))
+        self.first = [torch.zeros(W + 1, dtype=torch.int32, device=device) for _ in range(2)]
         self.ws_bytes = int(_lib.load().brRowIndexWorkspaceBytes(B, self.id_type))
         self.ws = [e(self.ws_bytes, torch.uint8) for _ in range(2)]
-        self.send_pad, self.recv_ids = [e(S, id_dtype) for _ in range(2)], [e(S, id_dtype) for _ in range(2)]
-        self.slot, self.bpos = [e(B, torch.int32) for _ in range(2)], [e(S, torch.int32) for _ in range(2)]
-        f = lambda: [torch.empty(S, self.dim, dtype=torch.float32, device=device) for _ in range(2)]
+        self.seg_ws = [e(int(_lib.load().brSegmentScratchFloats(B, self.dim)), torch.float32) for _ in range(2)]
+        self.send_ids_buf, self.recv_ids = e(S, id_dtype), e(S, id_dtype)
+        f = lambda: torch.empty(S, self.dim, dtype=torch.float32, device=device)
         self.served, self.rows, self.gpad, self.grecv = f(), f(), f(), f()
+        self.seg = (cap, 2 * cap, 0, cap)                     # (seg_len, seg_stride, offset of the user half, of the item half): common.h seg_phys
 
     def plan(self, ids_a, ids_b, err_flag):
         from . import _lib, ops
         n = ids_a.shape[0]
-        if ids_b.shape[0] != n or n > self.dest[0].shape[0]:
+        if ids_b.shape[0] != n or n > self.keys[0].shape[0]:
             raise ValueError("PaddedExchange.plan: both streams must have the same length <= max_batch")
         P = lambda t: t.data_ptr()
-        lib = _lib.load()
-        _lib.check(lib.brShardPlanPair(P(ids_a), P(ids_b), self.id_type, n, self.W, P(self.dest[0]), P(self.dest[1]), P(self.sdest[0]), P(self.sdest[1]),
-                                       P(self.order[0]), P(self.order[1]), P(self.ws[0]), P(self.ws[1]), self.ws_bytes, P(self.inv[0]), P(self.inv[1]),
-                                       P(self.send[0]), P(self.send[1]), P(self.counts[0]), P(self.counts[1]), ops._stream()), "brShardPlanPair")
-        _lib.check(lib.brShardPadPair(P(self.sdest[0]), P(self.sdest[1]), P(self.order[0]), P(self.order[1]), P(self.send[0]), P(self.send[1]),
-                                      P(self.counts[0]), P(self.counts[1]), self.id_type, n, self.W, self.cap, self.total_rows[0], self.total_rows[1],
-                                      P(self.send_pad[0]), P(self.send_pad[1]), P(self.slot[0]), P(self.slot[1]), P(self.bpos[0]), P(self.bpos[1]),
-                                      P(self.gpad[0]), P(self.gpad[1]), self.dim, P(err_flag), ops._stream()), "brShardPadPair")
+        _lib.check(_lib.load().brShardDedupPlanPair(
+            P(ids_a), P(ids_b), self.id_type, n, self.W, self.cap, self.total_rows[0], self.total_rows[1], P(self.keys[0]), P(self.keys[1]),
+            P(self.skeys[0]), P(self.skeys[1]), P(self.spos[0]), P(self.spos[1]), P(self.ws[0]), P(self.ws[1]), self.ws_bytes, P(self.urank[0]), P(self.urank[1]),
+            P(self.first[0]), P(self.first[1]), P(self.send_ids_buf), P(self.slot[0]), P(self.slot[1]), P(self.gpad), self.dim, P(err_flag), ops._stream()),
+            "brShardDedupPlanPair")
         self.n = n
         return self
 
     def send_ids(self):
-        """all-to-all #1 (per stream): padded local row ids -> the ids this rank serves, n_slots each."""
-        for s in range(2):
-            self.ctx.all_to_all_equal(self.recv_ids[s], self.send_pad[s])
-        return self.recv_ids
+        """all-to-all #1: every owner's distinct local row ids of both streams -> the ids this rank serves ([source][stream][cap])."""
+        return self.ctx.all_to_all_equal(self.recv_ids, self.send_ids_buf)
 
     def return_rows(self):
-        """all-to-all #2: self.served (filled by the owner-side gather) -> self.rows in the requester's slot order."""
-        for s in range(2):
-            self.ctx.all_to_all_equal(self.rows[s], self.served[s])
-        return self.rows
+        """all-to-all #2: self.served (filled by the owner-side gather, slot for slot) -> self.rows in the requester's slot numbering."""
+        return self.ctx.all_to_all_equal(self.rows, self.served)
 
-    def send_row_grads(self, g_a=None, g_b=None):
-        """all-to-all #3: the padded gradient slots self.gpad (pad rows were cleared by plan()) -> owners, aligned with recv_ids.
-        g_a / g_b: per-pair rows (n x dim, batch order) to lay into the slots first; None = the producer wrote the slots itself
-        (brNeumfEmbedBackward out_rows_by_id)."""
+    def send_row_grads(self, g0_a, g1_a, g0_b, g1_b, ldg, hi_scale, split):
+        """the per-id sums of the step's row gradients into the send slots (brSegmentSumToSlotsPair: columns [0, split) from g0, the
+        rest hi_scale[position] * g1 - the NeuMF step passes the MLP halves of dx0, the partner streams' stashed MF rows and ddot),
+        then all-to-all #3 -> self.grecv on the owners, slot for slot with recv_ids."""
         from . import _lib, ops
-        if g_a is not None:
-            _lib.check(_lib.load().brRowsToSlotsPair(g_a.data_ptr(), g_b.data_ptr(), g_a.stride(0), self.bpos[0].data_ptr(), self.bpos[1].data_ptr(),
-                                                     self.gpad[0].data_ptr(), self.gpad[1].data_ptr(), self.n_slots, self.dim, ops._stream()), "brRowsToSlotsPair")
-        for s in range(2):
-            self.ctx.all_to_all_equal(self.grecv[s], self.gpad[s])
-        return self.grecv
+        P = lambda t: 0 if t is None else t.data_ptr()
+        _lib.check(_lib.load().brSegmentSumToSlotsPair(P(self.skeys[0]), P(self.spos[0]), P(self.slot[0]), P(g0_a), P(g1_a), P(self.skeys[1]), P(self.spos[1]),
+                                                       P(self.slot[1]), P(g0_b), P(g1_b), ldg, ldg, P(hi_scale), self.id_type, self.n, self.dim, split, P(self.gpad),
+                                                       P(self.seg_ws[0]), P(self.seg_ws[1]), ops._stream()), "brSegmentSumToSlotsPair")
+        return self.ctx.all_to_all_equal(self.grecv, self.gpad)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -394,8 +393,10 @@ def make_sharded_engine(base_cls):
         def _embed_forward(self, users, items, B):
             D = self.cfg.dim
             if self.exchange == "padded":
-                x = self.px.plan(users, items, self.err)
-                ru, ri = x.send_ids()                              # all-to-all #1
+                x, cfg = self.px, self.cfg
+                x.plan(users, items, self.err)
+                rid = x.send_ids()                                 # all-to-all #1 (both streams)
+                S, (sl, ss_, ou_, oi_) = x.n_slots, x.seg
                 # the owner-side dedup indexes depend only on the ids just received: both in shared launches on a side stream,
                 # beside the lookup / MLP, joined before the Adam-rows kernels
                 main = torch.cuda.current_stream(self.device)
@@ -404,22 +405,29 @@ def make_sharded_engine(base_cls):
                 self._ev_ids.record(main)
                 self._side.wait_event(self._ev_ids)
                 with torch.cuda.stream(self._side):
-                    ops.row_index_build_pair(self.user_index, ru, self.local_rows("user_mf"), self.item_index, ri, self.local_rows("item_mf"))
+                    ops.row_index_build_pair_seg(self.user_index, self.local_rows("user_mf"), self.item_index, self.local_rows("item_mf"), rid, S, x.seg)
                     self._ev_index.record(self._side)
-                if self.deferred and ru.shape[0] == ri.shape[0]:  # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64): both shards, one launch
-                    cfg = self.cfg
-                    ops.gather_rows_deferred_pair(self.fused["user"], self.fused_m["user"], self.fused_v["user"], self.last["user"], ru, x.served[0],
-                                                  self.fused["item"], self.fused_m["item"], self.fused_v["item"], self.last["item"], ri, x.served[1],
-                                                  self.step_state, cfg.beta1, cfg.beta2, cfg.adam_eps, err_flag=self.err)
+                # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64): both shards, one launch, straight into the slots
+                if self.deferred and 2 * D in (64, 128, 256):
+                    ops.gather_rows_deferred_pair_seg(self.fused["user"], self.fused_m["user"], self.fused_v["user"], self.last["user"],
+                                                      self.fused["item"], self.fused_m["item"], self.fused_v["item"], self.last["item"], rid, x.served, S, x.seg,
+                                                      self.step_state, cfg.beta1, cfg.beta2, cfg.adam_eps, err_flag=self.err)
+                elif self.deferred:      # other row widths: the row-group gather per stream, through contiguous copies of the stream's slots
+                    W, cap = x.W, x.cap
+                    for k, stream in enumerate(("user", "item")):
+                        ids_k = rid.view(W, 2, cap)[:, k].contiguous().view(-1)
+                        rows_k = self._serve_rows(stream, ids_k)
+                        x.served.view(W, 2, cap, 2 * D)[:, k].copy_(rows_k.view(W, cap, 2 * D))
                 else:
-                    self._serve_rows("user", ru, out=x.served[0])
-                    self._serve_rows("item", ri, out=x.served[1])
-                self.r_user, self.r_item = x.return_rows()         # all-to-all #2
+                    ops.gather_rows_pair_seg(self.fused["user"], self.fused["item"], rid, x.served, S, x.seg, err_flag=self.err)
+                rows = x.return_rows()                             # all-to-all #2 (both streams)
                 self.pos_u, self.pos_i = x.slot[0][:B], x.slot[1][:B]
                 if self.id_dtype != torch.int32:
                     self.pos_u, self.pos_i = self.pos_u.to(self.id_dtype), self.pos_i.to(self.id_dtype)
-                ops.neumf_embed_forward(self.r_user[:, :D], self.r_item[:, :D], self.r_user[:, D:], self.r_item[:, D:], self.pos_u,
-                                        self.pos_i, self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
+                # requester side: the fused embed kernel with the received slots as its "tables" (ids = slots; an id without a slot reads
+                # zeros - flagged by the plan, not here); the MF rows of every pair are stashed by position for the backward
+                ops.neumf_embed_forward(rows[:, :D], rows[:, :D], rows[:, D:], rows[:, D:], self.pos_u, self.pos_i, self.cfg.item_first,
+                                        self.x0[:B], self.dot[:B], None, stash=(self.g_user[:B, D:], self.g_item[:B, D:]))
                 return
             xu, xi = ShardExchange.plan_pair(self.xu, users, self.xi, items)
             xu.exchange_counts(xi)                     # the step's one host sync (variable split sizes)
@@ -472,16 +480,16 @@ def make_sharded_engine(base_cls):
         def _embed_backward_apply(self, users, items, B):
             cfg, D = self.cfg, self.cfg.dim
             if self.exchange == "padded":
-                # fused per-pair row gradients [mlp | mf] written straight into the padded send slots (the ids ARE the slots)
+                # per-id sums of the row gradients [mlp half of dx0 | ddot * the partner's stashed MF row] into the send slots
                 x = self.px
-                gu, gi = x.gpad[0], x.gpad[1]
-                ops.neumf_embed_backward(self.r_user[:, D:], self.r_item[:, D:], self.pos_u, self.pos_i, cfg.item_first,
-                                         self.dx0[:B], self.ddot[:B], gu[:, D:], gi[:, D:], gu[:, :D], gi[:, :D], out_rows_by_id=True)
-                ou, oi = x.send_row_grads()                        # all-to-all #3
+                uo, io = (D, 0) if cfg.item_first else (0, D)
+                dx0 = self.dx0[:B]
+                og = x.send_row_grads(dx0[:, uo:], self.g_item[:B, D:], dx0[:, io:], self.g_user[:B, D:], 2 * D, self.ddot[:B], D)      # + all-to-all #3
                 torch.cuda.current_stream(self.device).wait_event(self._ev_index)
-                # x.served still holds the rows this rank served for these very slots = its rows replayed to step t-1
-                self._adam_tables({"user": (ou, 2 * D, None, 0), "item": (oi, 2 * D, None, 0)},
-                                  replayed={"user": x.served[0], "item": x.served[1]} if self.deferred else None)
+                # x.served still holds the rows this rank served for these very slots = its rows replayed to step t-1; the indexes carry
+                # physical slot numbers, so both tables read the one received buffer
+                self._adam_tables({"user": (og, 2 * D, None, 0), "item": (og, 2 * D, None, 0)},
+                                  replayed={"user": x.served, "item": x.served} if self.deferred else None)
                 return
             gu, gi = self.g_user[:B], self.g_item[:B]
             # fused per-pair row gradients [mlp | mf] (the MLP halves are copied out of dx0 here)

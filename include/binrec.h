@@ -69,6 +69,14 @@ int brNeumfEmbedForward(const float* user_mlp, const float* item_mlp, const floa
                         int64_t item_rows, const void* users, const void* items, int id_type,
                         int dim, int64_t batch, int item_first, float* x0, float* dot,
                         int* err_flag, brStream stream);
+/* The same, also leaving the two MF rows of every pair behind (stash_user[b] = user_mf[u_b], stash_item[b] = item_mf[i_b], stride ld_stash):
+ * the backward of the GMF dot is then ddot[b] * the partner's stash, formed where it is consumed (brSegmentSumToSlotsPair,
+ * brAdamRowsSortedPair hi_scale) instead of by a launch that writes it out per pair. */
+int brNeumfEmbedForwardStash(const float* user_mlp, const float* item_mlp, const float* user_mf,
+                             const float* item_mf, int64_t ld_user, int64_t ld_item, int64_t user_rows,
+                             int64_t item_rows, const void* users, const void* items, int id_type, int dim,
+                             int64_t batch, int item_first, float* x0, float* dot, float* stash_user, float* stash_item, int64_t ld_stash,
+                             int* err_flag, brStream stream);
 /* B1 for the same block: per-pair row gradients (IndexedSlices values, [TF-sem]).
  * dx0: (B x 2*dim) gradient w.r.t. the concat; ddot: (B).
  * g_user_mf[b] = ddot[b]*item_mf[i_b], g_item_mf[b] = ddot[b]*user_mf[u_b];
@@ -130,6 +138,45 @@ int brShardPadPair(const void* sorted_dest_a, const void* sorted_dest_b, const i
                    int32_t* slot_a, int32_t* slot_b, int32_t* bpos_a, int32_t* bpos_b, float* zero_a, float* zero_b, int zero_dim,
                    int* err_flag, brStream stream);   /* zero_*: optional [world*cap][zero_dim] buffers whose pad rows are cleared
                                                          (the gradient send slots, written in place by brNeumfEmbedBackward out_rows_by_id) */
+/* ---- The same exchange with duplicate ids MERGED and both id streams in ONE all-to-all buffer per phase (parallel.py PaddedExchange) ----
+ * Replaces the reference's mirrored variables + all-reduced IndexedSlices (src/models/RModel.py:119, NeuMFModel.py:92-98) for one
+ * NeuMF step: owner(id) = id mod world serves each DISTINCT id of the batch once.
+ * Requester side, brShardDedupPlanPair: key = owner * R + id div world (R = rows per owner, rounded up, + 1), (key, position) sorted;
+ * the k-th distinct key of owner d gets physical slot (d * 2 + stream) * cap + k of the merged buffers [owner][user | item][cap]
+ * (ids out: send_ids; rows back and gradients out: the same slot numbering, `dim` floats per slot); slot[b] = the slot of batch
+ * position b's id or -1; sorted_keys / sorted_pos stay behind as the dedup index of the backward (brSegmentSumToSlotsPair).  Pad slots
+ * name the owner's spare row (index = its row count) and their rows of grad_slots (optional, zero_dim floats each) are cleared.
+ * More than cap DISTINCT ids for one owner and stream: the surplus ids get slot -1 (the step reads zeros for them and sends no
+ * gradient - no slot is ever written twice, no table row sees another row's gradient) and BR_ERRFLAG_CAPACITY is set; ids outside
+ * [0, total_rows): slot -1, BR_ERRFLAG_RANGE.  Scratch: keys / urank [n] each, first [world + 1] int32 each, ws brRowIndexWorkspaceBytes(n). */
+int brShardDedupPlanPair(const void* ids_a, const void* ids_b, int id_type, int64_t n, int world, int64_t cap, int64_t total_rows_a,
+                         int64_t total_rows_b, void* keys_a, void* keys_b, void* sorted_keys_a, void* sorted_keys_b, int32_t* sorted_pos_a,
+                         int32_t* sorted_pos_b, void* ws_a, void* ws_b, int64_t ws_bytes, int32_t* urank_a, int32_t* urank_b, int32_t* first_a,
+                         int32_t* first_b, void* send_ids, int32_t* slot_a, int32_t* slot_b, float* grad_slots, int zero_dim, int* err_flag,
+                         brStream stream);
+/* Backward of that plan: out_slots[slot[p]] = ordered (two-level, see below) sum over the positions p' of p's id of the per-pair row
+ * gradient [g0[p'] (split floats, stride ldg0) | hi_scale[p'] * g1[p'] (dim - split floats, stride ldg1)] - for a NeuMF step g0 = the
+ * MLP half of dx0, g1 = the PARTNER stream's stashed MF rows, hi_scale = ddot (brNeumfEmbedBackward's products without writing them
+ * out per pair).  g1_* NULL: one source (split = dim).  seg_ws_*: brSegmentScratchFloats(n, dim) each, or both NULL. */
+int brSegmentSumToSlotsPair(const void* sorted_ids_a, const int32_t* sorted_pos_a, const int32_t* slot_a, const float* g0_a, const float* g1_a,
+                            const void* sorted_ids_b, const int32_t* sorted_pos_b, const int32_t* slot_b, const float* g0_b, const float* g1_b,
+                            int64_t ldg0, int64_t ldg1, const float* hi_scale, int id_type, int64_t n, int dim, int split, float* out_slots,
+                            float* seg_ws_a, float* seg_ws_b, brStream stream);
+/* Owner side: the ids arrive as ONE array [source rank][stream][cap]; stream k's logical position t = src * cap + j sits at element
+ * (src * 2 + k) * cap + j (seg_len = cap, seg_stride = 2 * cap, seg_off = k * cap).  brRowIndexBuildPairSeg = brRowIndexBuildPair over
+ * such arrays, sorted_pos = the PHYSICAL element index (so the optimizer kernels read received gradient rows / served rows of the same
+ * layout unchanged); brGatherRows[Deferred]PairSeg: out[p] = row ids[p] of the stream's table at every physical position p of both
+ * streams, one launch. */
+int brRowIndexBuildPairSeg(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
+                           const void* ids_b, int64_t upper_b, void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes,
+                           int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b, brStream stream);
+int brGatherRowsDeferredPairSeg(const float* table_a, const float* m_a, const float* v_a, const int32_t* last_a, int64_t rows_a, const float* table_b,
+                                const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b, const void* ids, float* out, int dim,
+                                int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b,
+                                const void* step_state, double beta1, double beta2, double eps, int64_t ld_out, int* err_flag, brStream stream);
+int brGatherRowsPairSeg(const float* table_a, int64_t rows_a, const float* table_b, int64_t rows_b, const void* ids, float* out, int dim, int id_type,
+                        int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b, int64_t ld_out, int* err_flag,
+                        brStream stream);
 /* dst[t] = bpos[t] >= 0 ? src[bpos[t]] : 0 (n_slots rows of dim floats; src rows at stride ld): per-pair rows -> padded send slots,
  * for one or two sets of equal shape (set b NULL: one). */
 int brRowsToSlotsPair(const float* src_a, const float* src_b, int64_t ld, const int32_t* bpos_a, const int32_t* bpos_b, float* dst_a,

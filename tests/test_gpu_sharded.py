@@ -369,7 +369,7 @@ def _overflow_worker(rank, world, port, q):
         neumf = import_module("binary-recommendation_amd.neumf")
         dev = torch.device("cuda:0")
         ctx = par.DistCtx()
-        U, I, Bl = 500, 300, 256
+        U, I, Bl = 1200, 300, 256
         eng = par.make_sharded_engine(neumf.NeuMFEngine)(neumf.NeuMFConfig("A", dim=16), U, I, dev, Bl, ctx, exchange_capacity=1.25)
         assert eng.px.cap == 192                                             # (256 / 2 * 1.25 + 64) // 64 * 64
         g = torch.Generator().manual_seed(5 + rank)
@@ -377,9 +377,27 @@ def _overflow_worker(rank, world, port, q):
         ok_u = torch.randint(0, U, (Bl,), generator=g).int().to(dev)
         it = torch.randint(0, I, (Bl,), generator=g).int().to(dev)
         eng.train_step(ok_u, it, y, row0=rank * Bl, batch_total=world * Bl)
-        eng.check_ids()                                                      # ~128 rows per owner: fits
-        hot = torch.full((Bl,), 6, dtype=torch.int32, device=dev)            # every row of both ranks for owner 0: 256 > 192
+        eng.check_ids()                                                      # ~128 distinct ids per owner: fits
+        hot = torch.full((Bl,), 6, dtype=torch.int32, device=dev)            # ONE id on every position of both ranks: one slot (duplicates are merged)
         eng.train_step(hot, it, y, row0=rank * Bl, batch_total=world * Bl)
+        eng.check_ids()
+        # 256 DISTINCT ids of this rank, all owned by rank 0: 256 > 192 slots.  The surplus (the 64 largest) must be dropped - zeros in the
+        # forward, no gradient - and nothing else may go wrong: the owner updates exactly the ids that found a slot, no other row moves.
+        crowd = (torch.randperm(U // 2, generator=g)[:Bl] * 2).int()
+        before = {k: eng.fused[k].clone() for k in ("user", "item")}
+        eng.train_step(crowd.to(dev), it, y, row0=rank * Bl, batch_total=world * Bl)
+        torch.cuda.synchronize()
+        kept = torch.sort(crowd).values[:192].tolist()                       # slots go to an owner's distinct ids in ascending order
+        lists = [None] * world
+        dist.all_gather_object(lists, kept)
+        if rank == 0:
+            want = sorted({i // world for l in lists for i in l})
+            got = torch.nonzero(eng.last["user"][:-1] == eng.t).view(-1).tolist()      # ([-1]: the spare row behind the pad slots)
+            assert got == want, f"owner updated {len(got)} rows, {len(want)} ids had a slot"
+            moved = torch.nonzero((eng.fused["user"][:-1] != before["user"][:-1]).any(dim=1)).view(-1).tolist()
+            assert set(moved) <= set(want), "a row outside the served ids moved"
+        else:
+            assert int((eng.last["user"][:-1] == eng.t).sum().item()) == 0   # rank 1 owns the odd ids: none in this batch
         try:
             eng.check_ids()
             q.put((rank, "FAIL: overflow not reported"))
@@ -396,6 +414,8 @@ def _overflow_worker(rank, world, port, q):
 
 
 def test_padded_exchange_reports_capacity_overflow(dev):
+    """fixed-capacity exchange: duplicates cost one slot; more DISTINCT ids for one owner than cap -> the surplus is dropped without
+    touching any other row and the flag is raised at the next check_ids()."""
     world, port = 2, _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
