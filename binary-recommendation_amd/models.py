@@ -35,6 +35,46 @@ class History:
             self.history.setdefault(k, []).append(v)
 
 
+def _dist_ctx(distributedConfig=None):
+    """The multi-worker switch of RModel.train (src/models/RModel.py:115-121: `if distributedConfig is not None: strategy =
+    MultiWorkerMirroredStrategy()`).  Here the workers are the ranks of a torch.distributed process group (one process per GPU, backend
+    "nccl" = RCCL, launched with torch.distributed.run): when one is initialised with more than one rank the models build their
+    row-sharded engines on it (parallel.py) -> DistCtx, else None.  A distributedConfig without a process group is an error: the
+    TF_CONFIG cluster description of the reference has no meaning here (INTEGRATION.md "Multi-worker")."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from .parallel import DistCtx
+        return DistCtx()
+    if distributedConfig is not None and not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("distributedConfig given but torch.distributed is not initialised: start one process per GPU with "
+                           "`python -m torch.distributed.run --nproc-per-node N ...` and call torch.distributed.init_process_group('nccl') first")
+    return None
+
+
+def _rank_device(device, ctx):
+    """one process per GPU: the default device of a rank is cuda:LOCAL_RANK"""
+    if ctx is not None and str(device) == "cuda:0" and "LOCAL_RANK" in os.environ and torch.cuda.device_count() > int(os.environ["LOCAL_RANK"]):
+        return f"cuda:{int(os.environ['LOCAL_RANK'])}"
+    return device
+
+
+def _rank_slices(n, gb, ctx):
+    """[(start, stop, row0, batch_total)] of THIS rank for the global batches of size gb over n samples: every global batch is cut into
+    world near-equal consecutive slices (the reference's MirroredStrategy shards each global batch over its replicas [TF-sem]); a ragged
+    tail with fewer samples than ranks is dropped (a rank without a pair cannot enter the step's collectives)."""
+    out = []
+    W, r = (ctx.world, ctx.rank) if ctx is not None else (1, 0)
+    for s in range(0, n, gb):
+        m = min(gb, n - s)
+        if m < W:
+            break
+        base, extra = divmod(m, W)
+        lo = r * base + min(r, extra)
+        cnt = base + (1 if r < extra else 0)
+        out.append((s + lo, s + lo + cnt, lo, m))
+    return out
+
+
 def _to_dev(a, device, dtype):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
@@ -81,6 +121,10 @@ class KerasLikeNeuMF:
         bs = int(batch_size or 32)
         if bs > e.max_batch:
             raise ValueError(f"batch_size {bs} > engine max_batch {e.max_batch}")
+        # multi-worker (row-sharded engine): batch_size is the PER-REPLICA batch, every rank holds the same samples and takes its slice
+        # of each global batch of batch_size x world (global-row dropout masks: row0; loss mean over the global batch: batch_total)
+        ctx = e.dist if getattr(e, "sharded", False) else None
+        slices = _rank_slices(n, bs * (ctx.world if ctx is not None else 1), ctx)
         hist = History()
         g = torch.Generator(device=e.device).manual_seed(seed)
         for ep in range(epochs):
@@ -92,10 +136,12 @@ class KerasLikeNeuMF:
                 uu, ii, ll = u[perm], i[perm], yy[perm]
             else:
                 uu, ii, ll = u, i, yy
-            for s in range(0, n, bs):
-                e.train_step(uu[s:s + bs], ii[s:s + bs], ll[s:s + bs])
+            for lo, hi, row0, bt in slices:
+                e.train_step(uu[lo:hi], ii[lo:hi], ll[lo:hi], row0=row0, batch_total=bt)
             e.check_ids()
-            logs = dict(zip(self.metrics_names, self._metric_values(e.pop_metrics(n))))
+            if ctx is not None:
+                ctx.all_reduce_sum(e.msums)          # the epoch's metric sums of all replicas (a collective: every rank runs fit)
+            logs = dict(zip(self.metrics_names, self._metric_values(e.pop_metrics(sum(s[3] for s in slices)))))
             if validation_data is not None:
                 vl = self.evaluate(validation_data[0], validation_data[1], batch_size=bs)
                 logs.update({"val_" + k: v for k, v in zip(self.metrics_names, vl)})
@@ -128,10 +174,16 @@ class KerasLikeNeuMF:
         """model.save(path) (NFC_plain.py:166, RModel.py:139): tables, dense params, BN moving stats and
         optimizer slots as one safetensors-style torch file (not a TF SavedModel)."""
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        if getattr(self.engine, "sharded", False):   # every rank owns different table rows: every rank writes its shard (parallel.save_sharded)
+            self.engine.save_sharded(path)
+            return
         sd = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in self.engine.state_dict().items()}
         torch.save(sd, path)
 
     def load_weights(self, path):
+        if getattr(self.engine, "sharded", False):
+            self.engine.load_sharded(path)
+            return
         self.engine.load_state_dict(torch.load(path, map_location=self.engine.device, weights_only=True))
 
     def summary(self):
@@ -191,7 +243,14 @@ class NeuMFModel(RModel):
     def compileModel(self, distributedConfig, numUser: int, numItem: int, numFactor: int):
         """NeuMFModel.py:53-100: relu tower F -> F/2 -> F/4, Dot GMF, MSE, Adam(1e-3)."""
         cfg = NeuMFConfig(variant="B", dim=numFactor, optimizer=self.optimizer)
-        self.model = KerasLikeNeuMF(NeuMFEngine(cfg, numUser, numItem, self.device, self.max_batch, id_dtype=torch.int32))
+        ctx = _dist_ctx(distributedConfig)
+        if ctx is not None:      # RModel.py:115-121: multi-worker -> tables row-sharded over the ranks, dense parameters data-parallel
+            from .parallel import make_sharded_engine
+            self.device = _rank_device(self.device, ctx)
+            eng = make_sharded_engine(NeuMFEngine)(cfg, numUser, numItem, self.device, self.max_batch, ctx, id_dtype=torch.int32)
+        else:
+            eng = NeuMFEngine(cfg, numUser, numItem, self.device, self.max_batch, id_dtype=torch.int32)
+        self.model = KerasLikeNeuMF(eng)
         return self.model
 
     def bootstrapDataset(self, df, negRatio=3.0, batchSize=128, shuffle=True, seed=0):
@@ -251,8 +310,14 @@ class BPRModel(RModel):
         self.max_batch, self.optimizer = max_batch, optimizer
 
     def compileModel(self, distributedConfig, numUser: int, numItem: int, numFactor: int):
-        self.model = BPREngine(numUser, numItem, numFactor, self.device, self.max_batch, lr=1e-3, optimizer=self.optimizer)
-        return self.model, None        # the reference returns (model, strategy) (BPRModel.py:74)
+        ctx = _dist_ctx(distributedConfig)
+        if ctx is not None:
+            from .parallel import make_sharded_bpr
+            self.device = _rank_device(self.device, ctx)
+            self.model = make_sharded_bpr(BPREngine)(numUser, numItem, numFactor, self.device, self.max_batch, ctx, lr=1e-3, optimizer=self.optimizer)
+        else:
+            self.model = BPREngine(numUser, numItem, numFactor, self.device, self.max_batch, lr=1e-3, optimizer=self.optimizer)
+        return self.model, ctx         # the reference returns (model, strategy) (BPRModel.py:74): the process group stands for the strategy
 
     def extractPositivesNegatives(self, trainDf, customerId, productIds):
         """BPRModel.py:111-119: every (positive, non-interacted) pair of one customer."""
@@ -333,12 +398,17 @@ class BPRModel(RModel):
         n = _to_dev(X["nProduct_input"], e.device, e.id_dtype).view(-1)
         hist = History()
         g = torch.Generator(device=e.device).manual_seed(seed)
+        ctx = getattr(e, "ctx", None)                 # row-sharded engine (compileModel under a process group): this rank's slice of each global batch
+        slices = _rank_slices(u.shape[0], batch_size * (ctx.world if ctx is not None else 1), ctx)
         for _ in range(epochs):
             perm = torch.randperm(u.shape[0], device=e.device, generator=g)
             uu, pp, nn = u[perm], p[perm], n[perm]
-            for s in range(0, u.shape[0], batch_size):
-                e.train_step(uu[s:s + batch_size], pp[s:s + batch_size], nn[s:s + batch_size])
+            for lo, hi, _row0, bt in slices:
+                e.train_step(uu[lo:hi], pp[lo:hi], nn[lo:hi], batch_total=bt)
             e.check_ids()
+            if ctx is not None:
+                ctx.all_reduce_sum(e.loss_slots)      # the epoch's loss over all replicas (a collective)
+                e.n_seen = sum(s[3] for s in slices) * 1
             hist.add({"loss": e.pop_loss()})
         return hist
 

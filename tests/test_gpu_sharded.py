@@ -130,6 +130,95 @@ def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer, impl, idt, exch
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
 
+def test_sharded_five_ranks_one_gpu(dev, tmp_path):
+    """the same step at the largest world a one-GPU box admits (its process guard allows 6 processes on the card: this runner + 5 ranks; the
+    virtual-rank test of tests/test_gpu_exchange.py covers the kernels at W = 8): owner = r mod 5, cap rounding at an odd W, the 5-way slot
+    blocks of the merged exchange, a sharded checkpoint written by five ranks and re-dealt into a single-GPU engine - NeuMF-A dim 64 (one wave
+    per row kernels on the owners), deferred Keras-Adam, against the oracle's single global step."""
+    world, port = 5, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, "A", 64, "adam_dense", "deferred", q, torch.int32, str(tmp_path), "padded")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
+
+
+def _surface_worker(rank, world, port, q, ckdir):
+    """RModel.train's multi-worker switch (src/models/RModel.py:115-121) on the model surface: under a process group compileModel builds the
+    row-sharded engines, fit feeds every rank its slice of each global batch, save writes one shard per rank."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from importlib import import_module
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        models = import_module("binary-recommendation_amd.models")
+        par = import_module("binary-recommendation_amd.parallel")
+        neumf = import_module("binary-recommendation_amd.neumf")
+        rng = np.random.default_rng(11)
+        U, I, n = 150, 60, 1500
+        u, i = rng.integers(0, U, n).astype(np.int32), rng.integers(0, I, n).astype(np.int32)
+        y = ((u * 7 + i * 3) % 5 == 0).astype(np.float32)
+        m = models.NeuMFModel(device="cuda:0", max_batch=128)
+        cfg_like_tf = {"cluster": {"worker": [f"localhost:{20000 + r}" for r in range(world)]}, "task": {"type": "worker", "index": rank}}
+        model = m.compileModel(cfg_like_tf, U, I, 16)
+        eng = model.engine
+        assert eng.sharded and eng.ctx.world == world and eng.local_rows("user_mf") == par.shard_rows(U, rank, world) + 1
+        h = model.fit({"user": u, "item": i}, y, epochs=4, batch_size=64, shuffle=True)      # 64 per replica: global batches of 64 x world
+        loss = h.history["loss"]
+        assert loss[-1] < loss[0], loss
+        # every replica holds the same dense parameters and reports the same (all-reduced) epoch metrics
+        th = eng.theta.buf.cpu()
+        allth, allloss = [None] * world, [None] * world
+        dist.all_gather_object(allth, th)
+        dist.all_gather_object(allloss, loss)
+        assert all(torch.equal(allth[0], t) for t in allth) and all(l == allloss[0] for l in allloss)
+        path = os.path.join(ckdir, "surface_ck")
+        model.save(path)                                                                       # one shard per rank + meta (collective)
+        pr = model.predict({"user": u[:200], "item": i[:200]})
+        if rank == 0:       # the shards re-dealt into a single-GPU engine give the same scores
+            single = neumf.NeuMFEngine(eng.cfg, U, I, torch.device("cuda:0"), 256)
+            par.load_sharded(single, path, 0, 1, {k: (U if ".user" in k else I) for k in eng.SHARDED_KEYS})
+            ps = single.predict(torch.from_numpy(u[:200]).to("cuda:0"), torch.from_numpy(i[:200]).to("cuda:0")).cpu().numpy().reshape(-1, 1)
+            np.testing.assert_allclose(ps, pr, rtol=2e-6, atol=1e-7)
+        # BPRModel under the same process group
+        b = models.BPRModel(device="cuda:0", max_batch=128)
+        bm, strategy = b.compileModel(cfg_like_tf, U, I, 16)
+        assert strategy is not None and bm.ctx.world == world
+        nn_ = rng.integers(0, I, n).astype(np.int32)
+        hb = b.fit({"customerId_input": u, "pProduct_input": i, "nProduct_input": nn_}, None, batch_size=32, epochs=3)
+        assert hb.history["loss"][-1] < hb.history["loss"][0] < 0.51
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()[-1800:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def test_model_surface_builds_sharded_engines_under_a_process_group(dev, tmp_path):
+    world, port = 3, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_surface_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
+
+
 def _tt_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

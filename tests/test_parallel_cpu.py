@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -69,8 +70,10 @@ def _worker(rank, world, port, U, D, B, out_q):
         dist.destroy_process_group()
 
 
-def test_shard_exchange_gloo_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_exchange_gloo_world2(world):
+    """world 8 = the node the row-sharding is designed for: owner = id mod 8, eight-way count exchange and splits"""
+    port = _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     procs = [ctxm.Process(target=_worker, args=(r, world, port, 101, 16, 64, q)) for r in range(world)]
