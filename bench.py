@@ -482,6 +482,15 @@ def main():
     }
     use_graph = ctx is None and not args.no_graph
     graph_exec = None
+    sharded_graph = None
+    if ctx is not None and not args.no_graph and deferred_mode:
+        # N > 1: the sharded step with its four RCCL collectives as ONE hipGraph per step (captured behind the first eager step; the engine
+        # keeps the eager sequence if the runtime refuses the capture)
+        try:
+            eng.enable_graph(B)
+            sharded_graph = eng
+        except Exception as exc:  # noqa: BLE001
+            log(f"sharded graph not enabled: {exc}")
     # warm-up outside the probe, at least one pass over the batch cycle: the tables are then in the state of a RUNNING job (every row of
     # the cycle carries moments and a lag).  On fresh tables (m = v = 0) the deferred kernels skip their replay arithmetic and look
     # ~30 % faster than they are in steady state.
@@ -763,12 +772,19 @@ def main():
             "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i}, "steady_state_lags": seeded,
             "launch_mode": ((f"hipGraph replay of the whole step, one graph per step; {dom_key} bracketed by event-record nodes inside every 4th replay (a HIP event pair each)"
                              if graph_exec is not None else f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)") if use_graph
-                            else "eager launches (brNeumfStepRun)"),
+                            else (("sharded step incl. its RCCL collectives as one hipGraph per step" if sharded_graph is not None and sharded_graph.graph_active
+                                   else "eager launches (brNeumfStepRun phases + torch.distributed collectives)" + (f" [graph refused: {sharded_graph._sgraph['refused']}]" if sharded_graph is not None and sharded_graph._sgraph else ""))
+                                  if ctx is not None else "eager launches (brNeumfStepRun)")),
             "eager": eager_profile, "graph_error": graph_error,
             "kernels": kernels,
         }
         print(json.dumps(line))
     if ctx is not None:
+        sys.stdout.flush(); sys.stderr.flush()
+        if sharded_graph is not None and sharded_graph.graph_active:
+            # no process-group teardown behind a capture that holds RCCL nodes: destroy_process_group() did not return on ROCm 7.2 / RCCL 2.26
+            ctx.barrier()
+            os._exit(0)
         torch.distributed.destroy_process_group()
 
 

@@ -41,44 +41,87 @@ __global__ __launch_bounds__(256) void dedup_key_kernel(DedupJobs jobs, int64_t 
   ((IdT*)jb.keys)[b] = (IdT)key;
 }
 
-// one 1024-thread workgroup per stream: heads of the sorted keys -> inclusive count - 1 = urank; then first[d] by binary search
+// urank[j] = (number of distinct keys in sorted positions [0, j]) - 1, in two launches of 2048-position blocks: block counts of the heads,
+// then every block adds the counts of the blocks in front of it to its own inclusive scan.  (One 1024-thread workgroup scanning a
+// stream alone took 118 us at 65 536 positions: 64 dependent loads per thread.)
+constexpr int kScanThreads = 256, kScanPer = 8, kScanBlock = kScanThreads * kScanPer;
+
 template <typename IdT>
-__global__ __launch_bounds__(1024) void dedup_scan_kernel(DedupJobs jobs, int64_t n, int world) {
-  const DedupJob& jb = jobs.j[blockIdx.x];
-  const IdT* __restrict__ sk = (const IdT*)jb.skeys;
-  __shared__ int32_t part[1024];
-  const int64_t per = (n + 1023) / 1024;
-  const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-  int32_t c = 0;
-  for (int64_t j = lo; j < hi; ++j) c += (j == 0 || sk[j] != sk[j - 1]) ? 1 : 0;
-  part[threadIdx.x] = c;
+__device__ __forceinline__ int scan_heads(const IdT* __restrict__ sk, int64_t n, int64_t base, int (&flag)[kScanPer]) {
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < kScanPer; ++q) {
+    const int64_t j = base + q;
+    flag[q] = (j < n && (j == 0 || sk[j] != sk[j - 1])) ? 1 : 0;
+    c += flag[q];
+  }
+  return c;
+}
+__device__ __forceinline__ int block_sum_256(int v, int* red) {      // sum over the 256 threads of a workgroup (red: 4 ints of LDS)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {                             // inclusive scan of the 1024 counts
-    const int32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;                 // distinct keys before this thread's range
-  for (int64_t j = lo; j < hi; ++j) {
-    run += (j == 0 || sk[j] != sk[j - 1]) ? 1 : 0;
-    jb.urank[j] = run - 1;
-  }
+  const int t = red[0] + red[1] + red[2] + red[3];
   __syncthreads();
-  __threadfence_block();
-  // (the uranks written above are read back below by OTHER threads of this workgroup: same CU, through L1/L2 - a barrier orders them)
-  for (int d = threadIdx.x; d <= world; d += 1024) {
-    const int64_t want = (int64_t)d * jb.R;                              // first sorted position with key >= d * R
-    int64_t a = 0, b = n;
-    while (a < b) { const int64_t mid = (a + b) >> 1; if ((int64_t)sk[mid] < want) a = mid + 1; else b = mid; }
-    // distinct keys in front of sorted position a = urank[a - 1] + 1 (the key at a, if any, starts a new owner's range: it is a head)
-    jb.first[d] = a == 0 ? 0 : jb.urank[a - 1] + 1;
-  }
+  return t;
 }
 
 template <typename IdT>
-__global__ __launch_bounds__(256) void dedup_slot_kernel(DedupJobs jobs, int64_t n, int world, int64_t cap, IdT* __restrict__ send_ids,
-                                                          float* __restrict__ zero_rows, int zero_dim, int* __restrict__ err) {
+__global__ __launch_bounds__(kScanThreads) void dedup_count_kernel(DedupJobs jobs, int64_t n, int32_t* __restrict__ block_cnt, int n_blocks) {
+  const DedupJob& jb = jobs.j[blockIdx.y];
+  __shared__ int red[4];
+  int flag[kScanPer];
+  const int c = scan_heads((const IdT*)jb.skeys, n, (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanPer, flag);
+  const int t = block_sum_256(c, red);
+  if (threadIdx.x == 0) block_cnt[blockIdx.y * n_blocks + blockIdx.x] = t;
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(kScanThreads) void dedup_rank_kernel(DedupJobs jobs, int64_t n, const int32_t* __restrict__ block_cnt, int n_blocks) {
+  const DedupJob& jb = jobs.j[blockIdx.y];
+  __shared__ int red[4];
+  __shared__ int wave_base[4];
+  // heads in the blocks in front of this one (n_blocks <= 256 for n <= 524 288; more: strided)
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kScanThreads) before += block_cnt[blockIdx.y * n_blocks + b];
+  before = block_sum_256(before, red);
+  int flag[kScanPer];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanPer;
+  const int c = scan_heads((const IdT*)jb.skeys, n, base, flag);
+  // exclusive scan of the per-thread counts: inside the wave by shuffles, across the 4 waves through LDS
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) wave_base[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int run = before + incl - c;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wave_base[w];
+#pragma unroll
+  for (int q = 0; q < kScanPer; ++q) {
+    run += flag[q];
+    if (base + q < n) jb.urank[base + q] = run - 1;
+  }
+}
+
+// first[d] = number of distinct keys in front of owner d's key range (d = 0 .. world; [world] = all valid distinct keys)
+template <typename IdT>
+__global__ __launch_bounds__(256) void dedup_first_kernel(DedupJobs jobs, int64_t n, int world) {
+  const DedupJob& jb = jobs.j[blockIdx.y];
+  const IdT* __restrict__ sk = (const IdT*)jb.skeys;
+  const int d = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (d > world) return;
+  const int64_t want = (int64_t)d * jb.R;                                // first sorted position with key >= d * R
+  int64_t a = 0, b = n;
+  while (a < b) { const int64_t mid = (a + b) >> 1; if ((int64_t)sk[mid] < want) a = mid + 1; else b = mid; }
+  jb.first[d] = a == 0 ? 0 : jb.urank[a - 1] + 1;                        // (the key at a, if any, starts a new owner's range: it is a head)
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void dedup_slot_kernel(DedupJobs jobs, int64_t n, int world, int64_t cap, IdT* __restrict__ send_ids, int* __restrict__ err) {
   const DedupJob& jb = jobs.j[blockIdx.y];
   const IdT* __restrict__ sk = (const IdT*)jb.skeys;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -98,16 +141,24 @@ __global__ __launch_bounds__(256) void dedup_slot_kernel(DedupJobs jobs, int64_t
     }
     jb.slot[jb.spos[t]] = sl;
   }
-  if (t < (int64_t)world * cap) {                                        // pad slots: the owner's spare row, a zero gradient
+  if (t < (int64_t)world * cap) {                                        // pad slots: the owner's spare row
     const int64_t d = t / cap, k = t - d * cap;
     const int64_t used = (int64_t)jb.first[d + 1] - jb.first[d];
-    if (k >= used) {
-      const int64_t ps = (d * 2 + jb.stream) * cap + k;
-      send_ids[ps] = (IdT)(jb.total_rows > d ? (jb.total_rows - d + world - 1) / world : 0);      // rows owner d holds = index of its spare row
-      if (zero_rows)
-        for (int c = 0; c < zero_dim; c += 4) *reinterpret_cast<float4*>(zero_rows + ps * zero_dim + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (k >= used) send_ids[(d * 2 + jb.stream) * cap + k] = (IdT)(jb.total_rows > d ? (jb.total_rows - d + world - 1) / world : 0);      // = rows owner d holds
   }
+}
+
+// the gradient rows of the pad slots cleared (one 16-B store per thread: whole rows leave as coalesced segments)
+__global__ __launch_bounds__(256) void dedup_zero_pads_kernel(DedupJobs jobs, int world, int64_t cap, float* __restrict__ zero_rows, int zero_dim) {
+  const DedupJob& jb = jobs.j[blockIdx.y];
+  const int q4 = zero_dim >> 2;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)world * cap * q4) return;
+  const int64_t t = e / q4;
+  const int c = (int)(e - t * q4) << 2;
+  const int64_t d = t / cap, k = t - d * cap;
+  if (k >= (int64_t)jb.first[d + 1] - jb.first[d])
+    *reinterpret_cast<float4*>(zero_rows + ((d * 2 + jb.stream) * cap + k) * zero_dim + c) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 }  // namespace br
@@ -142,13 +193,30 @@ extern "C" int brShardDedupPlanPair(const void* ids_a, const void* ids_b, int id
                                        sorted_pos_b, ws_b, ws_bytes, id_type, n, stream);
     if (rc != BR_OK) return rc;
   }
-  if (id_type == BR_IDS_I32) dedup_scan_kernel<int32_t><<<2, 1024, 0, s>>>(J, n, world);
-  else dedup_scan_kernel<int64_t><<<2, 1024, 0, s>>>(J, n, world);
-  BR_CHECK_LAUNCH("brShardDedupPlanPair(scan)");
+  if (n > 0) {
+    // block counts of the scan live in the head of workspace a's second half (the sort is done with it: brRowIndexWorkspaceBytes covers
+    // 2 x align256(4 n) bytes, the counts need 8 * ceil(n / 2048) bytes)
+    const int n_blocks = (int)ceil_div(n, kScanBlock);
+    int32_t* block_cnt = (int32_t*)ws_a;
+    BR_CHECK_ARG(ws_bytes >= (int64_t)sizeof(int32_t) * 2 * n_blocks, "brShardDedupPlanPair: workspace too small for the scan");
+    const dim3 gs((unsigned)n_blocks, 2);
+    if (id_type == BR_IDS_I32) { dedup_count_kernel<int32_t><<<gs, kScanThreads, 0, s>>>(J, n, block_cnt, n_blocks); dedup_rank_kernel<int32_t><<<gs, kScanThreads, 0, s>>>(J, n, block_cnt, n_blocks); }
+    else { dedup_count_kernel<int64_t><<<gs, kScanThreads, 0, s>>>(J, n, block_cnt, n_blocks); dedup_rank_kernel<int64_t><<<gs, kScanThreads, 0, s>>>(J, n, block_cnt, n_blocks); }
+    BR_CHECK_LAUNCH("brShardDedupPlanPair(scan)");
+  }
+  const dim3 gf((unsigned)ceil_div(world + 1, 256), 2);
+  if (id_type == BR_IDS_I32) dedup_first_kernel<int32_t><<<gf, 256, 0, s>>>(J, n, world);
+  else dedup_first_kernel<int64_t><<<gf, 256, 0, s>>>(J, n, world);
+  BR_CHECK_LAUNCH("brShardDedupPlanPair(first)");
   const int64_t m = n > (int64_t)world * cap ? n : (int64_t)world * cap;
   const dim3 g2((unsigned)ceil_div(m, 256), 2);
-  if (id_type == BR_IDS_I32) dedup_slot_kernel<int32_t><<<g2, 256, 0, s>>>(J, n, world, cap, (int32_t*)send_ids, grad_slots, zero_dim, err_flag);
-  else dedup_slot_kernel<int64_t><<<g2, 256, 0, s>>>(J, n, world, cap, (int64_t*)send_ids, grad_slots, zero_dim, err_flag);
+  if (id_type == BR_IDS_I32) dedup_slot_kernel<int32_t><<<g2, 256, 0, s>>>(J, n, world, cap, (int32_t*)send_ids, err_flag);
+  else dedup_slot_kernel<int64_t><<<g2, 256, 0, s>>>(J, n, world, cap, (int64_t*)send_ids, err_flag);
   BR_CHECK_LAUNCH("brShardDedupPlanPair(slots)");
+  if (grad_slots) {
+    const dim3 gz((unsigned)ceil_div((int64_t)world * cap * (zero_dim >> 2), 256), 2);
+    dedup_zero_pads_kernel<<<gz, 256, 0, s>>>(J, world, cap, grad_slots, zero_dim);
+    BR_CHECK_LAUNCH("brShardDedupPlanPair(pads)");
+  }
   return BR_OK;
 }

@@ -370,6 +370,12 @@ class NeuMFEngine:
             self._run(PH["ALL"])
             self._keep_for = (self.t + 1, row0) if self.step_struct.keep_prefetch and cfg.dropout > 0 else None
             return
+        self._dist_step(users, items, B)
+
+    def _dist_step(self, users, items, B):
+        """the launches and collectives of one data-parallel step (after _set_batch): no host sync with the fixed-capacity exchange, so the
+        row-sharded engine can capture this body into a hipGraph (parallel.py ShardedNeuMFEngine.enable_graph)."""
+        cfg, PH = self.cfg, self.PH
         d, sync = self.dist, cfg.sync_bn
         emb = 0 if self.sharded else PH["EMBED"]
         if self.sharded:

@@ -444,6 +444,72 @@ def make_sharded_engine(base_cls):
             ops.neumf_embed_forward(self.r_user[:, :D], self.r_item[:, :D], self.r_user[:, D:], self.r_item[:, D:], self.pos_u,
                                     self.pos_i, self.cfg.item_first, self.x0[:B], self.dot[:B], self.err)
 
+        # ------------------------------------------------------------------ hipGraph replay of the sharded step
+        def enable_graph(self, batch: int | None = None):
+            """Replay the row-sharded step - its ~25 launches AND its four RCCL collectives - as ONE hipGraph per step for local batches
+            of exactly `batch` pairs.  Needs the fixed-capacity exchange (no host sync in the step) and deferred tables (every per-step
+            scalar in the device step state).  The first such step runs eagerly on the static input buffers (every kernel and every
+            collective once outside a capture), then the step's body is captured; a runtime / backend that refuses the capture (gloo
+            stages its collectives through the host) keeps the eager sequence - `graph_active` tells which."""
+            if self.exchange != "padded" or not self.deferred:
+                raise ValueError("graph replay of the sharded step needs exchange='padded' and optimizer='adam_dense' with dense_impl='deferred'")
+            B = self.max_batch if batch is None else int(batch)
+            if not 0 < B <= self.max_batch:
+                raise ValueError("graph batch must be in (0, max_batch]")
+            dev = self.device
+            self.in_users = torch.zeros(B, dtype=self.id_dtype, device=dev)
+            self.in_items = torch.zeros(B, dtype=self.id_dtype, device=dev)
+            self.in_labels = torch.zeros(B, dtype=torch.float32, device=dev)
+            self._sgraph = {"batch": B, "graph": None, "key": None, "refused": None}
+
+        def disable_graph(self):
+            self._sgraph = None
+
+        @property
+        def graph_active(self) -> bool:
+            g = getattr(self, "_sgraph", None)
+            return bool(g and g["graph"] is not None)
+
+        def train_step(self, users, items, labels, row0: int = 0, batch_total: int | None = None):
+            g = getattr(self, "_sgraph", None)
+            B = users.shape[0]
+            if g is None or B != g["batch"]:
+                return super().train_step(users, items, labels, row0=row0, batch_total=batch_total)
+            from . import _lib
+            bt = B if batch_total is None else batch_total
+            self._check_batch(users, items, labels)
+            _lib.check(_lib.load().brStageBatch(self.in_users.data_ptr(), self.in_items.data_ptr(), self.in_labels.data_ptr(), users.data_ptr(), items.data_ptr(),
+                                                labels.data_ptr(), self.step_struct.id_type, B, ops._stream()), "brStageBatch")
+            if g["graph"] is not None and g["key"] == (row0, bt):
+                if self.t + 1 - self._flush_t >= self.ALPHA_RING - 8:
+                    self.flush()
+                self._stale = True
+                self.t += 1
+                g["graph"].replay()
+                return
+            super().train_step(self.in_users, self.in_items, self.in_labels, row0=row0, batch_total=bt)      # eager: also the warm-up of the capture
+            if g["graph"] is None and g["refused"] is None:
+                self._capture_step(g, B, row0, bt)
+
+        def _capture_step(self, g, B, row0, bt):
+            ctx = self.ctx
+            if not ctx.local and ctx.backend != "nccl":
+                g["refused"] = f"backend {ctx.backend}: collectives are staged through the host"
+                return
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, row0, bt)
+                with torch.cuda.graph(graph):
+                    self._dist_step(self.in_users, self.in_items, B)
+                g["graph"], g["key"] = graph, (row0, bt)
+            except Exception as exc:  # noqa: BLE001 - the runtime refused (a collective or a launch that cannot be captured): eager from here on
+                g["refused"] = f"{type(exc).__name__}: {exc}"
+                try:
+                    torch.cuda.synchronize(self.device)
+                except Exception:  # noqa: BLE001
+                    pass
+
         SHARDED_KEYS = ("table.user", "table.user.m", "table.user.v", "table.item", "table.item.m", "table.item.v")
 
         def save_sharded(self, path):

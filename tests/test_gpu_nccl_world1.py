@@ -58,6 +58,26 @@ def _worker(port, q):
                 assert np.median(np.abs(a - b)) <= 1e-7, k
             np.testing.assert_allclose(sh.theta.buf.cpu().numpy(), single.theta.buf.cpu().numpy(), rtol=1e-5, atol=2e-2 * travel)
             np.testing.assert_allclose(sh.predict(steps[0][0], steps[0][1]).cpu().numpy(), single.predict(steps[0][0], steps[0][1]).cpu().numpy(), rtol=1e-3, atol=1e-4)
+        # the sharded step INCLUDING its RCCL collectives as one hipGraph per step (ShardedNeuMFEngine.enable_graph): the first step runs eagerly,
+        # the body is captured behind it, later steps replay - same tables as the eager engine fed the same batches
+        cfg = neumf.NeuMFConfig(variant="A", dim=64, seed=11, sync_bn=False)
+        mk = lambda: par.make_sharded_engine(neumf.NeuMFEngine)(cfg, U, I, dev, B, ctx, init_seed=5)
+        eager, graphed = mk(), mk()
+        graphed.enable_graph(B)
+        more = steps + [(torch.randint(0, U, (B,), generator=g).int().to(dev), torch.randint(0, I, (B,), generator=g).int().to(dev),
+                         (torch.rand(B, generator=g) < 0.25).float().to(dev)) for _ in range(4)]
+        for u, i, y in more:
+            eager.train_step(u, i, y)
+            graphed.train_step(u, i, y)
+        torch.cuda.synchronize()
+        eager.check_ids(); graphed.check_ids()
+        graph_note = f"graph_active={graphed.graph_active} refused={graphed._sgraph['refused']}"
+        assert eager.t == graphed.t == len(more)
+        eager.flush(); graphed.flush()
+        for k in ("user", "item"):      # (same launches in the same order; the BatchNorm column sums are double atomics: not bit for bit)
+            np.testing.assert_allclose(graphed.fused[k].cpu().numpy(), eager.fused[k].cpu().numpy(), rtol=1e-5, atol=5e-3 * len(more) * cfg.lr, err_msg=k)
+            assert np.median(np.abs(graphed.fused[k].cpu().numpy() - eager.fused[k].cpu().numpy())) <= 1e-7
+        np.testing.assert_allclose(graphed.theta.buf.cpu().numpy(), eager.theta.buf.cpu().numpy(), rtol=1e-5, atol=2e-2 * len(more) * cfg.lr)
         # BPR and TwoTower sharded steps on the same group
         eb = par.make_sharded_bpr(bpr.BPREngine)(U, I, 16, dev, B, ctx)
         es = bpr.BPREngine(U, I, 16, dev, B)
@@ -75,15 +95,17 @@ def _worker(port, q):
         la, lb = et.pop_loss(), e1.pop_loss()
         assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
         torch.cuda.synchronize()
-        q.put("ok")
+        graphed.disable_graph()
+        del graphed, eager
+        q.put("ok " + graph_note)
     except Exception:  # noqa: BLE001
         import traceback
         q.put("FAIL: " + traceback.format_exc()[-2500:])
     finally:
-        try:
-            dist.destroy_process_group()
-        except Exception:  # noqa: BLE001
-            pass
+        # leave without the process group's teardown: destroy_process_group() after a capture that holds RCCL nodes did not return on ROCm 7.2 /
+        # RCCL 2.26 (the first run of this test sat in it until the box's silence guard ended the call); the result is already in the queue
+        q.close(); q.join_thread()
+        os._exit(0)
 
 
 def test_rccl_one_rank_group(dev):
@@ -96,4 +118,8 @@ def test_rccl_one_rank_group(dev):
     p.start()
     res = q.get(timeout=300)
     p.join(timeout=60)
-    assert res == "ok", res
+    if p.is_alive():        # never leave a child behind: the interpreter would wait for it at exit
+        p.kill()
+        p.join(timeout=30)
+    assert res.startswith("ok"), res
+    print("\n[rccl 1-rank group] sharded step " + res[3:])

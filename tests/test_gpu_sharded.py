@@ -126,6 +126,9 @@ def test_sharded_two_ranks_one_gpu(dev, variant, dim, optimizer, impl, idt, exch
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
@@ -144,6 +147,9 @@ def test_sharded_five_ranks_one_gpu(dev, tmp_path):
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
@@ -215,6 +221,9 @@ def test_model_surface_builds_sharded_engines_under_a_process_group(dev, tmp_pat
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
@@ -279,6 +288,9 @@ def test_sharded_two_tower_global_negatives(dev):
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
@@ -364,6 +376,9 @@ def test_sharded_bpr_two_ranks(dev, optimizer, tmp_path):
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
@@ -443,6 +458,9 @@ def test_per_replica_batchnorm_two_ranks(dev):
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
 
@@ -514,5 +532,8 @@ def test_padded_exchange_reports_capacity_overflow(dev):
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"

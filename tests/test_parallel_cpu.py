@@ -82,6 +82,9 @@ def test_shard_exchange_gloo_world2(world):
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for p in procs:      # never leave a child behind: the interpreter would wait for it at exit
+        if p.is_alive():
+            p.kill()
     assert all(r[1] == "ok" for r in res), res
 
 
