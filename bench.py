@@ -461,8 +461,9 @@ def main():
         "FWD_L1": ((f"dense_fwd[{2 * D}x{n1}]", "dense_fwd_kernel", "mfma", 2.0 * B * 2 * D * n1), ("FWD1",)),
         "FWD_L2": ((f"dense_fwd[{n1}x{n2}] (+ BatchNorm 1 finalize)", "dense_fwd_kernel", "mfma", 2.0 * B * n1 * n2), ("FWD2",)),
         "FWD_L3": ((f"dense_fwd[{n2}x{n3}]", "dense_fwd_kernel", "mfma", 2.0 * B * n2 * n3), ("FWD3",)),
-        "HEAD": ((f"tail: BatchNorm 2 finalize + dense {n2}x{n3} fwd + head + loss + their backward (one launch)", "neumf_tail_mfma_kernel", "mfma",
-                  6.0 * B * n2 * n3), ("FWD3",)),
+        # (an HBM kernel: 0.2 GFLOP over 2 x a2 / gh2 rows + a3, logits, probabilities - SURVEY.md 8d's per-pair bytes of the tail)
+        "HEAD": ((f"tail: BatchNorm 2 finalize + dense {n2}x{n3} fwd + head + loss + their backward (one launch)", "neumf_tail_mfma_kernel", "hbm",
+                  B * (2 * l2 * 4 + n3 * 4 + 5 * 4) + (B * ((n2 + 31) // 32) * 4 if eng.cfg.dropout > 0 else 0)), ("FWD3",)),
         "BWD_L3": ((f"dense_bwd[{n2}x{n3}]", "dense_bwd_kernel", "mfma", 4.0 * B * n2 * n3), ("FWD3",)),
         "BWD_L2": ((f"dense_bwd[{n1}x{n2}] (dx + dW + db + BatchNorm sums, one launch)", "dense_bwd_kernel", "mfma", 4.0 * B * n1 * n2), ("BWD2",)),
         "BWD_L1": ((f"dense_bwd[{2 * D}x{n1}] (dx + dW + db, one launch)", "dense_bwd_kernel", "mfma", 4.0 * B * 2 * D * n1), ("BWD1",)),

@@ -370,6 +370,9 @@ class BPRModel(RModel):
         `items`, bpr_predict scores).  ground_truth: iterable of (user_id, [true item ids])."""
         gt = list(ground_truth)
         col = {it: j for j, it in enumerate(items)}
+        missing = [p for _u, t in gt for p in t if p not in col]
+        if missing:      # the reference's `items.index(p)` (bpr.py:247) raises ValueError for a true item outside `items`
+            raise ValueError(f"{missing[0]!r} is not in list")
         rows = [r for r, (_u, t) in enumerate(gt) for _ in t]
         cols = [col[p] for _u, t in gt for p in t]
         off, idx = ops.truth_csr(len(gt), rows, cols, self.model.device)
@@ -388,7 +391,13 @@ class BPRModel(RModel):
         k = min(int(k), len(items))
         _ts, ti = ops.topk_rows(self._scores([u for u, _ in gt], items), k)
         ap, _ = ops.map_at_k(ti, off, idx, want_hits=False)
-        return float(ap.double().mean().item())
+        # brMapAtK divides by min(truth items it was given, k); the reference by min(len(actual), k) with EVERY listed item, also those
+        # outside `items` (bpr.py:286): rescale per user on the host (tiny vectors).  A user without positives: the reference divides by
+        # zero there (ZeroDivisionError); here such a user contributes AP 0.
+        have = np.array([len({p for p in t if p in col}) for _u, t in gt], dtype=np.float64)
+        want = np.array([len(t) for _u, t in gt], dtype=np.float64)
+        scale = np.where(want > 0, np.minimum(have, k) / np.maximum(np.minimum(want, k), 1.0), 0.0)
+        return float((ap.double().cpu().numpy() * scale).mean())
 
     def fit(self, X: dict, y=None, batch_size=64, epochs=1, seed=0):
         """model.fit({'customerId_input','pProduct_input','nProduct_input'}, ones, batch_size, epochs) (BPRModel.py:100-109)."""
@@ -432,12 +441,41 @@ class TwoTowerModel:
         u, i = self._ids(info)
         return self.engine.compute_emb(u, i, u.shape[0])
 
+    def computeLossTfrs(self, usersCaracteristics, itemCaracteristics, info):
+        """trainers/twoTower.py:82-83: self.task(q, c, compute_metrics=False, training=True, candidate_ids=info[itemKey]) with
+        task = tfrs.tasks.Retrieval(loss=None) [TF-sem, TFRS unpinned]: in-batch softmax over the batch's candidates, accidental hits
+        (another position with the SAME item id) masked with float32 min / 100, categorical cross-entropy from logits, reduction SUM.
+        -> the loss of (q, c) as a 0-dim float32 DEVICE tensor (no host sync), by brInBatchSoftmaxLse."""
+        q, c = _to_dev(usersCaracteristics, self.device, torch.float32), _to_dev(itemCaracteristics, self.device, torch.float32)
+        ids = self.itemTowerIn(info[self.itemKey], self.device)
+        slots = torch.zeros(ops.SUM_SLOTS, dtype=torch.float64, device=self.device)
+        lse = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
+        ops.inbatch_softmax_lse(q, c, ids, ids, 0, lse, slots)
+        return slots.sum().float()
+
+    def computeLossRdZero(self, usersCaracteristics, itemCaracteristics, info):
+        """trainers/twoTower.py:85-87: compiled_loss(info[resKey], sigmoid(Dot(axes=-1)([q, c]))) with the BinaryCrossentropy the trainer
+        compiles (twoTower.py:209): mean over the batch, evaluated from the logit (brRowDot + brBceLogits) -> 0-dim float32 device tensor."""
+        q, c = _to_dev(usersCaracteristics, self.device, torch.float32), _to_dev(itemCaracteristics, self.device, torch.float32)
+        n = q.shape[0]
+        y = _to_dev(info[self.resKey], self.device, torch.float32).view(-1)
+        z = ops.row_dot(q, c)
+        slots = torch.zeros(ops.SUM_SLOTS, dtype=torch.float64, device=self.device)
+        ops.bce_logits(z, y, 1.0 / n, sums=slots)
+        return (slots.sum() / n).float()
+
+    def computeLoss(self, usersCaracteristics, itemCaracteristics, info):
+        """bound at construction like the reference's `self.computeLoss = ...` (twoTower.py:45,48)"""
+        return (self.computeLossRdZero if self.rdZero else self.computeLossTfrs)(usersCaracteristics, itemCaracteristics, info)
+
     def _step_loss(self, batch, mean):
         """the step's loss as a 0-dim DEVICE tensor (metrics["loss"] = loss, twoTower.py:99-102,107-111): the difference of the
-        engine's running loss sum across the step (softmax: the TFRS SUM over the batch; rdZero: mean BCE) - no host sync;
-        float() / .item() on it is the caller's."""
+        engine's running loss sum across the step (softmax: the TFRS SUM over the batch; rdZero train_step: mean BCE, as the
+        compiled loss; test_step: always the retrieval task's SUM, twoTower.py:106) - no host sync; float() / .item() on it is the
+        caller's.  The running sum only grows (both losses are >= 0), so a total BELOW the last one seen means somebody read and
+        cleared the slots in between (engine.pop_loss()): the step's loss is then the total itself."""
         total = self.engine.loss_slots.sum()
-        loss = total - self._loss_seen
+        loss = torch.where(total < self._loss_seen, total, total - self._loss_seen)
         self._loss_seen = total
         return loss / batch if mean else loss
 

@@ -473,6 +473,7 @@ def make_sharded_engine(base_cls):
         def train_step(self, users, items, labels, row0: int = 0, batch_total: int | None = None):
             g = getattr(self, "_sgraph", None)
             B = users.shape[0]
+            self._moving_dirty = True            # (per-replica BatchNorm: this rank's moving statistics move apart from the others')
             if g is None or B != g["batch"]:
                 return super().train_step(users, items, labels, row0=row0, batch_total=batch_total)
             from . import _lib
@@ -527,9 +528,13 @@ def make_sharded_engine(base_cls):
             return super().state_dict()
 
         def sync_moving_stats(self):
-            if self.ctx.world > 1 and not self.cfg.sync_bn:
+            """a COLLECTIVE when per-replica BatchNorm has trained since the last call (every rank must then reach it: state_dict(),
+            save_sharded(), predict() and evaluate_batch() of a sharded engine are collectives anyway); a no-op otherwise, so repeated
+            reads between two training steps cost nothing and cannot hang a lone reader."""
+            if self.ctx.world > 1 and not self.cfg.sync_bn and getattr(self, "_moving_dirty", False):
                 self.ctx.all_reduce_sum(self.moving_buf)
                 self.moving_buf.div_(self.ctx.world)
+            self._moving_dirty = False
 
         def _infer(self, users, items, labels, n):
             self.sync_moving_stats()

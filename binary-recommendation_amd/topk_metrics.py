@@ -55,7 +55,6 @@ def topKMetrics(predictions, positives, usersId, itemsId):
     nbrUser, nbrItem = len(usersId), len(itemsId)
     total = nbrUser * nbrItem
     real = set(positives)
-    urow = {u: n for n, (u, _) in enumerate(predictions)}
     icol = {}
     for _u, lst in predictions:
         for _r, i in lst:
@@ -68,8 +67,14 @@ def topKMetrics(predictions, positives, usersId, itemsId):
         for n, (_u, lst) in enumerate(predictions):
             topk[n, :len(lst)] = [icol[i] for _r, i in lst]
             n_pred += len(lst)
-        rows = [urow[u] for (u, i) in real if u in urow and i in icol]
-        cols = [icol[i] for (u, i) in real if u in urow and i in icol]
+        # the truth CSR has one row per PREDICTION row (a user listed twice in `predictions` is counted twice, as the reference's loop
+        # over `predictions` does, topKmetrics.py:85-93)
+        by_user = {}
+        for (u, i) in real:
+            if i in icol:
+                by_user.setdefault(u, []).append(icol[i])
+        rows = [n for n, (u, _l) in enumerate(predictions) for _ in by_user.get(u, ())]
+        cols = [c for (u, _l) in predictions for c in by_user.get(u, ())]
         off, idx = ops.truth_csr(len(predictions), rows, cols, dev)
         _, h = ops.map_at_k(torch.from_numpy(topk).to(dev), off, idx, want_ap=False)
         h = h.cpu().numpy()

@@ -11,9 +11,13 @@
  * Conventions
  *  - extern "C", plain pointers and sizes, no torch types.  Every function returns int:
  *    BR_OK (0) or a negative BR_ERR_*; brGetLastError() gives the thread-local message.
- *  - Caller owns ALL memory (device buffers, e.g. torch tensors' data_ptr()).  The library
- *    never allocates, never synchronises, and keeps no global state but the error string.
- *    Scratch needs are queried (br*WorkspaceBytes) and passed in by the caller.
+ *  - Caller owns ALL memory (device buffers, e.g. torch tensors' data_ptr()); scratch needs are queried
+ *    (br*WorkspaceBytes) and passed in.  The library allocates no device memory and does not synchronise on a step's
+ *    path.  What it does keep, per process: the thread-local error string; four fork / join events for brNeumfStep.aux_stream
+ *    (created on first use: ONE stepping thread per process, as everywhere in this build); the optional measurement probes
+ *    (brProbe*, brProbeGraph*: HIP events created by brProbeEnable / brProbeGraphSelect, never in a launch path); and, during a
+ *    brNeumfStepRun call, a pointer to that call's step state.  Two entry points synchronise their stream because they copy from
+ *    pageable host memory: brStepStateSet and brStepStateInit (set-up / reload, never inside a step).
  *  - Every launch goes to the caller's stream (`brStream` = hipStream_t).
  *  - Tables are row-major fp32 [rows][dim].  ids are int32 or int64 (BR_IDS_*); ids == NULL
  *    means identity (row b of an already-gathered [batch][dim] buffer: the row-sharded

@@ -90,3 +90,20 @@ def test_product_never_imports_the_oracle():
     src = open(os.path.join(ROOT, "bench.py")).read()
     body = src[src.index("def cpu_baseline"):src.index("def log(")]
     assert len(pat.findall(src)) == len(pat.findall(body)) == 2
+
+
+def test_integration_stub_matches_the_header():
+    """INTEGRATION.md section 1 is generated from include/binrec.h (tools/gen_integration_stub.py): the committed block equals what the
+    generator prints now, and its argtypes list has exactly the header's argument count (round 2 shipped a 16-argument example for an
+    18-argument prototype)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_stub", os.path.join(ROOT, "tools", "gen_integration_stub.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index(gen.BEGIN) + len(gen.BEGIN):text.index(gen.END)].strip()
+    assert block == gen.stub().strip(), "INTEGRATION.md stub is stale: run `python tools/gen_integration_stub.py --write`"
+    _lib = import_module("binary-recommendation_amd._lib")
+    n_header = len(_lib.parse_header()[gen.FN][1])
+    assert block.count("ctypes.c_") - 1 == n_header                      # (one more: the restype line)
+    assert block.count("# ") >= 2 * n_header

@@ -195,3 +195,64 @@ def test_cross_validation_driver(dev, tmp_path):
     assert set(out) >= {"tp", "fp", "fn", "tn", "precision", "recall", "hitRate", "full_hitRate", "full_recall"}
     assert 0.0 < out["hitRate"] <= 1.0 and out["full_hitRate"] >= out["hitRate"] - 1e-9
     assert len(os.listdir(tmp_path / "bench")) == 3
+
+
+def test_cross_validation_equals_the_oracle_side_run(dev):
+    """f-4 against the oracle, not only for its key names: crossValidation on three tiny folds == the same loop restated on the oracle
+    (trainers/twoTower.py:179-272: per fold a fresh TwoTower model, fit for `epoch` epochs over the shuffled batches of the other folds -
+    O.twotower_step_grads + Keras Adagrad per step (O.adagrad_dense / O.adagrad_sparse) -, BruteForce top-k of every user over all items,
+    O.topk_metrics against the held-out fold and against all folds, averaged).  Same initial parameters (the engine's init is a fixed
+    seed), same batch orders (the driver's rng), float64 on the oracle side: the counts tp / fp / fn may differ by a near-tie at a top-k
+    boundary (<= 1 per fold), the rates accordingly."""
+    tr, models = _m("trainers"), _m("models")
+    rng = np.random.default_rng(19)
+    users = [f"c{k}" for k in range(40)]; items = [f"m{k}" for k in range(24)]
+    folds = []
+    for f in range(3):
+        uu = rng.integers(0, 40, 300)
+        folds.append({"CUSTOMER_ID": [users[a] for a in uu], "MATERIAL": [items[(5 * a + rng.integers(0, 3)) % 24] for a in uu], "RATING_TYPE": [1.0] * 300})
+    K, lr, epochs, E, S, bs, seed = 5, 0.1, 2, 12, 8, 64, 3
+    got = tr.crossValidation(folds, K, lr, "Adagrad", None, epochs, E, bs, semb=S, device="cuda:0", seed=seed)
+    # ---- the oracle-side run ----
+    usersId = list(dict.fromkeys(str(x) for ds in folds for x in ds["CUSTOMER_ID"]))
+    matId = list(dict.fromkeys(str(x) for ds in folds for x in ds["MATERIAL"]))
+    uix = {u: n + 2 for n, u in enumerate(usersId)}; iix = {m: n + 2 for n, m in enumerate(matId)}      # StringLookup: '' -> 0, OOV -> 1
+    order_rng = np.random.default_rng(seed)
+    res, full = [], []
+    pairs = lambda ds: [(str(a), str(b)) for a, b in zip(ds["CUSTOMER_ID"], ds["MATERIAL"])]
+    for it in range(3):
+        fresh = models.TwoTowerModel(E, len(matId), len(usersId), "CUSTOMER_ID", "MATERIAL", usersId, matId, semb=S, device="cuda:0", max_batch=bs,
+                                     learningRate=lr, optimiser="Adagrad").engine          # the initial parameters every fold's model starts from
+        Wu, bu = fresh.W("user"); Wi, bi = fresh.W("item")
+        p = {k: v.cpu().numpy().astype(np.float64) for k, v in (("user_emb", fresh.user_emb), ("item_emb", fresh.item_emb), ("Wu", Wu), ("bu", bu), ("Wi", Wi), ("bi", bi))}
+        acc = {k: np.full_like(v, 0.1) for k, v in p.items()}
+        tu = [uix[str(x)] for j, ds in enumerate(folds) if j != it for x in ds["CUSTOMER_ID"]]
+        ti = [iix[str(x)] for j, ds in enumerate(folds) if j != it for x in ds["MATERIAL"]]
+        order = order_rng.permutation(len(tu))
+        tu, ti = np.asarray(tu)[order], np.asarray(ti)[order]
+        for _ in range(epochs):
+            for s0 in range(0, len(tu), bs):
+                u, i = tu[s0:s0 + bs], ti[s0:s0 + bs]
+                _loss, _qc, g, rg = O.twotower_step_grads(p, u, i)
+                for k in ("Wu", "bu", "Wi", "bi"):
+                    p[k], acc[k] = O.adagrad_dense(p[k], acc[k], g[k], lr)
+                p["user_emb"], acc["user_emb"] = O.adagrad_sparse(p["user_emb"], acc["user_emb"], u, rg["user_emb"], lr)
+                p["item_emb"], acc["item_emb"] = O.adagrad_sparse(p["item_emb"], acc["item_emb"], i, rg["item_emb"], lr)
+        q = p["user_emb"][[uix[u] for u in usersId]] @ p["Wu"] + p["bu"]
+        c = p["item_emb"][[iix[m] for m in matId]] @ p["Wi"] + p["bi"]
+        scores = q @ c.T
+        topk = [(u, O.topk_reference_order(scores[n], matId, K)) for n, u in enumerate(usersId)]
+        res.append(O.topk_metrics(topk, pairs(folds[it]), usersId, matId))
+        full.append(O.topk_metrics(topk, [pp for ds in folds for pp in pairs(ds)], usersId, matId))
+    want = {m: sum(r[m] for r in res) / 3 for m in res[0]}
+    want.update({"full_" + m: sum(r[m] for r in full) / 3 for m in full[0]})
+    assert set(got) == set(want)
+    nU = len(usersId)
+    for k in ("tp", "fp", "fn", "tn", "full_tp", "full_fp", "full_fn", "full_tn"):
+        assert abs(got[k] - want[k]) <= 1.0 + 1e-9, (k, got[k], want[k])                      # averaged counts: <= 1 near-tie per fold
+    for k in ("hitRate", "full_hitRate"):
+        assert abs(got[k] - want[k]) <= 1.0 / nU + 1e-12, (k, got[k], want[k])
+    for k in ("precision", "recall", "full_precision", "full_recall"):
+        assert abs(got[k] - want[k]) <= 0.02, (k, got[k], want[k])
+    assert got["tp"] + got["fp"] == want["tp"] + want["fp"] == nU * K                            # every user gets exactly k predictions
+    assert want["hitRate"] > 0.3                                                                   # the folds are learnable: the comparison is not about noise

@@ -152,6 +152,38 @@ def test_twotower_step_vs_golden(dev, rd_zero):
     assert np.median(np.abs(eng.item_emb.cpu().numpy() - ref_t)) <= 1e-7
 
 
+def test_twotower_compute_loss_vs_golden(dev):
+    """TwoTowerModel.computeLoss / computeLossTfrs / computeLossRdZero (trainers/twoTower.py:42-47,82-87) on given (q, c, info): the committed
+    oracle fixture's q, c and losses (tests/golden/twotower_e75_s50_b64.npz: TFRS in-batch softmax with accidental-hit mask, SUM; sigmoid-dot
+    BCE, mean) within 1e-5 relative; also through computeEmb on the fixture's parameters, and the step-loss bookkeeping after a pop_loss()."""
+    models = _m("models")
+    z = np.load(os.path.join(GOLD, "twotower_e75_s50_b64.npz"), allow_pickle=False)
+    E, S = z["p_Wu"].shape
+    nU, nI = z["p_user_emb"].shape[0] - 2, z["p_item_emb"].shape[0] - 2
+    users, items = [f"u{k}" for k in range(nU)], [f"m{k}" for k in range(nI)]
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    info = {"CUSTOMER_ID": [users[k - 2] for k in z["users"]], "MATERIAL": [items[k - 2] for k in z["items"]], "RATING_TYPE": z["labels"]}
+    for rd in (False, True):
+        tag = "rdzero" if rd else "softmax"
+        m = models.TwoTowerModel(E, nI, nU, "CUSTOMER_ID", "MATERIAL", users, items, semb=S, max_batch=64, rdZero=rd, resKey="RATING_TYPE")
+        got = float(m.computeLoss(td(z[tag + "_q"]), td(z[tag + "_c"]), info))
+        want = float(z[tag + "_loss"])
+        assert abs(got - want) <= 1e-5 * abs(want), (tag, got, want)
+        direct = float((m.computeLossRdZero if rd else m.computeLossTfrs)(td(z[tag + "_q"]), td(z[tag + "_c"]), info))
+        assert direct == got
+        e = m.engine
+        e.user_emb.copy_(td(z["p_user_emb"])); e.item_emb.copy_(td(z["p_item_emb"]))
+        Wu, bu = e.W("user"); Wi, bi = e.W("item")
+        Wu.copy_(td(z["p_Wu"])); bu.copy_(td(z["p_bu"])); Wi.copy_(td(z["p_Wi"])); bi.copy_(td(z["p_bi"]))
+        q, c = m.computeEmb(info)                                           # twoTower.py:77-80 -> 82-87
+        assert abs(float(m.computeLoss(q, c, info)) - want) <= 1e-5 * abs(want)
+        l1 = float(m.train_step(info)["loss"])                              # the same loss through the step (first step: the fixture's parameters)
+        assert abs(l1 - want) <= 1e-5 * abs(want), (tag, l1, want)
+        e.pop_loss()                                                        # somebody reads and clears the engine's running sum ...
+        l2 = float(m.train_step(info)["loss"])                              # ... the next step still reports its own loss (not a difference against the old total)
+        assert 0.0 < l2 < l1
+
+
 @pytest.mark.parametrize("optimizer", ["adam_dense", "adam_lazy"])
 def test_bpr_engine_three_steps(dev, optimizer):
     bpr = _m("bpr")
