@@ -252,6 +252,13 @@ def twotower_leg(ops, dev, U, I, E, S, B, seed):
     u, it = (torch.randint(0, U, (B,), generator=g) + 2).int().to(dev), (torch.randint(0, I, (B,), generator=g) + 2).int().to(dev)
     ms = loop_ms(lambda: e.train_step(u, it))
     e.check_ids()
+    ms_graph = None
+    try:      # the same step replayed as one hipGraph (TwoTowerEngine.enable_graph)
+        e.enable_graph(B)
+        ms_graph = loop_ms(lambda: e.train_step(u, it))
+        e.check_ids()
+    except Exception as exc:  # noqa: BLE001
+        log(f"TwoTower graph capture failed: {type(exc).__name__}: {exc}")
     del e
     q, c = torch.randn(B, S, device=dev) * 0.3, torch.randn(B, S, device=dev) * 0.3
     lse, slots = torch.empty(B, device=dev), torch.zeros(64, dtype=torch.float64, device=dev)
@@ -261,8 +268,25 @@ def twotower_leg(ops, dev, U, I, E, S, B, seed):
     t_fused, _ = time_us(lambda: ops.inbatch_softmax_lse_grad_q(q, c, it, it, 0, lse, slots, dq), reps=10)       # what the step runs: lse + dQ in one sweep,
     t_dc, _ = time_us(lambda: ops.inbatch_softmax_grad(q, c, it, it, 0, lse, None, dc), reps=10)                 # then dC
     flop = 2.0 * B * B * S
+    # the per-rank shape of BASELINE configs[3] on 8 GPUs: 1 024 local queries against the 65 536 all-gathered candidates (lse + loss + dQ in
+    # one sweep), then the rank's 1 024 candidates against the 65 536 all-gathered queries (dC): 3 GEMMs of 1 024 x 65 536 x S
+    Bq, Bc = 1024, 65536
+    gq = torch.Generator().manual_seed(seed + 1)
+    qs, ca = torch.randn(Bq, S, device=dev) * 0.3, torch.randn(Bc, S, device=dev) * 0.3
+    qa, cs = torch.randn(Bc, S, device=dev) * 0.3, torch.randn(Bq, S, device=dev) * 0.3
+    ida = (torch.randint(0, I, (Bc,), generator=gq) + 2).int().to(dev)
+    ids_ = ida[:Bq].contiguous()
+    lse_s, lse_a, dqs, dcs = torch.empty(Bq, device=dev), torch.zeros(Bc, device=dev), torch.empty(Bq, S, device=dev), torch.empty(Bq, S, device=dev)
+    t_s1, _ = time_us(lambda: ops.inbatch_softmax_lse_grad_q(qs, ca, ids_, ida, 0, lse_s, slots, dqs), reps=10)
+    lse_a.fill_(10.0)                                   # any finite lse: the dC sweep's time does not depend on its values
+    t_s2, _ = time_us(lambda: ops.inbatch_softmax_grad(qa, cs, ida, ids_, 0, lse_a, None, dcs), reps=10)
+    sflop = 2.0 * Bq * Bc * S
+    stripe = {"shape": f"{Bq} queries x {Bc} gathered candidates, semb {S}", "lse_dq_one_sweep_us": t_s1, "dc_us": t_s2, "algorithmic_flop": 3 * sflop,
+              "achieved_TFLOPs": 3 * sflop / (t_s1 + t_s2) * 1e-6, "frac": 3 * sflop / (t_s1 + t_s2) * 1e-6 / MFMA_F32_PEAK_TFLOPS, "bound": "mfma"}
     return {"workload": f"TwoTower step, {U} users x {I} items, embed {E}, semb {S}, batch {B} (in-batch negatives: {B} candidates), Adagrad, uniform ids",
             "ms_per_step": ms, "pairs_per_s": B / ms * 1e3, "launch_mode": "eager launches from the Python host",
+            "hipgraph_replay": None if ms_graph is None else {"ms_per_step": ms_graph, "pairs_per_s": B / ms_graph * 1e3},
+            "config4_per_rank_stripe": stripe,
             "inbatch_softmax": {"lse_dq_one_sweep_us": t_fused, "dc_us": t_dc, "lse_us": t_lse, "grad_us": t_grad, "bound": "mfma", "algorithmic_flop": 3 * flop,
                                 "achieved_TFLOPs": 3 * flop / (t_fused + t_dc) * 1e-6, "frac": 3 * flop / (t_fused + t_dc) * 1e-6 / MFMA_F32_PEAK_TFLOPS,
                                 "frac_separate_passes": 3 * flop / (t_lse + t_grad) * 1e-6 / MFMA_F32_PEAK_TFLOPS,

@@ -9,6 +9,8 @@ Adam(1e-3) (BPRModel.py:70).  One fused launch does the 3 gathers, 2 dots, the l
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -26,7 +28,6 @@ class BPREngine:
     def __init__(self, num_users: int, num_items: int, num_factor: int, device, max_batch: int, lr: float = 1e-3,
                  optimizer: str = "adam_dense", id_dtype=torch.int32, init_seed: int = 0, dense_impl: str = "deferred", replay: str | None = None):
         assert optimizer in ("adam_dense", "adam_lazy") and dense_impl in ("deferred", "sweep")
-        import os
         self.replay = os.environ.get("BR_REPLAY", "fast") if replay is None else replay      # NeuMFConfig.replay: form of the deferred replay
         assert self.replay in ("fast", "exact")
         self.device, self.max_batch, self.lr, self.optimizer, self.id_dtype = torch.device(device), int(max_batch), lr, optimizer, id_dtype
@@ -173,6 +174,20 @@ class BPREngine:
         """the step's launches (ids2 = [pos | neg] already in place)"""
         gi = self.g_item[:2 * B]
         U, I = self._user, self._item
+        # one-wave-per-row shapes at a batch that fills the chip: the chunk sorts of both id streams ride in the gather's launch, the
+        # chunk-rank launch advances the step state - five launches on one stream, no fork (include/binrec.h brGatherRowsDeferredPairWithIndex)
+        fused = self.deferred and self.dim in (64, 128, 256) and B >= 1024 and 2 * B <= 524288 and max(U.shape[0], I.shape[0]) < (1 << 31) - 2 \
+            and os.environ.get("BR_FUSED_SORT", "1") != "0"
+        if fused:
+            hp = (self.BETA1, self.BETA2, self.EPS)
+            ru, ri = ops.gather_rows_deferred_pair_with_index(U, self.user_m, self.user_v, self.user_last, users, self.r_user[:B], self.user_index,
+                                                              I, self.item_m, self.item_v, self.item_last, ids2, self.r_item[:2 * B], self.item_index,
+                                                              self.step_state, self.lr, *hp, err_flag=self.err)
+            ar = self.pos_b[:B]
+            ops.bpr_forward_backward(ru, ri, ar, ar, self.pos_b[B:2 * B], 1.0 / bt, self.loss_slots, self.g_user[:B], gi, self.per_triplet[:B], self.err)
+            ops.adam_rows_sorted_deferred_pair_replayed(U, self.user_m, self.user_v, self.user_last, self.user_index, self.g_user[:B], ru,
+                                                        I, self.item_m, self.item_v, self.item_last, self.item_index, gi, ri, 0, self.step_state, *hp)
+            return
         if self.deferred:
             _lib.check(_lib.load().brStepStateAdvance(self.step_state.data_ptr(), self.lr, self.BETA1, self.BETA2, None, 0, ops._stream()), "brStepStateAdvance")
         # the two dedup indexes depend only on the ids: each on a side stream of its own (their sort kernels fill 8 and 16 CUs), beside

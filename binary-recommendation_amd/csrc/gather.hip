@@ -271,30 +271,14 @@ __global__ __launch_bounds__(256) void gather_rows_deferred_wave_kernel(
 
 // two deferred tables of one geometry served by ONE launch (blockIdx.y): a row-sharded owner's user and item shard - each gather alone
 // is a chain of dependent round trips per row and leaves HBM half idle
-struct GatherDefJob { const float* table; const float* M; const float* Vv; const int32_t* last; int64_t rows; const void* ids; float* out; int64_t n; int64_t seg_off = 0; };
-struct GatherDefJobs { GatherDefJob j[2]; int64_t seg_len = 0, seg_stride = 0; };      // segmented ids / outputs: common.h seg_phys
+// (GatherDefJob / GatherDefJobs / gather_deferred_wave_row: lookup_wave.h - the fused gather + chunk-sort launch of sparse_opt.hip shares them)
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void gather_rows_deferred_wave_pair_kernel(GatherDefJobs jobs, const StepStateDev* __restrict__ ss, AdamHp h,
                                                                               int64_t ld_out, int* err) {
-  using V = typename VecT<VEC>::type;
-  constexpr int dim = 64 * VEC;
   const GatherDefJob& jb = jobs.j[blockIdx.y];
-  const int64_t n = jb.n;
-  int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (b >= n) return;
-  b = seg_phys(b, jobs.seg_len, jobs.seg_stride, jb.seg_off);
-  const int lane = (int)(threadIdx.x & 63);
-  int64_t r = load_id((const IdT*)jb.ids, b);
-  const bool ok = (uint64_t)r < (uint64_t)jb.rows;
-  if (!ok) { if (err && lane == 0) *err = 1; r = 0; }
-  const uint32_t t = ss->step, seen = (uint32_t)jb.last[r];
-  const int64_t off = r * dim + lane * VEC;
-  V th = vload<VEC>(jb.table + off);
-  if (seen + 1 < t) {
-    V m = vload<VEC>(jb.M + off), v = vload<VEC>(jb.Vv + off);
-    adam_catch_up_uniform<false>(th, m, v, seen, t - 1, ss, h);
-  }
-  vstore<VEC>(jb.out + b * ld_out + lane * VEC, ok ? th : vzero<VEC>());
+  const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (b >= jb.n) return;
+  gather_deferred_wave_row<IdT, VEC>(jobs, jb, b, (int)(threadIdx.x & 63), ss, h, ld_out, err);
 }
 
 // B1 of the GMF dot on the stashed MF rows, in place: (u, i) -> (ddot * i, ddot * u).  No __restrict__: the

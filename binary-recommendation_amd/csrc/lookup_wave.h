@@ -66,4 +66,31 @@ __device__ __forceinline__ void lookup_wave_pair(const LookupArgs& a, int64_t b,
   if (lane == 63) a.dot[b] = s;
 }
 
+// one row of a deferred table by one wave (rows of 64 * VEC floats): out[p] = row ids[p] as of step - 1, p = the physical position of
+// logical position b (segmented id arrays: common.h seg_phys)
+struct GatherDefJob { const float* table; const float* M; const float* Vv; const int32_t* last; int64_t rows; const void* ids; float* out; int64_t n; int64_t seg_off = 0; };
+struct GatherDefJobs {
+  GatherDefJob j[2];
+  int64_t seg_len = 0, seg_stride = 0;
+  uint32_t step_add = 0;      // 1: the step state is advanced BEHIND this launch (by the chunk-rank launch): the step being computed is ss->step + 1
+};
+template <typename IdT, int VEC>
+__device__ __forceinline__ void gather_deferred_wave_row(const GatherDefJobs& jobs, const GatherDefJob& jb, int64_t b, int lane, const StepStateDev* __restrict__ ss,
+                                                         const AdamHp& h, int64_t ld_out, int* err) {
+  using V = typename VecT<VEC>::type;
+  constexpr int dim = 64 * VEC;
+  b = seg_phys(b, jobs.seg_len, jobs.seg_stride, jb.seg_off);
+  int64_t r = load_id((const IdT*)jb.ids, b);
+  const bool ok = (uint64_t)r < (uint64_t)jb.rows;
+  if (!ok) { if (err && lane == 0) *err = 1; r = 0; }
+  const uint32_t t = ss->step + jobs.step_add, seen = (uint32_t)jb.last[r];
+  const int64_t off = r * dim + lane * VEC;
+  V th = vload<VEC>(jb.table + off);
+  if (seen + 1 < t) {
+    V m = vload<VEC>(jb.M + off), v = vload<VEC>(jb.Vv + off);
+    adam_catch_up_uniform<false>(th, m, v, seen, t - 1, ss, h);
+  }
+  vstore<VEC>(jb.out + b * ld_out + lane * VEC, ok ? th : vzero<VEC>());
+}
+
 }  // namespace br

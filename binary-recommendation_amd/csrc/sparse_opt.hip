@@ -695,6 +695,8 @@ struct IdxJob {
   // segmented id arrays (brRowIndexBuildPairSeg): logical position t sits at element seg_phys(t) of `ids`, and the index carries
   // that PHYSICAL position (the optimizer reads gradient rows by it); seg_len == 0: contiguous
   int64_t seg_len = 0, seg_stride = 0, seg_off = 0;
+  int64_t n = 0;      // this stream's keys when the two streams of a launch differ in length (0: the launch's n)
+  int n_chunks = 0;   // its chunk count then
 };
 
 struct IdxJobs { IdxJob j[2]; };
@@ -706,6 +708,7 @@ __device__ __forceinline__ void chunk_sort_block(const IdxJobs& jobs, int64_t n,
   using Sort = hipcub::BlockRadixSort<uint32_t, kSortThreads, IPT, uint32_t>;
   __shared__ typename Sort::TempStorage tmp;
   const IdxJob& job = jobs.j[which];
+  if (job.n) n = job.n;
   const IdT* ids = (const IdT*)job.ids;
   const int64_t base = (int64_t)chunk * kChunk + threadIdx.x * IPT;
   uint32_t k[IPT], p[IPT];
@@ -744,15 +747,37 @@ __global__ __launch_bounds__(kThreadsL) void lookup_sort_kernel(const LookupArgs
   lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
 }
 
+// Two deferred gathers of one row width (rows of 64 * VEC floats, one wave per row) and the chunk sorts of their two id streams in ONE
+// launch of 1024-thread workgroups - the BPR step's user gather (B rows) and [pos | neg] item gather (2 B rows): the first workgroups each
+// sort a chunk, the rest gather 16 rows each and flow around them; the chunk-rank launch (+ the step-state advance) follows on the same
+// stream.  As launches of their own on two side streams the sorts and ranks were 42 % of the step's kernel time and cost a fork / join
+// inside the step's hipGraph.
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(kThreadsL) void gather_sort_kernel(const GatherDefJobs gj, const StepStateDev* __restrict__ ss, const AdamHp h, int64_t ld_out, int* err,
+                                                                IdxJobs jobs, int n_sort_a, int n_sort_b) {
+  const int n_sort = n_sort_a + n_sort_b;
+  if ((int)blockIdx.x < n_sort) {
+    const int which = (int)blockIdx.x < n_sort_a ? 0 : 1;
+    chunk_sort_block<IdT, kChunkL, kThreadsL>(jobs, 0, which ? (int)blockIdx.x - n_sort_a : (int)blockIdx.x, which);
+    return;
+  }
+  int64_t b = ((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int which = b < gj.j[0].n ? 0 : 1;
+  if (which) b -= gj.j[0].n;
+  if (b >= gj.j[which].n) return;
+  gather_deferred_wave_row<IdT, VEC>(gj, gj.j[which], b, (int)(threadIdx.x & 63), ss, h, ld_out, err);
+}
+
 // adv.st != NULL: the grid has one extra column of workgroups, whose y = 0 member advances the step state (nothing in this launch reads it;
 // the lookup in front computed its step as ss->step + 1, everything behind sees the advanced state) - one launch less per step
 template <typename IdT, int kChunk>
-__global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n, int n_chunks, const StepAdvance adv) {
+__global__ __launch_bounds__(256) void chunk_rank_kernel(IdxJobs jobs, int64_t n, int n_chunks, const StepAdvance adv) {      // (n: the longer stream's keys)
   if (adv.st && blockIdx.x == gridDim.x - 1) {
     if (blockIdx.y == 0) step_state_advance_block(adv);
     return;
   }
   const IdxJob& job = jobs.j[blockIdx.y];
+  if (job.n) { n = job.n; n_chunks = job.n_chunks; }
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int c = (int)(e / kChunk);
@@ -946,6 +971,53 @@ int br::lookup_with_index(const LookupArgs& la, int dim, int id_type, const Inde
   if (id_type == BR_IDS_I32) chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks, av);
   else chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, n, n_chunks, av);
   BR_CHECK_LAUNCH("lookup_with_index(rank)");
+  return BR_OK;
+}
+
+extern "C" int brGatherRowsDeferredPairWithIndex(const float* table_a, const float* m_a, const float* v_a, const int32_t* last_a, int64_t rows_a, const void* ids_a,
+                                                 float* out_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes, const float* table_b,
+                                                 const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b, const void* ids_b, float* out_b,
+                                                 void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes, int dim, int id_type, int64_t n_a, int64_t n_b,
+                                                 void* step_state, int advance, double lr, double beta1, double beta2, double eps, int64_t ld_out, int* err_flag,
+                                                 brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brGatherRowsDeferredPairWithIndex: bad id_type");
+  BR_CHECK_ARG(table_a && m_a && v_a && last_a && ids_a && out_a && sorted_ids_a && sorted_pos_a && ws_a && table_b && m_b && v_b && last_b && ids_b && out_b &&
+                   sorted_ids_b && sorted_pos_b && ws_b && step_state && rows_a > 0 && rows_b > 0 && n_a > 0 && n_b > 0 && ld_out >= dim,
+               "brGatherRowsDeferredPairWithIndex: bad args");
+  const int wvec = dim / 64;
+  BR_CHECK_ARG(dim % 64 == 0 && (wvec == 1 || wvec == 2 || wvec == 4) && ld_out % wvec == 0 &&
+                   ((reinterpret_cast<uintptr_t>(out_a) | reinterpret_cast<uintptr_t>(out_b)) & (4 * wvec - 1)) == 0,
+               "brGatherRowsDeferredPairWithIndex: rows of 64 / 128 / 256 floats (one wave per row)");
+  BR_CHECK_ARG(rank_path_ok(n_a, rows_a) && rank_path_ok(n_b, rows_b), "brGatherRowsDeferredPairWithIndex: at most %lld ids per stream, table rows < 2^31 - 2", (long long)kRankMaxN);
+  if (ws_a_bytes < brRowIndexWorkspaceBytes(n_a, id_type) || ws_b_bytes < brRowIndexWorkspaceBytes(n_b, id_type)) {
+    set_error("brGatherRowsDeferredPairWithIndex: index workspace too small");
+    return BR_ERR_WORKSPACE;
+  }
+  GatherDefJobs G;
+  G.j[0] = GatherDefJob{table_a, m_a, v_a, last_a, rows_a, ids_a, out_a, n_a};
+  G.j[1] = GatherDefJob{table_b, m_b, v_b, last_b, rows_b, ids_b, out_b, n_b};
+  G.step_add = advance ? 1u : 0u;
+  IdxJobs jobs;
+  jobs.j[0] = make_job(ids_a, sorted_ids_a, sorted_pos_a, ws_a, n_a, rows_a);
+  jobs.j[1] = make_job(ids_b, sorted_ids_b, sorted_pos_b, ws_b, n_b, rows_b);
+  const int ca = (int)ceil_div(n_a, kChunkL), cb = (int)ceil_div(n_b, kChunkL);
+  jobs.j[0].n = n_a; jobs.j[0].n_chunks = ca; jobs.j[1].n = n_b; jobs.j[1].n_chunks = cb;
+  const AdamHp h = make_hp(0.0, beta1, beta2, eps);
+  StepStateDev* ss = (StepStateDev*)step_state;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(ca + cb + ceil_div(n_a + n_b, kThreadsL / 64));
+  if (id_type == BR_IDS_I32)
+    BR_DISPATCH_VEC(wvec, (gather_sort_kernel<int32_t, VEC><<<grid, kThreadsL, 0, s>>>(G, ss, h, ld_out, err_flag, jobs, ca, cb)));
+  else
+    BR_DISPATCH_VEC(wvec, (gather_sort_kernel<int64_t, VEC><<<grid, kThreadsL, 0, s>>>(G, ss, h, ld_out, err_flag, jobs, ca, cb)));
+  BR_CHECK_LAUNCH("brGatherRowsDeferredPairWithIndex(gather + sort)");
+  StepAdvance av;
+  if (advance) { av.st = ss; av.lr = lr; av.b1 = beta1; av.b2 = beta2; }
+  const int64_t nmax = n_a > n_b ? n_a : n_b;
+  const dim3 g2((unsigned)(ceil_div(nmax, 256) + (advance ? 1 : 0)), 2);
+  if (id_type == BR_IDS_I32) chunk_rank_kernel<int32_t, kChunkL><<<g2, 256, 0, s>>>(jobs, nmax, ca > cb ? ca : cb, av);
+  else chunk_rank_kernel<int64_t, kChunkL><<<g2, 256, 0, s>>>(jobs, nmax, ca > cb ? ca : cb, av);
+  BR_CHECK_LAUNCH("brGatherRowsDeferredPairWithIndex(rank)");
   return BR_OK;
 }
 

@@ -122,6 +122,25 @@ def gather_rows_deferred_pair(tab_a, m_a, v_a, last_a, ids_a, out_a, tab_b, m_b,
     return out_a, out_b
 
 
+def gather_rows_deferred_pair_with_index(tab_a, m_a, v_a, last_a, ids_a, out_a, idx_a: "RowIndex", tab_b, m_b, v_b, last_b, ids_b, out_b, idx_b: "RowIndex",
+                                         step_state, lr, beta1=0.9, beta2=0.999, eps=1e-7, advance=True, err_flag=None):
+    """gather_rows_deferred_pair + both dedup indexes (+ the step-state advance) in two launches on one stream
+    (brGatherRowsDeferredPairWithIndex): the chunk sorts ride in the gather's launch."""
+    ta, ty = _ids(ids_a, "ids_a"); tb, tyb = _ids(ids_b, "ids_b")
+    na, nb, dim = ta.shape[0], tb.shape[0], tab_a.shape[1]
+    if ty != tyb or ty != idx_a.id_type or ty != idx_b.id_type or tab_b.shape[1] != dim or out_a.stride(0) != out_b.stride(0) or na > idx_a.capacity or nb > idx_b.capacity:
+        raise ValueError("gather_rows_deferred_pair_with_index: id type / dim / stride / capacity mismatch")
+    idx_a.n, idx_b.n = na, nb
+    check(_lib.load().brGatherRowsDeferredPairWithIndex(
+        _f32(tab_a, "table_a").data_ptr(), m_a.data_ptr(), v_a.data_ptr(), last_a.data_ptr(), tab_a.shape[0], ta.data_ptr(), _f32(out_a, "out_a").data_ptr(),
+        idx_a.sorted_ids.data_ptr(), idx_a.sorted_pos.data_ptr(), idx_a.ws.data_ptr(), idx_a.ws_bytes,
+        _f32(tab_b, "table_b").data_ptr(), m_b.data_ptr(), v_b.data_ptr(), last_b.data_ptr(), tab_b.shape[0], tb.data_ptr(), _f32(out_b, "out_b").data_ptr(),
+        idx_b.sorted_ids.data_ptr(), idx_b.sorted_pos.data_ptr(), idx_b.ws.data_ptr(), idx_b.ws_bytes,
+        dim, ty, na, nb, step_state.data_ptr(), 1 if advance else 0, float(lr), beta1, beta2, eps, out_a.stride(0), _p(err_flag), _stream()),
+        "brGatherRowsDeferredPairWithIndex")
+    return out_a, out_b
+
+
 def adam_rows_sorted_deferred(table, m, v, last, index, row_grads, ldg, step_state, beta1=0.9, beta2=0.999, eps=1e-7,
                               row_grads_hi=None, ldg_hi=0, split=0, replayed=None):
     """replayed: (n, >= dim) rows as this step's gather_rows_deferred wrote them, aligned with the positions the index was built

@@ -580,6 +580,17 @@ int brGatherRowsDeferredPair(const float* table_a, const float* m_a, const float
                              float* out_a, const float* table_b, const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b,
                              const void* ids_b, float* out_b, int dim, int id_type, int64_t n, int64_t n_b, const void* step_state, double beta1,
                              double beta2, double eps, int64_t ld_out, int* err_flag, brStream stream);
+/* brGatherRowsDeferredPair AND both dedup indexes of the step (brRowIndexBuild of ids_a over n_a, of ids_b over n_b) in two launches on
+ * one stream: the chunk sorts of the two id streams run as workgroups of the gather's own launch, the chunk-rank launch follows.
+ * advance != 0: the step state is advanced (brStepStateAdvance with lr) by that second launch - the gather then computes the step as
+ * step + 1 - so a BPR step (src/models/BPRModel.py:49-74: user gather of B rows, [pos | neg] gather of 2 B rows of the shared item
+ * table) needs no launch of its own for it and no side stream for its sorts.  Rows of 64 / 128 / 256 floats, n <= 524 288 per stream. */
+int brGatherRowsDeferredPairWithIndex(const float* table_a, const float* m_a, const float* v_a, const int32_t* last_a, int64_t rows_a, const void* ids_a,
+                                      float* out_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes, const float* table_b,
+                                      const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b, const void* ids_b, float* out_b,
+                                      void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes, int dim, int id_type, int64_t n_a, int64_t n_b,
+                                      void* step_state, int advance, double lr, double beta1, double beta2, double eps, int64_t ld_out, int* err_flag,
+                                      brStream stream);
 /* B1 of the GMF dot on the MF rows the deferred forward stashed, in place: (u_b, i_b) -> (ddot_b i_b, ddot_b u_b). */
 int brMfGradInplace(float* stash_user, float* stash_item, int64_t ld, const float* ddot, int64_t batch, int dim, brStream stream);
 int brAdamRowsSortedDeferred(float* table, float* m, float* v, int32_t* last, int64_t table_rows, int dim,

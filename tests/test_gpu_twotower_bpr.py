@@ -260,6 +260,64 @@ def test_bpr_graph_replay_equals_eager(dev):
     assert abs(a.pop_loss() - b.pop_loss()) < 1e-9
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_bpr_fused_gather_sort_step_equals_the_side_stream_step(dev, graph):
+    """Batches >= 1024 at 64 / 128 / 256 factors take the five-launch step (brGatherRowsDeferredPairWithIndex: the chunk sorts of the user
+    stream (B ids) and the [pos | neg] stream (2 B ids) ride in the gather's launch, the chunk-rank launch advances the step state behind
+    it; no side stream).  Against the same engine with BR_FUSED_SORT=0 (step-state launch, indexes on two side streams, plain pair gather):
+    tables, moments and last[] bit for bit over steps with lags, hot ids, a ragged batch and, optionally, the hipGraph replay."""
+    bpr = _m("bpr")
+    g = torch.Generator().manual_seed(12)
+    U, I, F, B = 20000, 3000, 64, 4096
+    a = bpr.BPREngine(U, I, F, dev, B, init_seed=7)
+    b = bpr.BPREngine(U, I, F, dev, B, init_seed=7)
+    draw = lambda N, n=B: torch.randint(0, N, (n,), generator=g).int().to(dev)
+    if graph:
+        a.enable_graph(B)
+    for t in range(6):
+        nb = 3000 if t == 2 else B
+        u, p, n = draw(U, nb), draw(I, nb), draw(I, nb)
+        u[:500] = 11; p[:300] = 5; n[:100] = 5                   # hot rows: runs that cross strips and 64-blocks; an id that is positive and negative
+        a.train_step(u, p, n)
+        os.environ["BR_FUSED_SORT"] = "0"
+        try:
+            b.train_step(u, p, n)
+        finally:
+            del os.environ["BR_FUSED_SORT"]
+    torch.cuda.synchronize()
+    a.check_ids(); b.check_ids()
+    assert a.t == b.t == 6 and int(a.step_state[0].item()) == int(b.step_state[0].item()) == 6
+    for k in ("_user", "_item", "user_m", "user_v", "item_m", "item_v", "user_last", "item_last"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert abs(a.pop_loss() - b.pop_loss()) < 1e-9
+
+
+@pytest.mark.parametrize("rd_zero", [False, True])
+def test_twotower_graph_replay_equals_eager(dev, rd_zero):
+    """TwoTowerEngine.enable_graph: the step as one hipGraph (dedup indexes on forked side streams inside the capture) == the eager launches,
+    incl. a ragged batch in between that falls back to the eager path."""
+    tt = _m("two_tower")
+    g = torch.Generator().manual_seed(8)
+    U, I, E, S, B = 900, 300, 24, 16, 256
+    a = tt.TwoTowerEngine(E, I, U, S, dev, B, rd_zero=rd_zero, init_seed=2)
+    b = tt.TwoTowerEngine(E, I, U, S, dev, B, rd_zero=rd_zero, init_seed=2)
+    draw = lambda N, n=B: (torch.randint(0, N, (n,), generator=g) + 2).int().to(dev)
+    lab = lambda n=B: (torch.rand(n, generator=g) < 0.4).float().to(dev)
+    a.enable_graph(B)
+    for t in range(7):
+        nb = 100 if t == 4 else B
+        u, i, y = draw(U, nb), draw(I, nb), lab(nb)
+        u[:9] = u[0]                                                 # duplicate ids in both streams
+        a.train_step(u, i, y); b.train_step(u, i, y)
+    torch.cuda.synchronize()
+    a.check_ids(); b.check_ids()
+    assert a._graph["graph"] is not None and a.t == b.t == 7
+    for k in ("user_emb", "item_emb", "theta", "user_acc", "theta_acc"):
+        np.testing.assert_allclose(getattr(a, k).cpu().numpy(), getattr(b, k).cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+    la, lb = a.pop_loss(), b.pop_loss()
+    assert abs(la - lb) <= 1e-6 * abs(lb)
+
+
 def test_topk_ties_and_scores(dev):
     ops = _m("ops")
     z = np.load(os.path.join(GOLD, "topk_ties.npz"), allow_pickle=False)
