@@ -3,8 +3,52 @@
 #pragma once
 #include "common.h"
 #include "philox.h"
+#include <stdlib.h>
 
 namespace br {
+
+// ---- fp32 products on the bf16 matrix pipe ("bf16x6") -------------------------------------------------------------------------------
+// The tower's GEMMs are fp32 (the 1e-5 bar on logits forbids bf16 DATA), and v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 MFMA rate.
+// An fp32 number is the exact sum of three bf16 pieces, x = h + m + l (8 + 8 + 8 significant bits; |x - h - m - l| <= 2^-24 |x|), and a
+// product of two bf16 numbers is exact in fp32.  x w = hh + (hm + mh) + (hl + lh + mm) + O(2^-24): six v_mfma_f32_16x16x32_bf16 per
+// 32-deep k-block (96 matrix-pipe cycles) replace eight fp32 MFMAs (256 cycles).  The dropped terms (ml, lm, ll and the split residuals)
+// are <= 4 x 2^-24 of each product - measured on the layer shapes 4e-9 of sum |x w| against 2.5e-7 for a 128-term fp32 fma chain
+// (whose one rounding per term dominates: the bf16 path rounds once per six products of a 32-deep block) - so the result is at least
+// as close to the real-number product as the exact-fp32 MFMA's.  BR_MLP_MATH=f32 selects that path instead (A/B runs, tests).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// (x0, x1) -> three packed bf16 pairs (x0 in the low half): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 hh = {(__bf16)x0, (__bf16)x1};
+  const float r0 = x0 - (float)hh.x, r1 = x1 - (float)hh.y;
+  const bf2 mm = {(__bf16)r0, (__bf16)r1};
+  const float s0 = r0 - (float)mm.x, s1 = r1 - (float)mm.y;
+  const bf2 ll = {(__bf16)s0, (__bf16)s1};
+  h = __builtin_bit_cast(uint32_t, hh); m = __builtin_bit_cast(uint32_t, mm); l = __builtin_bit_cast(uint32_t, ll);
+}
+__device__ __forceinline__ bf16x8 frag8(const uint32_t (&p)[4]) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 v = {p[0], p[1], p[2], p[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 frag8(const float4& q) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = {q.x, q.y, q.z, q.w};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f32x4_t mfma_bf16(bf16x8 a, bf16x8 b, f32x4_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+  return c;      // host pass of the single-source compile: never called
+#endif
+}
+// 1: bf16x6 (default), 0: exact fp32 MFMA (BR_MLP_MATH=f32)
+static inline bool mlp_bf16x6() {
+  static const bool on = [] { const char* e = getenv("BR_MLP_MATH"); return !(e && e[0] == 'f'); }();
+  return on;
+}
 
 struct BwdArgs {
   const float* gy; int64_t ldgy;

@@ -44,6 +44,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ------------------------------------------------------------------------------ fp32 products on the bf16 matrix pipe
+// (BR_MLP_MATH, dense.h split3 / mfma_bf16: x = h + m + l in three bf16 pieces, x w = hh + hm + mh + hl + lh + mm - six
+//  v_mfma_f32_16x16x32_bf16 per 32-deep k-block and n-tile = 96 matrix-pipe cycles where eight v_mfma_f32_16x16x4_f32 take 256.)
+
 // ------------------------------------------------------------------------------ keep-bit planes
 // (KeepSite / KeepArgs / keep_bits_block: philox.h - the optimizer launch can carry the planes of the next step in its own grid)
 __global__ __launch_bounds__(256) void keep_bits_kernel(KeepArgs a) {
@@ -208,13 +212,16 @@ __device__ __forceinline__ void fwd_epilogue_multi(const f32x4 (&acc)[4], const 
 // same time, the matrix pipe idles through the two memory phases) or 2 (half the waves, two tiles each, the second tile's loads
 // issued before the first tile's MFMA passes and the first tile's stores behind them: the memory phases of one tile overlap the
 // MFMA phase of the other)
-template <int NT, int KJ, bool VEC, int WPS>
+template <int NT, int KJ, bool VEC, int WPS, bool EMU>
 __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kFwdThreads = 256 * WPS, kFwdWaves = 4 * WPS;
   constexpr int Np = NT * 16, Kp = KJ * 16, KWJ = (KJ + 1) / 2;
-  float* Ws = smem;                                     // [KJ][4][Np][4]
-  float* ssb = Ws + Kp * Np;                            // [scale Kp | shift Kp]
+  constexpr int KB = (KJ + 1) / 2;                      // 32-deep k-blocks of the bf16 path
+  // W image.  fp32 path: [KJ][4][Np][4] floats.  bf16 path: [KB][3 pieces][4 g][Np][8 bf16] = KB * 3 * 4 * Np * 16 bytes (1.5 x the fp32 image)
+  constexpr int kWsFloats = EMU ? KB * 3 * 4 * Np * 4 : Kp * Np;
+  float* Ws = smem;
+  float* ssb = Ws + kWsFloats;                          // [scale Kp | shift Kp]
   float* bs = ssb + 2 * Kp;                             // [bias Np]
   float* patches = bs + Np;                             // [waves][16][kPatchLd]
   constexpr int kPatchesPerWave = WPS == 2 ? 4 : 1;
@@ -241,6 +248,45 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
   fwd_load_tile<KJ, VEC>(av, kb, a, tile, c16, g);      // the first tile's loads fly while W is staged (row clamped)
   BR_STAMP(1);
 
+  if constexpr (EMU) {
+    // bf16 image: thread -> (J, g, n): the 8 k-values a lane's fragment of k-block J holds (k = 32J + 16(i >> 2) + 4g + (i & 3): the
+    // columns of the two float4 A loads of 16-column blocks 2J and 2J+1), split into three bf16 pieces, one 16-B LDS write per piece
+    constexpr int TOT = KB * 4 * Np, TR = (TOT + kFwdThreads - 1) / kFwdThreads;
+    float wv[TR][8];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kFwdThreads;
+      const int idc = idx < TOT ? idx : 0;
+      const int Jg = idc / Np, n = idc - Jg * Np;
+      const int J = Jg >> 2, gg = Jg & 3;
+      const int nc = n < N ? n : N - 1;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 32 * J + 16 * (q >> 2) + 4 * gg + (q & 3);
+        wv[i][q] = a.W[(k < K ? k : K - 1) * N + nc];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int idx = threadIdx.x + i * kFwdThreads;
+      const int Jg = idx / Np, n = idx - Jg * Np;
+      const int J = Jg >> 2, gg = Jg & 3;
+      uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k0 = 32 * J + 16 * (q >> 1) + 4 * gg + 2 * (q & 1);
+        const float w0 = (n < N && k0 < K) ? wv[i][2 * q] : 0.f, w1 = (n < N && k0 + 1 < K) ? wv[i][2 * q + 1] : 0.f;
+        split3(w0, w1, ph[q], pm[q], pl[q]);
+      }
+      if (idx < TOT) {
+        uint32_t* wsu = reinterpret_cast<uint32_t*>(Ws);
+        *reinterpret_cast<uint4*>(wsu + ((((J * 3 + 0) * 4 + gg) * Np + n) << 2)) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        *reinterpret_cast<uint4*>(wsu + ((((J * 3 + 1) * 4 + gg) * Np + n) << 2)) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        *reinterpret_cast<uint4*>(wsu + ((((J * 3 + 2) * 4 + gg) * Np + n) << 2)) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
   // W image: thread -> (j, g, n): 4 coalesced loads (k = 16j+4g+s) -> one conflict-free ds_write_b128.  All loads of the
   // image are issued before the first LDS write (compile-time trip count, clamped addresses).
   {
@@ -340,6 +386,30 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
     uint32_t kbn[WPS == 2 ? KWJ : 1];
     const bool has_next = tile + tstride < n_tiles;                        // wave-uniform
     if (WPS == 2 && has_next) fwd_load_tile<KJ, VEC>(reinterpret_cast<float4 (&)[KJ]>(avn), reinterpret_cast<uint32_t (&)[KWJ]>(kbn), a, tile + tstride, c16, g);
+    // bf16 path: the transformed operands split once per tile into three bf16 pieces (h + m + l = x to 2^-24), packed as the A
+    // fragments of the 32-deep k-blocks: elements 0-3 from 16-column block 2J, 4-7 from block 2J+1 (zeros past KJ)
+    // WPS == 2 (256 VGPRs): all k-blocks split here, once per tile.  WPS == 4 (128 VGPRs): 48 registers of pieces do not fit beside the
+    // accumulators and fragments - each k-block is split where it is used, once per pass (NT > 4: twice per tile).
+    constexpr bool PRESPLIT = EMU && WPS == 2;
+    uint32_t ah[PRESPLIT ? KB : 1][4], am[PRESPLIT ? KB : 1][4], al[PRESPLIT ? KB : 1][4];
+    auto split_block = [&](int J, uint32_t (&h)[4], uint32_t (&m)[4], uint32_t (&l)[4]) {
+      const int j1 = 2 * J + 1 < KJ ? 2 * J + 1 : 0;
+      split3(av[2 * J].x, av[2 * J].y, h[0], m[0], l[0]);
+      split3(av[2 * J].z, av[2 * J].w, h[1], m[1], l[1]);
+      if (2 * J + 1 < KJ) {
+        split3(av[j1].x, av[j1].y, h[2], m[2], l[2]);
+        split3(av[j1].z, av[j1].w, h[3], m[3], l[3]);
+      } else {
+        h[2] = h[3] = m[2] = m[3] = l[2] = l[3] = 0u;
+      }
+    };
+    if constexpr (PRESPLIT) {
+#pragma unroll
+      for (int J = 0; J < KB; ++J) {
+        split_block(J, ah[J], am[J], al[J]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     // ---- MFMA in passes of <= 4 n-tiles: 4 independent accumulator chains, each revisited every 4th MFMA ----
 #pragma unroll
     for (int nt0 = 0; nt0 < NT; nt0 += 4) {
@@ -348,6 +418,44 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
       f32x4 acc[WMAX];
 #pragma unroll
       for (int w = 0; w < WMAX; ++w) acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (EMU) {
+        // per k-block and n-tile: three 16-B B fragments (h, m, l) and six products, the small ones first: l h, h l, m m, m h, h m, h h.
+        // The fragments of step (J, w) + 1 are requested before the six MFMAs of step (J, w) (two buffers of 12 VGPRs; the fence
+        // after every step keeps hipcc from hoisting a whole k-block's 48 fragment registers, which spilled the A pieces).
+        // (read as float4, the type the epilogue's patch stores use: a uint4 view lets type-based alias analysis hoist every fragment
+        //  read of the image out of the tile loop - 336 VGPRs of "loop invariants")
+        float4 bq[2][3];
+        // one per-lane base + compile-time offsets (which fold into the ds_read immediates): left as (..g..) * Np + n, hipcc keeps one
+        // address VGPR per fragment
+        const float* wl_ = Ws + ((g * Np + c16) << 2);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const float4*>(wl_ + (((0 * 3 + p) * 4 * Np + nt0 * 16) << 2));
+#pragma unroll
+        for (int J = 0; J < KB; ++J) {
+          uint32_t th[4], tm[4], tl[4];
+          if constexpr (!PRESPLIT) { split_block(J, th, tm, tl); __builtin_amdgcn_sched_barrier(0); }
+          const bf16x8 xh = frag8(PRESPLIT ? ah[J] : th), xm = frag8(PRESPLIT ? am[J] : tm), xl = frag8(PRESPLIT ? al[J] : tl);
+#pragma unroll
+          for (int w = 0; w < WMAX; ++w) {
+            if (w < Wn) {
+              const int st = J * Wn + w, cur = st & 1;
+              const int Jn = (w + 1 < Wn) ? J : J + 1, wn = (w + 1 < Wn) ? w + 1 : 0;
+              if (Jn < KB) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bq[cur ^ 1][p] = *reinterpret_cast<const float4*>(wl_ + (((Jn * 3 + p) * 4 * Np + (nt0 + wn) * 16) << 2));
+              }
+              const bf16x8 wh = frag8(bq[cur][0]), wm = frag8(bq[cur][1]), wl = frag8(bq[cur][2]);
+              acc[w] = mfma_bf16(xl, wh, acc[w]);
+              acc[w] = mfma_bf16(xh, wl, acc[w]);
+              acc[w] = mfma_bf16(xm, wm, acc[w]);
+              acc[w] = mfma_bf16(xm, wh, acc[w]);
+              acc[w] = mfma_bf16(xh, wm, acc[w]);
+              acc[w] = mfma_bf16(xh, wh, acc[w]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      } else
       // One k-block at a time: 4 B fragments (ds_read_b128), then their 16 MFMAs.  No double buffer: while this wave waits for
       // its fragments the lower-priority waves of the SIMD own the matrix pipe, and 16 more VGPRs of fragments do not fit the
       // 128-VGPR budget.  The fence keeps hipcc from hoisting every block's reads to the top of the pass (~200 spills).
@@ -466,14 +574,14 @@ int br::dropout_keep_bits_ahead(float drop_p, uint64_t seed, uint32_t step, uint
   return BR_OK;
 }
 
-template <int NT, int KJ, bool VEC, int WPS>
+template <int NT, int KJ, bool VEC, int WPS, bool EMU>
 static void launch_fwd_v(unsigned grid, size_t shmem, hipStream_t s, const FwdArgs& a) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ, VEC, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    (void)hipFuncSetAttribute((const void*)dense_fwd_kernel<NT, KJ, VEC, WPS, EMU>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  dense_fwd_kernel<NT, KJ, VEC, WPS><<<grid, 256 * WPS, shmem, s>>>(a);
+  dense_fwd_kernel<NT, KJ, VEC, WPS, EMU><<<grid, 256 * WPS, shmem, s>>>(a);
 }
 // waves per SIMD of a forward launch: 2 (two tiles per wave, software-pipelined) once every wave of a one-workgroup-per-CU grid would
 // get two tiles anyway, else 4 (one tile per wave, more waves to hide latency); BR_FWD_WPS=2|4 forces one (experiments)
@@ -487,7 +595,7 @@ static int fwd_wps(int64_t batch, bool vec, int KJ) {
 }
 
 template <int NT, int KJ>
-static void launch_fwd(size_t shmem_words_fixed, int Np, hipStream_t s, const FwdArgs& a) {
+static void launch_fwd(size_t shmem_words_fixed, int Np, hipStream_t s, const FwdArgs& a, bool emu) {
   // VEC: 16-B accesses on both sides: x rows / y rows 16-B aligned with row strides that are multiples of 4 floats (rows of K
   // or N floats are then padded to 4, and a 16-B access that starts inside a row stays inside its allocation)
   const bool vec = (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
@@ -497,15 +605,23 @@ static void launch_fwd(size_t shmem_words_fixed, int Np, hipStream_t s, const Fw
   const size_t shmem = (shmem_words_fixed + (size_t)waves * (wps == 2 ? 4 : 1) * 16 * kPatchLd + (size_t)waves * 2 * Np) * sizeof(float);
   const int64_t wgs = ceil_div(ceil_div(a.batch, (int64_t)16), (int64_t)waves);
   const unsigned grid = (unsigned)(wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs));      // one workgroup per CU
-  if (vec && wps == 2) launch_fwd_v<NT, KJ, true, 2>(grid, shmem, s, a);
-  else if (vec) launch_fwd_v<NT, KJ, true, 4>(grid, shmem, s, a);
-  else launch_fwd_v<NT, KJ, false, 4>(grid, shmem, s, a);
+  if (emu) {
+    if (vec && wps == 2) launch_fwd_v<NT, KJ, true, 2, true>(grid, shmem, s, a);
+    else if (vec) launch_fwd_v<NT, KJ, true, 4, true>(grid, shmem, s, a);
+    else launch_fwd_v<NT, KJ, false, 4, true>(grid, shmem, s, a);
+    return;
+  }
+  if (vec && wps == 2) launch_fwd_v<NT, KJ, true, 2, false>(grid, shmem, s, a);
+  else if (vec) launch_fwd_v<NT, KJ, true, 4, false>(grid, shmem, s, a);
+  else launch_fwd_v<NT, KJ, false, 4, false>(grid, shmem, s, a);
 }
 
 static int dense_forward_one(FwdArgs a, hipStream_t s) {
   const int NT = tiles16(a.N), KJ = tiles16(a.K), Kp = KJ * 16, Np = NT * 16;
-  const size_t fixed = (size_t)Kp * Np + 2 * (size_t)Kp + (size_t)Np;           // W image, affine, bias (floats); + per-wave patches / sums
-#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(fixed, Np, s, a); break;
+  const bool emu = br::mlp_bf16x6();
+  const size_t wimg = emu ? (size_t)((KJ + 1) / 2) * 3 * 4 * Np * 4 : (size_t)Kp * Np;      // W image in floats: bf16x6 keeps three bf16 pieces per element
+  const size_t fixed = wimg + 2 * (size_t)Kp + (size_t)Np;                      // W image, affine, bias (floats); + per-wave patches / sums
+#define BR_FWD_KJ(NTv, KJv) case KJv: launch_fwd<NTv, KJv>(fixed, Np, s, a, emu); break;
 #define BR_FWD(NTv)                                                                                        \
   case NTv:                                                                                                \
     switch (KJ) { BR_FWD_KJ(NTv, 1) BR_FWD_KJ(NTv, 2) BR_FWD_KJ(NTv, 3) BR_FWD_KJ(NTv, 4) BR_FWD_KJ(NTv, 5) \
