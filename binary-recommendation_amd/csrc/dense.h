@@ -19,13 +19,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // (x0, x1) -> three packed bf16 pairs (x0 in the low half): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even
 __device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  // written so that hipcc emits 11 VALU ops per pair (v_cvt_pk_bf16_f32, two bit ops to widen the pieces back, v_pk_add_f32); through
+  // (float)(__bf16) round trips it emitted 15
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  const bf2 hh = {(__bf16)x0, (__bf16)x1};
-  const float r0 = x0 - (float)hh.x, r1 = x1 - (float)hh.y;
-  const bf2 mm = {(__bf16)r0, (__bf16)r1};
-  const float s0 = r0 - (float)mm.x, s1 = r1 - (float)mm.y;
-  const bf2 ll = {(__bf16)s0, (__bf16)s1};
-  h = __builtin_bit_cast(uint32_t, hh); m = __builtin_bit_cast(uint32_t, mm); l = __builtin_bit_cast(uint32_t, ll);
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 x = {x0, x1};
+  h = __builtin_bit_cast(uint32_t, (bf2){(__bf16)x.x, (__bf16)x.y});
+  const f2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+  const f2 r = x - hf;
+  m = __builtin_bit_cast(uint32_t, (bf2){(__bf16)r.x, (__bf16)r.y});
+  const f2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+  const f2 t = r - mf;
+  l = __builtin_bit_cast(uint32_t, (bf2){(__bf16)t.x, (__bf16)t.y});
 }
 __device__ __forceinline__ bf16x8 frag8(const uint32_t (&p)[4]) {
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));

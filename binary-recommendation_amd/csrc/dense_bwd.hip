@@ -49,18 +49,48 @@ __device__ __forceinline__ float keep_bit(float x, uint32_t w, uint32_t pos) {  
 // k-step: the same XOR for every lane) stay conflict-free.
 __device__ __forceinline__ int bwd_swz(int col16, int row_quad) { return (((col16 >> 2) ^ (row_quad & 3)) << 2) | (col16 & 3); }
 
-template <int NT, int KT, bool IBN>
-__global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs a) {
+// EMU ("bf16x6", dense.h): every fp32 product runs as six bf16 MFMAs on three-piece operands, and every operand is split ONCE:
+//   W   -> Wp[n-block J][piece][g][k][8 bf16] in LDS at staging (B fragments of the dx product, 16 B per lane; an odd last n-tile is a
+//          half block of 8 B).  1.5 x the fp32 image.
+//   dz  -> split by the dx wave that formed it: packed along n in registers (its own A fragments), and published element by element
+//          (ds_write_b16) as Zp[n-tile][32-row block b][piece][g][n16][8 bf16]: the dW waves' B fragments, element i <-> row 32b + 4i + g.
+//          Single-buffered (the LDS is full): barrier B_t "the dW waves are done with dz(t-1)" in front of the publish, A_t "dz(t) is
+//          visible" behind it.
+//   T(x)-> the dW wave loads its 32 columns as the fp32 kernel does (full 128-B lines, one tile ahead), transforms, turns one 32-row block at a
+//          time through a private 4 KB LDS patch into the A layout (lane (c16, g) <- rows 32b + 4i + g of column c16) and splits in
+//          registers.  (Loading x straight in the A layout - 32 dword loads of 4 rows x 64 B per tile and wave - clogged the CU's address
+//          pipe: the dx waves' loads behind them took 3.5 x as long, 62 us for the layer instead of 53.)
+//   db  -> ones^T dz: three more MFMAs (A = 1.0) per fragment on the dW wave that owns the n-tile (nt mod 4).
+// The dz arithmetic, the dx epilogue and the slab layout are the fp32 kernel's, line for line.
+template <int NT, int KT>
+constexpr size_t bwd_emu_wp_floats() { return (size_t)(NT / 2) * 3 * 4 * (KT * 16) * 4 + (size_t)(NT & 1) * 3 * 4 * (KT * 16) * 2; }
+constexpr int kZpTile = 2 * 3 * 4 * 16 * 4;               // floats of one n-tile of Zp (6 KB)
+constexpr size_t bwd_emu_lds(int NT, int KT) {
+  const size_t Np = NT * 16, Kp = KT * 16;
+  return sizeof(float) * ((size_t)(NT / 2) * 3 * 4 * Kp * 4 + (size_t)(NT & 1) * 3 * 4 * Kp * 2 + 4 * Np + 4 * Kp + (size_t)NT * kZpTile +
+                          4 * 2 * 32 * 16 + 4 * 16 * (size_t)kBwdPatchLd) + sizeof(double) * 2 * Kp;
+}
+constexpr bool bwd_emu_fits(int NT, int KT) { return bwd_emu_lds(NT, KT) <= 160 * 1024; }
+constexpr int bwd_emu_chunks(int Kp, int ldw, int room) {      // fewest chunks of rows whose [rows][ldw] image fits in `room` floats
+  int n = 1;
+  while (((Kp + n - 1) / n) * ldw > room) ++n;
+  return n;
+}
+
+template <int NT, int KT, bool IBN, bool EMU>
+__global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int Np = NT * 16, Kp = KT * 16, ldw = Np + 4;
   constexpr int KW = (KT + 1) / 2;                      // keep words per row
-  float* Ws = smem;                                     // [Kp][ldw]   W row-major, zero padded
-  float* Cs = Ws + Kp * ldw;                            // [4][Np]     out-BN constants
+  constexpr int NBF = NT / 2, NB = (NT + 1) / 2;        // full 32-deep n-blocks of the dx product / all of them (an odd NT ends in a half block)
+  constexpr int kWsFloats = EMU ? (int)bwd_emu_wp_floats<NT, KT>() : Kp * ldw;
+  float* Ws = smem;                                     // fp32: [Kp][ldw] W row-major, zero padded.  EMU: the piece image Wp
+  float* Cs = Ws + kWsFloats;                           // [4][Np]     out-BN constants
   float* Is = Cs + 4 * Np;                              // [mean Kp | rstd Kp] of the in BN
   float* ssb = Is + 2 * Kp;                             // [scale Kp | shift Kp]
-  float* Zs = ssb + 2 * Kp;                             // [2][NT][64][16]  dz
-  float* Xs = Zs + 2 * NT * kBwdRows * 16;              // [4 dW waves][2][64][16]  T(x)
-  float* patches = Xs + 4 * 2 * kBwdRows * 16;          // [4 dx waves][16][kBwdPatchLd]
+  float* Zs = ssb + 2 * Kp;                             // [2][NT][64][16]  dz.  EMU: Zp, [NT] tiles of kZpTile floats
+  float* Xs = Zs + (EMU ? NT * kZpTile : 2 * NT * kBwdRows * 16);      // [4 dW waves][2][64][16]  T(x).  EMU: [4][2][32][16], a transposition patch
+  float* patches = Xs + 4 * 2 * (EMU ? 32 : kBwdRows) * 16;     // [4 dx waves][16][kBwdPatchLd]   (EMU: Xs holds one 32-row block per dW wave)
   double* red = reinterpret_cast<double*>(patches + 4 * 16 * kBwdPatchLd);    // [2][Kp]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
@@ -125,15 +155,52 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           wv[i] = make_float4(wr[n < N ? n : 0], wr[n + 1 < N ? n + 1 : 0], wr[n + 2 < N ? n + 2 : 0], wr[n + 3 < N ? n + 3 : 0]);
         }
       }
+      // EMU: the fp32 rows pass through the (still unused) Zp region in NCH chunks of KCH rows; after each chunk thread -> (J, g, k) reads the
+      // 8 n-values of a lane's B fragment (n = 32J + 16(i >> 2) + 4g + (i & 3): the columns of the dx waves' float4 registers dz[2J],
+      // dz[2J+1]), splits them and writes the pieces to Wp.  Both roles run stage(): the barriers below are workgroup-wide.
+      constexpr int NCH = EMU ? bwd_emu_chunks(Kp, ldw, NT * kZpTile) : 1, KCH = (Kp + NCH - 1) / NCH;
   #pragma unroll
-      for (int i = 0; i < TR; ++i) {
-        const int idx = threadIdx.x + i * kBwdThreads;
-        const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
-        const int kin = k < K ? -1 : 0;
-        const int m0 = kin & (n < N ? -1 : 0), m1 = kin & (n + 1 < N ? -1 : 0), m2 = kin & (n + 2 < N ? -1 : 0), m3 = kin & (n + 3 < N ? -1 : 0);
-        const float4 w = make_float4(__int_as_float(__float_as_int(wv[i].x) & m0), __int_as_float(__float_as_int(wv[i].y) & m1),
-                                     __int_as_float(__float_as_int(wv[i].z) & m2), __int_as_float(__float_as_int(wv[i].w) & m3));
-        if (idx < TOT) *reinterpret_cast<float4*>(Ws + k * ldw + n) = w;
+      for (int c = 0; c < NCH; ++c) {
+  #pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const int idx = threadIdx.x + i * kBwdThreads;
+          const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
+          const int kin = k < K ? -1 : 0;
+          const int m0 = kin & (n < N ? -1 : 0), m1 = kin & (n + 1 < N ? -1 : 0), m2 = kin & (n + 2 < N ? -1 : 0), m3 = kin & (n + 3 < N ? -1 : 0);
+          const float4 w = make_float4(__int_as_float(__float_as_int(wv[i].x) & m0), __int_as_float(__float_as_int(wv[i].y) & m1),
+                                       __int_as_float(__float_as_int(wv[i].z) & m2), __int_as_float(__float_as_int(wv[i].w) & m3));
+          if constexpr (EMU) {
+            if (idx < TOT && k >= c * KCH && k < (c + 1) * KCH) *reinterpret_cast<float4*>(Zs + (k - c * KCH) * ldw + n) = w;
+          } else {
+            if (idx < TOT) *reinterpret_cast<float4*>(Ws + k * ldw + n) = w;
+          }
+        }
+        if constexpr (EMU) {
+          __syncthreads();
+          constexpr int TOTP = NB * 4 * KCH;
+          for (int idx = threadIdx.x; idx < TOTP; idx += kBwdThreads) {
+            const int kc = idx % KCH, Jg = idx / KCH, J = Jg >> 2, gg = Jg & 3, k = c * KCH + kc;
+            if (k >= Kp) continue;
+            const float4 lo = *reinterpret_cast<const float4*>(Zs + kc * ldw + 32 * J + 4 * gg);
+            const bool full = J < NBF;
+            const float4 hi = full ? *reinterpret_cast<const float4*>(Zs + kc * ldw + 32 * J + 16 + 4 * gg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t ph[4], pm[4], pl[4];
+            split3(lo.x, lo.y, ph[0], pm[0], pl[0]); split3(lo.z, lo.w, ph[1], pm[1], pl[1]);
+            split3(hi.x, hi.y, ph[2], pm[2], pl[2]); split3(hi.z, hi.w, ph[3], pm[3], pl[3]);
+            if (full) {
+              float* d = Ws + (((J * 3 * 4 + gg) * Kp + k) << 2);
+              *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+              *reinterpret_cast<uint4*>(d + 4 * Kp * 4) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+              *reinterpret_cast<uint4*>(d + 2 * 4 * Kp * 4) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            } else {
+              float* d = Ws + NBF * 3 * 4 * Kp * 4 + ((gg * Kp + k) << 1);
+              *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
+              *reinterpret_cast<uint2*>(d + 4 * Kp * 2) = make_uint2(pm[0], pm[1]);
+              *reinterpret_cast<uint2*>(d + 2 * 4 * Kp * 2) = make_uint2(pl[0], pl[1]);
+            }
+          }
+          __syncthreads();
+        }
       }
     }
 
@@ -155,9 +222,15 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
       py_n = a.y + row * a.ldy + 4 * g;
     };
     auto load_gy_j = [&](int j) {                        // A layout: lane (c16,g) <- row c16, columns 16j+4g..+3
-      const bool in = 16 * j + 16 <= N || 16 * j + 4 * g < N;          // the 16-B group starts inside N (rows are padded to 4 floats)
-      vg[j] = *reinterpret_cast<const float4*>(in ? pg_n + 16 * j : pg_n - 4 * g);
-      vy[j] = *reinterpret_cast<const float4*>(in ? py_n + 16 * j : py_n - 4 * g);
+      // the 16-B group starts inside N (rows are padded to 4 floats).  Only the last n-tile can straddle N (N > 16 (NT - 1)): written with
+      // the runtime test 16j + 16 <= N for every j, hipcc kept one 64-bit select per j alive across the tile loop, spilled them, and
+      // reloaded each one - s_waitcnt vmcnt(0) - right behind the previous prefetch load: every load of the next tile waited for the one before
+      int g4 = 4 * g;
+      if (j == NT - 1) asm volatile("" : "+v"(g4));          // (opaque: the select below is recomputed per tile - two VALU ops - instead of hoisted and spilled)
+      const bool in = j < NT - 1 || 16 * j + g4 < N;
+      const int off = in ? 16 * j : -g4;
+      vg[j] = *reinterpret_cast<const float4*>(pg_n + off);
+      vy[j] = *reinterpret_cast<const float4*>(py_n + off);
     };
     auto load_gy = [&](int64_t tile) {
       gy_rows(tile);
@@ -178,7 +251,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
     for (; tile < n_tiles; tile += gridDim.x, ++it) {
       const int64_t rbase = tile * kBwdRows + rt * 16;
       const bool live = rbase + c16 < batch;             // A-layout row of this lane
-      float* Zb = Zs + (it & 1) * NT * kBwdRows * 16;
+      float* Zb = Zs + (EMU ? 0 : (it & 1)) * NT * kBwdRows * 16;
       // ---- dz = act'(y) * BN-backward(gy), published to the dW waves ----
       float4 dz[NT];
 #pragma unroll
@@ -191,7 +264,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int lm = (live && (16 * j + 16 <= N || n + e < N)) ? -1 : 0;      // 0 for rows past the batch / columns past N
+          const int lm = (live && (j < NT - 1 || n + e < N)) ? -1 : 0;            // 0 for rows past the batch / columns past N
           const float da = k1[e] * (ge[e] - k2[e] - (ye[e] - km[e]) * k3[e]);
           // act'(y) from the activation output: sigmoid y(1-y), relu [y > 0], linear 1 - blended with bit masks (no branches)
           const float ds = ye[e] * (1.f - ye[e]);
@@ -200,16 +273,60 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           v[e] = __int_as_float(__float_as_int(da * dl) & lm);
         }
         dz[j] = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(Zb + (j * kBwdRows + rt * 16 + c16) * 16 + 4 * (g ^ ((c16 >> 2) & 3))) = dz[j];     // swizzled: see bwd_swz
+        if constexpr (!EMU) *reinterpret_cast<float4*>(Zb + (j * kBwdRows + rt * 16 + c16) * 16 + 4 * (g ^ ((c16 >> 2) & 3))) = dz[j];     // swizzled: see bwd_swz
         __builtin_amdgcn_sched_barrier(0);
+      }
+      // EMU: dz split once per tile into three bf16 pieces, packed along n as the A fragments of the 32-deep n-blocks of the dx product
+      // (elements 0-3 from dz[2J], 4-7 from dz[2J+1]; zeros in the half block) ...
+      uint32_t ah[EMU ? NB : 1][4], am[EMU ? NB : 1][4], al[EMU ? NB : 1][4];
+      if constexpr (EMU) {
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          split3(dz[2 * J].x, dz[2 * J].y, ah[J][0], am[J][0], al[J][0]);
+          split3(dz[2 * J].z, dz[2 * J].w, ah[J][1], am[J][1], al[J][1]);
+          if (J < NBF) {
+            split3(dz[J < NBF ? 2 * J + 1 : 0].x, dz[J < NBF ? 2 * J + 1 : 0].y, ah[J][2], am[J][2], al[J][2]);
+            split3(dz[J < NBF ? 2 * J + 1 : 0].z, dz[J < NBF ? 2 * J + 1 : 0].w, ah[J][3], am[J][3], al[J][3]);
+          } else {
+            ah[J][2] = ah[J][3] = am[J][2] = am[J][3] = al[J][2] = al[J][3] = 0u;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                 // B_it: the dW waves have multiplied tile it-1: the single dz image is free
+        // ... and published element by element for the dW waves: element (row r = 16 rt + c16, column n = 16 j + 4 g + e), piece p ->
+        // Zp[j][b = r >> 5][p][r & 3][n & 15] half-word (r >> 2) & 7.  Per lane a base + compile-time offsets; the low / high half of a packed
+        // pair goes out with ds_write_b16 / ds_write_b16_d16_hi (no VALU).
+        uint16_t* zp = reinterpret_cast<uint16_t*>(Zs) + (rt >> 1) * (3 * 4 * 16 * 8) + (((c16 & 3) * 16 + 4 * g) << 3) + 4 * (rt & 1) + (c16 >> 2);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int J = j >> 1, d = 2 * (j & 1) + (e >> 1);
+            uint16_t* q = zp + j * (2 * 3 * 4 * 16 * 8) + e * 8;
+            const uint32_t vh = ah[J][d], vm = am[J][d], vl = al[J][d];
+            q[0] = (uint16_t)((e & 1) ? (vh >> 16) : (vh & 0xffffu));
+            q[4 * 16 * 8] = (uint16_t)((e & 1) ? (vm >> 16) : (vm & 0xffffu));
+            q[2 * 4 * 16 * 8] = (uint16_t)((e & 1) ? (vl >> 16) : (vl & 0xffffu));
+          }
+        }
+        __syncthreads();                                 // A_it: dz(it) is visible to them
       }
       BR_STAMP(4);      // dz of the first tile published (includes the wait for gy / y)
       const bool has_next = tile + gridDim.x < n_tiles;                  // wave-uniform
       if (has_next) gy_rows(tile + gridDim.x);
       if (has_next && !a.gx) load_gy(tile + gridDim.x);                  // (no dx product to hide them behind)
       // keep words of this lane's 4 C-layout rows (rows 4g..4g+3 of the row tile) and, with an input BN, the raw x of its outputs
-      uint32_t kb[4][KW];
-      if (a.keep && a.gx) {
+      // (EMU without an input BN: the keep bits are applied in ROW layout behind the transposition patch - one row, KW words per lane
+      //  instead of four rows: 12 VGPRs that the 256-register budget of the bf16 variant does not have)
+      constexpr bool ROWKEEP = EMU && !IBN;
+      uint32_t kb[ROWKEEP ? 1 : 4][KW];
+      if (ROWKEEP && a.keep && a.gx) {
+        int64_t row = rbase + c16;
+        row = row < batch ? row : batch - 1;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) kb[0][w] = a.keep[row * a.kw + w];
+      }
+      if (!ROWKEEP && a.keep && a.gx) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int64_t row = rbase + 4 * g + r;
@@ -238,6 +355,8 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
         const int rows16 = left > 16 ? 16 : (left < 0 ? 0 : (int)left);
         const bool row_ok = c16 < rows16;
         float* gxrow = a.gx + (rbase + (row_ok ? c16 : 0)) * a.ldgx + 4 * g;      // row layout: &gx[rbase + c16][4g]
+        const float* wpf = Ws + ((g * Kp + c16) << 2);                              // full blocks: + ((J*3 + p) * 4 * Kp + kt * 16) * 4
+        const float* wph = Ws + NBF * 3 * 4 * Kp * 4 + ((g * Kp + c16) << 1);       // half block: + (p * 4 * Kp + kt * 16) * 2
         // ---- dx = dz · W^T in passes of 4 k-tiles: 4 independent accumulator chains ----
 #pragma unroll
         for (int kt0 = 0; kt0 < KT; kt0 += 4) {
@@ -246,6 +365,43 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           f32x4 acc[WMAX];
 #pragma unroll
           for (int w = 0; w < WMAX; ++w) acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if constexpr (EMU) {
+            // step (J, w): the three B fragments of step + 1 are requested, then six MFMAs (small products first); a fence per step
+            float4 bq[2][3];
+            auto fetch_b = [&](int J, int w, float4 (&b)[3]) {
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                if (J < NBF) b[p] = *reinterpret_cast<const float4*>(wpf + (((J * 3 + p) * 4 * Kp + (kt0 + w) * 16) << 2));
+                else { const float2 t = *reinterpret_cast<const float2*>(wph + ((p * 4 * Kp + (kt0 + w) * 16) << 1)); b[p] = make_float4(t.x, t.y, 0.f, 0.f); }
+              }
+            };
+            fetch_b(0, 0, bq[0]);
+#pragma unroll
+            for (int J = 0; J < NB; ++J) {
+              const bf16x8 xh = frag8(ah[J]), xm = frag8(am[J]), xl = frag8(al[J]);
+#pragma unroll
+              for (int w = 0; w < WMAX; ++w) {
+                if (w < Wn) {
+                  const int st = J * Wn + w, cur = st & 1;
+                  const int Jn = (w + 1 < Wn) ? J : J + 1, wn = (w + 1 < Wn) ? w + 1 : 0;
+                  if (Jn < NB) fetch_b(Jn, wn, bq[cur ^ 1]);
+                  const bf16x8 wh = frag8(bq[cur][0]), wm = frag8(bq[cur][1]), wl = frag8(bq[cur][2]);
+                  acc[w] = mfma_bf16(xl, wh, acc[w]);
+                  acc[w] = mfma_bf16(xh, wl, acc[w]);
+                  acc[w] = mfma_bf16(xm, wm, acc[w]);
+                  acc[w] = mfma_bf16(xm, wh, acc[w]);
+                  acc[w] = mfma_bf16(xh, wm, acc[w]);
+                  acc[w] = mfma_bf16(xh, wh, acc[w]);
+                  if (kt0 == 0 && has_next && st < NT) load_gy_j(st < NT ? st : 0);      // next tile's gy / y: two loads behind a step of the first pass
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
+            if (kt0 == 0 && has_next) {
+#pragma unroll
+              for (int j = NB * Wn; j < NT; ++j) load_gy_j(j);       // (KT == 1: fewer steps than n-tiles)
+            }
+          } else
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             float4 b[WMAX];
@@ -275,7 +431,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 float dh = acc[w][r] * a.inv_keep;
-                if (a.keep) dh = keep_bit(dh, kb[r][kt >> 1], 16u * (kt & 1) + c16);
+                if (!ROWKEEP && a.keep) dh = keep_bit(dh, kb[ROWKEEP ? 0 : r][kt >> 1], 16u * (kt & 1) + c16);
                 if (IBN) {                                              // (dh is 0 for rows past the batch: dz is)
                   isum[kt] += dh;
                   isq[kt] = fmaf(dh, (xraw[r][kt] - xm) * xr, isq[kt]);
@@ -283,8 +439,12 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
                 patch[(4 * g + r) * kBwdPatchLd + c16] = dh;
               }
               __builtin_amdgcn_wave_barrier();
-              const float4 o = *reinterpret_cast<const float4*>(patch + c16 * kBwdPatchLd + 4 * g);
+              float4 o = *reinterpret_cast<const float4*>(patch + c16 * kBwdPatchLd + 4 * g);
               __builtin_amdgcn_wave_barrier();
+              if (ROWKEEP && a.keep) {
+                const uint32_t w_ = kb[0][kt >> 1], p0 = 16u * (kt & 1) + 4u * g;
+                o.x = keep_bit(o.x, w_, p0); o.y = keep_bit(o.y, w_, p0 + 1); o.z = keep_bit(o.z, w_, p0 + 2); o.w = keep_bit(o.w, w_, p0 + 3);
+              }
               if (row_ok && (kt * 16 + 16 <= K || kt * 16 + 4 * g < K)) *reinterpret_cast<float4*>(gxrow + kt * 16) = o;
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -292,7 +452,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
           BR_STAMP(6 + 2 * (kt0 / 4));      // pass epilogue issued
         }
       }
-      __syncthreads();                                   // S_it: Zs[it & 1] is published; the dW waves' readers of Zs[(it - 1) & 1] are done
+      if constexpr (!EMU) __syncthreads();               // S_it: Zs[it & 1] is published; the dW waves' readers of Zs[(it - 1) & 1] are done
     }
     if (IBN && a.in_sums) {
 #pragma unroll
@@ -302,6 +462,161 @@ __global__ __launch_bounds__(kBwdThreads, 2) void dense_bwd_kernel(const BwdArgs
         q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
         if (g == 0) { atomicAdd(&red[kt * 16 + c16], (double)sv); atomicAdd(&red[Kp + kt * 16 + c16], (double)q); }
       }
+    }
+  } else if constexpr (EMU) {
+    // =========================================== dW waves, bf16x6 ===========================================
+    const int q = wave - 4;                              // k-tiles 2q, 2q+1; db of the n-tiles nt = q (mod 4)
+    const bool q_live = 2 * q < KT, h1 = 2 * q + 1 < KT; // wave-uniform
+    float* Xw = Xs + q * 2 * 32 * 16;                    // [k-tile h][32 rows][16], swizzled as the fp32 kernel's image
+    const int lr = lane >> 3, lc = lane & 7;             // x loads: row lr + 8i, columns 32q + 4lc..+3
+    const int kcol = 32 * q + 4 * lc;
+    const bool col_in = kcol < K;
+    float4 xv[8];
+    uint32_t kwl = 0xFFFFFFFFu;                          // keep word q (columns 32q..32q+31) of row `lane` of the tile
+    auto load_x = [&](int64_t tile) {
+      const int64_t r0 = tile * kBwdRows;
+      if (a.keep) { const int64_t row = r0 + lane < batch ? r0 + lane : batch - 1; kwl = a.keep[row * a.kw + (q_live ? q : 0)]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int64_t row = r0 + lr + 8 * i;
+        row = row < batch ? row : batch - 1;
+        xv[i] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + (col_in ? kcol : 0));
+      }
+    };
+    int64_t tile = blockIdx.x;
+    if (q_live && tile < n_tiles) load_x(tile);
+    BR_STAMP(1);
+    stage();
+    BR_STAMP(2);
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NDB = (NT + 3) / 4;
+    f32x4 accdb[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) accdb[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                     // staging visible
+    BR_STAMP(3);
+    const float4 sc = *reinterpret_cast<const float4*>(ssb + (col_in ? kcol : 0)), sh = *reinterpret_cast<const float4*>(ssb + Kp + (col_in ? kcol : 0));
+    const uint32_t ones2 = 0x3F803F80u;
+    const uint32_t ones4[4] = {ones2, ones2, ones2, ones2};
+    const bf16x8 ones = frag8(ones4);
+    const float* zl = Zs + ((g * 16 + c16) << 2);        // + (((nt * 2 + b) * 3 + p) * 4 * 16) * 4
+    int it = 0;
+    for (; tile < n_tiles; tile += gridDim.x, ++it) {
+      const bool has_next = tile + gridDim.x < n_tiles;                      // wave-uniform
+      // ---- T(x) = BN affine + keep bits, split into the A fragments of the tile (columns past K: zero) ----
+      uint32_t xh[2][2][4], xm[2][2][4], xl[2][2][4];
+      if (q_live) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {                    // rows lr + 8i of block b: T() as the fp32 kernel, into the patch
+            const float4 xx = xv[4 * b + i];
+            const uint32_t kx = __shfl(kwl, 32 * b + lr + 8 * i, 64);
+            const uint32_t p0 = 4u * lc;
+            float4 t;
+            t.x = keep_bit(fmaf(xx.x, sc.x, sh.x), kx, p0); t.y = keep_bit(fmaf(xx.y, sc.y, sh.y), kx, p0 + 1);
+            t.z = keep_bit(fmaf(xx.z, sc.z, sh.z), kx, p0 + 2); t.w = keep_bit(fmaf(xx.w, sc.w, sh.w), kx, p0 + 3);
+            if (!col_in) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (K & 3) {                                   // wave-uniform: a 16-B group may straddle K (padded rows)
+              if (kcol + 1 >= K) t.y = 0.f;
+              if (kcol + 2 >= K) t.z = 0.f;
+              if (kcol + 3 >= K) t.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(Xw + ((lc >> 2) * 32 + lr + 8 * i) * 16 + 4 * ((lc & 3) ^ (((lr + 8 * i) >> 2) & 3))) = t;
+          }
+          __builtin_amdgcn_wave_barrier();
+          float t0[8], t1[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {                    // element i <- row 4i + g of the block, column c16 of k-tile h
+            const int cs = bwd_swz(c16, i);
+            t0[i] = Xw[(4 * i + g) * 16 + cs];
+            t1[i] = Xw[(32 + 4 * i + g) * 16 + cs];
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) {
+            split3(t0[2 * p2], t0[2 * p2 + 1], xh[0][b][p2], xm[0][b][p2], xl[0][b][p2]);
+            split3(t1[2 * p2], t1[2 * p2 + 1], xh[1][b][p2], xm[1][b][p2], xl[1][b][p2]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (has_next) load_x(tile + gridDim.x);            // next tile's x in flight
+      }
+      BR_STAMP(4);      // first T(x) split
+      __syncthreads();                                   // B_it: this wave is done with dz(it-1)
+      __syncthreads();                                   // A_it: dz(it) is visible
+      BR_STAMP(5);
+      // ---- dW[32 x N] += T(x)^T · dz: two 32-row blocks x NT n-tiles; the three B fragments of step + 1 are requested before the MFMAs of a step ----
+      {
+        float4 bq[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const float4*>(zl + ((p * 4 * 16) << 2));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const bf16x8 a0h = frag8(xh[0][b]), a0m = frag8(xm[0][b]), a0l = frag8(xl[0][b]);
+          const bf16x8 a1h = frag8(xh[1][b]), a1m = frag8(xm[1][b]), a1l = frag8(xl[1][b]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int st = b * NT + nt, cur = st & 1;
+            const int bn = (nt + 1 < NT) ? b : b + 1, ntn = (nt + 1 < NT) ? nt + 1 : 0;
+            if (bn < 2) {
+#pragma unroll
+              for (int p = 0; p < 3; ++p) bq[cur ^ 1][p] = *reinterpret_cast<const float4*>(zl + ((((ntn * 2 + bn) * 3 + p) * 4 * 16) << 2));
+            }
+            const bf16x8 wh = frag8(bq[cur][0]), wm = frag8(bq[cur][1]), wl = frag8(bq[cur][2]);
+            if (q_live) {
+              acc[0][nt] = mfma_bf16(a0l, wh, acc[0][nt]);
+              acc[0][nt] = mfma_bf16(a0h, wl, acc[0][nt]);
+              acc[0][nt] = mfma_bf16(a0m, wm, acc[0][nt]);
+              acc[0][nt] = mfma_bf16(a0m, wh, acc[0][nt]);
+              acc[0][nt] = mfma_bf16(a0h, wm, acc[0][nt]);
+              acc[0][nt] = mfma_bf16(a0h, wh, acc[0][nt]);
+            }
+            if (h1) {
+              acc[1][nt] = mfma_bf16(a1l, wh, acc[1][nt]);
+              acc[1][nt] = mfma_bf16(a1h, wl, acc[1][nt]);
+              acc[1][nt] = mfma_bf16(a1m, wm, acc[1][nt]);
+              acc[1][nt] = mfma_bf16(a1m, wh, acc[1][nt]);
+              acc[1][nt] = mfma_bf16(a1h, wm, acc[1][nt]);
+              acc[1][nt] = mfma_bf16(a1h, wh, acc[1][nt]);
+            }
+            if ((nt & 3) == q) {                         // db: column sums of dz = ones^T dz (every row of the result tile carries them)
+              accdb[nt >> 2] = mfma_bf16(ones, wl, accdb[nt >> 2]);
+              accdb[nt >> 2] = mfma_bf16(ones, wm, accdb[nt >> 2]);
+              accdb[nt >> 2] = mfma_bf16(ones, wh, accdb[nt >> 2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (it == 0) BR_STAMP(7);      // first product done
+    }
+    // ---- the workgroup's slab: [dW (K x N) | db (N)], scaled by 1/(1-p) (folded out of T()) ----
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_elems;
+    if (q_live) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (2 * q + h < KT) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = (2 * q + h) * 16 + 4 * g + r;
+              if (k < K && n < N) slab[(int64_t)k * N + n] = acc[h][nt][r] * a.inv_keep;
+            }
+          }
+        }
+      }
+    }
+    if (a.db_off >= 0 && g == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if ((nt & 3) == q && nt * 16 + c16 < N) slab[a.db_off + nt * 16 + c16] = accdb[nt >> 2][0];
     }
   } else {
     // =========================================== dW waves ===========================================
@@ -468,19 +783,27 @@ size_t dense_bwd_fused_lds(int NT, int KT) {
 }
 }  // namespace br
 
-template <int NT, int KT, bool IBN>
+template <int NT, int KT, bool IBN, bool EMU>
 static void launch_bwd_v(unsigned grid, size_t shmem, hipStream_t s, const BwdArgs& a) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dense_bwd_kernel<NT, KT, IBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dense_bwd_kernel<NT, KT, IBN, EMU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dense_bwd_kernel<NT, KT, IBN><<<grid, kBwdThreads, shmem, s>>>(a);
+  dense_bwd_kernel<NT, KT, IBN, EMU><<<grid, kBwdThreads, shmem, s>>>(a);
 }
 template <int NT, int KT>
 static void launch_bwd(unsigned grid, size_t shmem, hipStream_t s, const BwdArgs& a) {
-  if (a.i_mean) launch_bwd_v<NT, KT, true>(grid, shmem, s, a);
-  else launch_bwd_v<NT, KT, false>(grid, shmem, s, a);
+  if constexpr (bwd_emu_fits(NT, KT)) {
+    if (mlp_bf16x6()) {
+      const size_t sh = bwd_emu_lds(NT, KT);
+      if (a.i_mean) launch_bwd_v<NT, KT, true, true>(grid, sh, s, a);
+      else launch_bwd_v<NT, KT, false, true>(grid, sh, s, a);
+      return;
+    }
+  }
+  if (a.i_mean) launch_bwd_v<NT, KT, true, false>(grid, shmem, s, a);
+  else launch_bwd_v<NT, KT, false, false>(grid, shmem, s, a);
 }
 
 namespace br {
