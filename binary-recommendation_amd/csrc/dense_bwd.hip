@@ -232,6 +232,15 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
       vg[j] = *reinterpret_cast<const float4*>(pg_n + off);
       vy[j] = *reinterpret_cast<const float4*>(py_n + off);
     };
+    auto load_gy_unit = [&](int u) {                     // half of load_gy_j: unit 2j = gy, 2j + 1 = y
+      const int j = u >> 1;
+      int g4 = 4 * g;
+      if (j == NT - 1) asm volatile("" : "+v"(g4));
+      const bool in = j < NT - 1 || 16 * j + g4 < N;
+      const int off = in ? 16 * j : -g4;
+      if (u & 1) vy[j] = *reinterpret_cast<const float4*>(py_n + off);
+      else vg[j] = *reinterpret_cast<const float4*>(pg_n + off);
+    };
     auto load_gy = [&](int64_t tile) {
       gy_rows(tile);
 #pragma unroll
@@ -354,7 +363,11 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
         const int64_t left = batch - rbase;
         const int rows16 = left > 16 ? 16 : (left < 0 ? 0 : (int)left);
         const bool row_ok = c16 < rows16;
-        float* gxrow = a.gx + (rbase + (row_ok ? c16 : 0)) * a.ldgx + 4 * g;      // row layout: &gx[rbase + c16][4g]
+        // (EMU: lane coordinates recomputed from the thread id behind an opaque barrier - at its 256-VGPR limit hipcc spilled the 64-bit
+        //  zero-extensions of c16 / 4g it keeps for this address, and a scratch reload waits for vmcnt(0), i.e. for every prefetch in flight)
+        int c16e = c16, g4e = 4 * g;
+        if constexpr (EMU) { c16e = threadIdx.x & 15; g4e = (threadIdx.x >> 2) & 12; asm volatile("" : "+v"(c16e), "+v"(g4e)); }
+        float* gxrow = a.gx + (rbase + (row_ok ? c16e : 0)) * a.ldgx + g4e;       // row layout: &gx[rbase + c16][4g]
         const float* wpf = Ws + ((g * Kp + c16) << 2);                              // full blocks: + ((J*3 + p) * 4 * Kp + kt * 16) * 4
         const float* wph = Ws + NBF * 3 * 4 * Kp * 4 + ((g * Kp + c16) << 1);       // half block: + (p * 4 * Kp + kt * 16) * 2
         // ---- dx = dz · W^T in passes of 4 k-tiles: 4 independent accumulator chains ----
@@ -392,14 +405,17 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
                   acc[w] = mfma_bf16(xm, wh, acc[w]);
                   acc[w] = mfma_bf16(xh, wm, acc[w]);
                   acc[w] = mfma_bf16(xh, wh, acc[w]);
-                  if (kt0 == 0 && has_next && st < NT) load_gy_j(st < NT ? st : 0);      // next tile's gy / y: two loads behind a step of the first pass
+                  // next tile's gy / y: its 2 NT loads spread evenly over the steps of ALL passes (every load is 1 KB against a CU share of
+                  // HBM of ~9 B/clk: requested in a row they hold the wave at the issue port - behind the first pass alone, +3 000 cycles)
+                  constexpr int STEPS = NB * KT, UN = 2 * NT;
+                  const int gs = NB * kt0 + st;              // steps of the earlier passes: NB * kt0
+                  if (has_next) {
+#pragma unroll
+                    for (int u = gs * UN / STEPS; u < (gs + 1) * UN / STEPS; ++u) load_gy_unit(u);
+                  }
                   __builtin_amdgcn_sched_barrier(0);
                 }
               }
-            }
-            if (kt0 == 0 && has_next) {
-#pragma unroll
-              for (int j = NB * Wn; j < NT; ++j) load_gy_j(j);       // (KT == 1: fewer steps than n-tiles)
             }
           } else
 #pragma unroll
@@ -544,7 +560,6 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (has_next) load_x(tile + gridDim.x);            // next tile's x in flight
       }
       BR_STAMP(4);      // first T(x) split
       __syncthreads();                                   // B_it: this wave is done with dz(it-1)
@@ -594,6 +609,10 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
         }
       }
       if (it == 0) BR_STAMP(7);      // first product done
+      // next tile's x: requested HERE, not in front of the barriers - this wave now waits for the dx waves (whose product and epilogue take
+      // ~3 x as long as the product above), so the back-pressure of a burst of loads (a CU's share of HBM is ~9 B/clk) stalls an idle wave,
+      // and the burst is over before the dx waves request the next gy / y
+      if (q_live && has_next) load_x(tile + gridDim.x);
     }
     // ---- the workgroup's slab: [dW (K x N) | db (N)], scaled by 1/(1-p) (folded out of T()) ----
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_elems;
