@@ -36,6 +36,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak (same guide)
+MLP_MATH = "f32" if os.environ.get("BR_MLP_MATH", "").startswith("f") else "bf16x6"      # csrc/dense.h mlp_bf16x6()
 
 
 class PyProbe:
@@ -473,6 +474,7 @@ def main():
     # theta / m / v / grad of the dense vector updated - their algorithmic bytes count towards that launch
     riders = deferred_mode and ctx is None and eng.cfg.dropout > 0 and os.environ.get("BR_KEEP_PREFETCH", "2") == "2"
     rider_bytes = (B * 4 * sum((w + 31) // 32 for w in (2 * D, n1, n2)) + 4 * int(eng.slabs.numel()) + 7 * 4 * int(eng.theta.buf.numel())) if riders else 0
+    kb = lambda width: (B * ((width + 31) // 32) * 4) if eng.cfg.dropout > 0 else 0      # keep-bit plane of a layer's input
     SPEC = {
         "EMBED_FWD": (((("lookup on deferred tables (4 lookups + replay of lagging rows + GMF dot + concat) + the chunk sorts of both id streams riding in its grid",
                          "lookup_sort_kernel") if fused_sort else
@@ -482,15 +484,16 @@ def main():
         "EMBED_BWD": (("mf_grad_inplace" if deferred_mode and ctx is None else "neumf_embed_bwd", "neumf_embed_bwd_kernel", "hbm", B * (4 * D * 4 + 8)), ("OPT_TABLES",)),
         "KEEP_BITS": ((f"dropout keep-bit planes (Philox4x32-10, {2 * D} + {n1} + {n2} bits per row)", "keep_bits_kernel", None, None), ("FWD1",)),
         "STEP_STATE": (("step counter / alpha_t advance + BatchNorm sum reset", "step_state_advance_kernel", None, None), ("FWD1",)),
-        "FWD_L1": ((f"dense_fwd[{2 * D}x{n1}]", "dense_fwd_kernel", "mfma", 2.0 * B * 2 * D * n1), ("FWD1",)),
-        "FWD_L2": ((f"dense_fwd[{n1}x{n2}] (+ BatchNorm 1 finalize)", "dense_fwd_kernel", "mfma", 2.0 * B * n1 * n2), ("FWD2",)),
-        "FWD_L3": ((f"dense_fwd[{n2}x{n3}]", "dense_fwd_kernel", "mfma", 2.0 * B * n2 * n3), ("FWD3",)),
+        # dense layers: (fp32-equivalent flop, algorithmic bytes = the activation rows in and out + the keep-bit plane of the input)
+        "FWD_L1": ((f"dense_fwd[{2 * D}x{n1}]", "dense_fwd_kernel", "mfma", (2.0 * B * 2 * D * n1, B * (2 * D + n1) * 4 + kb(2 * D))), ("FWD1",)),
+        "FWD_L2": ((f"dense_fwd[{n1}x{n2}] (+ BatchNorm 1 finalize)", "dense_fwd_kernel", "mfma", (2.0 * B * n1 * n2, B * (n1 + n2) * 4 + kb(n1))), ("FWD2",)),
+        "FWD_L3": ((f"dense_fwd[{n2}x{n3}]", "dense_fwd_kernel", "mfma", (2.0 * B * n2 * n3, B * (n2 + n3) * 4 + kb(n2))), ("FWD3",)),
         # (an HBM kernel: 0.2 GFLOP over 2 x a2 / gh2 rows + a3, logits, probabilities - SURVEY.md 8d's per-pair bytes of the tail)
         "HEAD": ((f"tail: BatchNorm 2 finalize + dense {n2}x{n3} fwd + head + loss + their backward (one launch)", "neumf_tail_mfma_kernel", "hbm",
                   B * (2 * l2 * 4 + n3 * 4 + 5 * 4) + (B * ((n2 + 31) // 32) * 4 if eng.cfg.dropout > 0 else 0)), ("FWD3",)),
-        "BWD_L3": ((f"dense_bwd[{n2}x{n3}]", "dense_bwd_kernel", "mfma", 4.0 * B * n2 * n3), ("FWD3",)),
-        "BWD_L2": ((f"dense_bwd[{n1}x{n2}] (dx + dW + db + BatchNorm sums, one launch)", "dense_bwd_kernel", "mfma", 4.0 * B * n1 * n2), ("BWD2",)),
-        "BWD_L1": ((f"dense_bwd[{2 * D}x{n1}] (dx + dW + db, one launch)", "dense_bwd_kernel", "mfma", 4.0 * B * 2 * D * n1), ("BWD1",)),
+        "BWD_L3": ((f"dense_bwd[{n2}x{n3}]", "dense_bwd_kernel", "mfma", (4.0 * B * n2 * n3, B * 2 * (n2 + n3) * 4 + kb(n2))), ("FWD3",)),
+        "BWD_L2": ((f"dense_bwd[{n1}x{n2}] (dx + dW + db + BatchNorm sums, one launch)", "dense_bwd_kernel", "mfma", (4.0 * B * n1 * n2, B * 2 * (n1 + n2) * 4 + kb(n1))), ("BWD2",)),
+        "BWD_L1": ((f"dense_bwd[{2 * D}x{n1}] (dx + dW + db, one launch)", "dense_bwd_kernel", "mfma", (4.0 * B * 2 * D * n1, B * 2 * (2 * D + n1) * 4 + kb(2 * D))), ("BWD1",)),
         "INDEX_SORT": (("row index, both tables: chunk sort", "chunk_sort_kernel", None, None), ("FWD1",)),
         "INDEX_USER": (("row index, both tables: chunk rank / merge", "chunk_rank_kernel", None, None), ("FWD1",)),
         "INDEX_ITEM": (("row index [item]", "chunk_rank_kernel", None, None), ("FWD1",)),
@@ -655,7 +658,15 @@ def main():
         if bound == "hbm":
             k.update({"bound": "hbm", "bytes": work, "achieved_GBps": work / us * 1e-3, "frac": work / us * 1e-3 / HBM_PEAK_GBPS})
         elif bound == "mfma":
-            k.update({"bound": "mfma", "flop": work, "achieved_TFLOPs": work / us * 1e-6, "frac": work / us * 1e-6 / MFMA_F32_PEAK_TFLOPS})
+            # the tower's GEMMs: fp32-equivalent flop against the fp32-MFMA peak (`frac`, comparable across rounds), the share of the launch
+            # the matrix pipe is busy (bf16x6, DESIGN.md 4c: six 16-cycle bf16 MFMAs do the work of eight 32-cycle fp32 ones -> 0.375 x), and
+            # the activation traffic against HBM; `bound` names the nearer roofline
+            flop, nbytes = work
+            frac = flop / us * 1e-6 / MFMA_F32_PEAK_TFLOPS
+            busy = frac * (0.375 if MLP_MATH == "bf16x6" else 1.0)
+            fh = nbytes / us * 1e-3 / HBM_PEAK_GBPS
+            k.update({"bound": "hbm" if fh > busy else "mfma", "math": MLP_MATH, "flop": flop, "achieved_TFLOPs": flop / us * 1e-6, "frac": frac,
+                      "matrix_pipe_busy": busy, "bytes": nbytes, "achieved_GBps": nbytes / us * 1e-3, "frac_hbm": fh})
         kernels[name] = k
         gpu_us_per_step += k["us_per_step"]
     for k in kernels.values():
@@ -676,7 +687,7 @@ def main():
                 traffic = None
         roofline = {"bound": dom["bound"], "kernel": f"{dom_sym} ({dom_key})", "achieved": dom["achieved_GBps" if dom["bound"] == "hbm" else "achieved_TFLOPs"],
                     "peak": HBM_PEAK_GBPS if dom["bound"] == "hbm" else MFMA_F32_PEAK_TFLOPS, "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s",
-                    "frac": dom["frac"], "traffic": traffic, "traffic_from": tmeta, "avg_launch_us": dom["us"], "measured_in": dom["measured_in"],
+                    "frac": (dom.get("frac_hbm", dom["frac"]) if dom["bound"] == "hbm" else dom["frac"]), "traffic": traffic, "traffic_from": tmeta, "avg_launch_us": dom["us"], "measured_in": dom["measured_in"],
                     "share_of_kernel_time": dom["share_of_kernel_time"], "chosen_by": "largest measured time per step among the kernels of the eager pass"}
         roofline["algorithmic_bytes_per_launch" if dom["bound"] == "hbm" else "algorithmic_flop_per_launch"] = dom["bytes" if dom["bound"] == "hbm" else "flop"]
         if dom["bound"] == "hbm" and dom_tag.startswith("ADAM_ROWS"):
