@@ -93,4 +93,52 @@ __device__ __forceinline__ void gather_deferred_wave_row(const GatherDefJobs& jo
   vstore<VEC>(jb.out + b * ld_out + lane * VEC, ok ? th : vzero<VEC>());
 }
 
+// R rows of deferred tables by one wave: every id, then every last[], then every row load of the R rows is requested before the first
+// replay starts.  A 256-B row (dim 64) per wave leaves 3 dependent round trips with <= 768 B in flight per wave - at 32 waves per CU half
+// of what the CU's share of HBM needs (the BPR gather ran at 0.48 of its memory time); control flow stays scalar per row (a wave replays
+// one row at a time).  Rows [0, n_a) belong to job 0, the rest to job 1; rows past the end are skipped.
+template <typename IdT, int VEC, int R>
+__device__ __forceinline__ void gather_deferred_wave_rows(const GatherDefJobs& jobs, int64_t b0, int lane, const StepStateDev* __restrict__ ss, const AdamHp& h,
+                                                          int64_t ld_out, int* err) {
+  using V = typename VecT<VEC>::type;
+  constexpr int dim = 64 * VEC;
+  const int64_t n_a = jobs.j[0].n, n_all = n_a + jobs.j[1].n;
+  const uint32_t t = ss->step + jobs.step_add;
+  int which[R];
+  int64_t pos[R], row[R];
+  bool live[R], ok[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int64_t b = b0 + q;
+    live[q] = b < n_all;
+    const int64_t bc = live[q] ? b : n_all - 1;
+    which[q] = bc < n_a ? 0 : 1;
+    const GatherDefJob& jb = jobs.j[which[q]];
+    pos[q] = seg_phys(which[q] ? bc - n_a : bc, jobs.seg_len, jobs.seg_stride, jb.seg_off);
+    row[q] = load_id((const IdT*)jb.ids, pos[q]);
+  }
+  uint32_t seen[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const GatherDefJob& jb = jobs.j[which[q]];
+    ok[q] = (uint64_t)row[q] < (uint64_t)jb.rows;
+    if (!ok[q]) { if (err && lane == 0 && live[q]) *err = 1; row[q] = 0; }
+    seen[q] = (uint32_t)jb.last[row[q]];
+  }
+  V th[R], m[R], v[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const GatherDefJob& jb = jobs.j[which[q]];
+    const int64_t off = row[q] * dim + lane * VEC;
+    th[q] = vload<VEC>(jb.table + off);
+    m[q] = vzero<VEC>(); v[q] = vzero<VEC>();
+    if (seen[q] + 1 < t) { m[q] = vload<VEC>(jb.M + off); v[q] = vload<VEC>(jb.Vv + off); }
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (seen[q] + 1 < t) adam_catch_up_uniform<false>(th[q], m[q], v[q], seen[q], t - 1, ss, h);
+    if (live[q]) vstore<VEC>(jobs.j[which[q]].out + pos[q] * ld_out + lane * VEC, ok[q] ? th[q] : vzero<VEC>());
+  }
+}
+
 }  // namespace br

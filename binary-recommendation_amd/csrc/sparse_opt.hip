@@ -752,6 +752,8 @@ __global__ __launch_bounds__(kThreadsL) void lookup_sort_kernel(const LookupArgs
 // sort a chunk, the rest gather 16 rows each and flow around them; the chunk-rank launch (+ the step-state advance) follows on the same
 // stream.  As launches of their own on two side streams the sorts and ranks were 42 % of the step's kernel time and cost a fork / join
 // inside the step's hipGraph.
+// rows per wave of the fused gather: 1 KB of row per wave and table (dim 64: four rows)
+template <int VEC> constexpr int kGatherRowsPerWave = VEC == 1 ? 4 : (VEC == 2 ? 2 : 1);
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(kThreadsL) void gather_sort_kernel(const GatherDefJobs gj, const StepStateDev* __restrict__ ss, const AdamHp h, int64_t ld_out, int* err,
                                                                 IdxJobs jobs, int n_sort_a, int n_sort_b) {
@@ -761,11 +763,10 @@ __global__ __launch_bounds__(kThreadsL) void gather_sort_kernel(const GatherDefJ
     chunk_sort_block<IdT, kChunkL, kThreadsL>(jobs, 0, which ? (int)blockIdx.x - n_sort_a : (int)blockIdx.x, which);
     return;
   }
-  int64_t b = ((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int which = b < gj.j[0].n ? 0 : 1;
-  if (which) b -= gj.j[0].n;
-  if (b >= gj.j[which].n) return;
-  gather_deferred_wave_row<IdT, VEC>(gj, gj.j[which], b, (int)(threadIdx.x & 63), ss, h, ld_out, err);
+  constexpr int R = kGatherRowsPerWave<VEC>;
+  const int64_t b0 = (((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * R;
+  if (b0 >= gj.j[0].n + gj.j[1].n) return;
+  gather_deferred_wave_rows<IdT, VEC, R>(gj, b0, (int)(threadIdx.x & 63), ss, h, ld_out, err);
 }
 
 // adv.st != NULL: the grid has one extra column of workgroups, whose y = 0 member advances the step state (nothing in this launch reads it;
@@ -1005,7 +1006,8 @@ extern "C" int brGatherRowsDeferredPairWithIndex(const float* table_a, const flo
   const AdamHp h = make_hp(0.0, beta1, beta2, eps);
   StepStateDev* ss = (StepStateDev*)step_state;
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)(ca + cb + ceil_div(n_a + n_b, kThreadsL / 64));
+  const int rpw = wvec == 1 ? 4 : (wvec == 2 ? 2 : 1);      // kGatherRowsPerWave
+  const unsigned grid = (unsigned)(ca + cb + ceil_div(ceil_div(n_a + n_b, (int64_t)rpw), (int64_t)(kThreadsL / 64)));
   if (id_type == BR_IDS_I32)
     BR_DISPATCH_VEC(wvec, (gather_sort_kernel<int32_t, VEC><<<grid, kThreadsL, 0, s>>>(G, ss, h, ld_out, err_flag, jobs, ca, cb)));
   else

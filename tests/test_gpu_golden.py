@@ -37,7 +37,9 @@ def test_neumf_step_vs_golden(dev, name, variant, dim):
         assert np.all(np.abs(got - z["g_" + k]) <= f * 1e-5 * z["gabs_" + k] + 1e-12), k
     for k, (g, _) in eng.row_grad_views(B).items():
         ref = z["rg_" + k]
-        np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=k)
+        # (same small-batch factor: the row gradients come through the BatchNorm backward of a 7-row batch, where c1 (gy - c2 - xhat c3)
+        #  cancels; with the tower on the bf16 pipe - DESIGN.md 4c - one element of the 7 x 10 case sat 6 % over the unscaled atol)
+        np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=1e-4, atol=f * 1e-5 * np.abs(ref).max(), err_msg=k)
     for k in ("user_mf", "item_mlp"):
         # the first Adam step is lr * g / (|g| + eps): sign-like, so an element whose gradient sits at the fp32 noise floor can move
         # by a visible fraction of lr; same small-batch factor as the gradient checks above

@@ -76,7 +76,10 @@ def _worker(rank, world, port, variant, dim, optimizer, impl, q, idt=torch.int32
         for k in neumf.TABLES:
             ref = P[k][rank::world]
             got = eng.tables[k].cpu().numpy()[: ref.shape[0]]
-            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=5e-3 * travel, err_msg=k)
+            # outliers: an element whose gradient sits at the fp32 noise floor takes Adam steps of either sign (lr g / (|g| + eps)), so two
+            # fp32 evaluation orders can part by a visible fraction of the distance travelled; 1 % of it bounds them (one element of 1 728
+            # reached 0.505 % when the tower moved to the bf16 pipe), the median pins everything else
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-2 * travel, err_msg=k)
             assert np.median(np.abs(got - ref)) <= 1e-7
         for k in O.DENSE_ORDER:
             np.testing.assert_allclose(eng.theta.view(k).cpu().numpy().reshape(P[k].shape), P[k], rtol=1e-5, atol=2e-2 * travel, err_msg=k)
@@ -97,7 +100,7 @@ def _worker(rank, world, port, variant, dim, optimizer, impl, q, idt=torch.int32
             for k in neumf.TABLES:
                 full = single.tables[k]
                 assert torch.equal(full[rank::world][: eng.tables[k].shape[0]], eng.tables[k][: full[rank::world].shape[0]]), k
-                np.testing.assert_allclose(full.cpu().numpy(), P[k], rtol=1e-5, atol=5e-3 * travel, err_msg=k)
+                np.testing.assert_allclose(full.cpu().numpy(), P[k], rtol=1e-5, atol=1e-2 * travel, err_msg=k)
             np.testing.assert_allclose(single.predict(ue, ie).cpu().numpy(), pr.cpu().numpy(), rtol=2e-6, atol=1e-7)
         ctx.barrier()
         q.put((rank, "ok"))
