@@ -71,11 +71,6 @@ constexpr size_t bwd_emu_lds(int NT, int KT) {
                           4 * 2 * 32 * 16 + 4 * 16 * (size_t)kBwdPatchLd) + sizeof(double) * 2 * Kp;
 }
 constexpr bool bwd_emu_fits(int NT, int KT) { return bwd_emu_lds(NT, KT) <= 160 * 1024; }
-constexpr int bwd_emu_chunks(int Kp, int ldw, int room) {      // fewest chunks of rows whose [rows][ldw] image fits in `room` floats
-  int n = 1;
-  while (((Kp + n - 1) / n) * ldw > room) ++n;
-  return n;
-}
 
 template <int NT, int KT, bool IBN, bool EMU>
 __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(const BwdArgs a) {
@@ -131,7 +126,59 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
       // da = c1 * (gy - c2 - (y - mu) * c3)
       Cs[n] = c1; Cs[Np + n] = c2; Cs[2 * Np + n] = c3; Cs[3 * Np + n] = mu;
     }
-    {   // W: 4 floats along n per thread (one 16-B load when N % 4 == 0).  Clamped addresses, no lane conditions around the loads and
+    if constexpr (EMU) {
+      // W -> Wp straight from global memory: item = (n-block J, k-tile kt) x 64 lanes (k16 = lane & 15, gg = lane >> 4) reads the 8 n-values of
+      // ITS B fragment (k = 16 kt + k16; n = 32J + 4gg..+3 and 32J + 16 + 4gg..+3: 16 rows x 64 B per load, the access shape of the gy
+      // loads), splits them and writes three 16-B pieces (16 lanes = 256 contiguous bytes per g: conflict-free).  All loads of the
+      // workgroup's items are requested before the first split.  (The first version staged the fp32 rows through the dz region in two
+      // chunks - four more barriers and two LDS round trips: 12.9 k cycles of prologue; this form needs no fp32 image at all.)
+      constexpr int ITEMS = NB * KT, TRB = (ITEMS * 64 + kBwdThreads - 1) / kBwdThreads;
+      float4 lo[TRB], hi[TRB];
+      const int k16 = threadIdx.x & 15, gg = (threadIdx.x >> 4) & 3;
+      const bool n4 = (N & 3) == 0;
+#pragma unroll
+      for (int i = 0; i < TRB; ++i) {
+        const int item = (threadIdx.x >> 6) + i * (kBwdThreads / 64);
+        const int itc = item < ITEMS ? item : 0;
+        const int J = itc / KT, kt = itc - J * KT, k = kt * 16 + k16;
+        const float* wr = a.W + (int64_t)(k < K ? k : 0) * N;
+        const int n0 = 32 * J + 4 * gg, n1 = n0 + 16;
+        if (n4) {      // quads are wholly inside or outside N
+          lo[i] = *reinterpret_cast<const float4*>(wr + (n0 < N ? n0 : 0));
+          hi[i] = *reinterpret_cast<const float4*>(wr + (n1 < N ? n1 : 0));
+        } else {
+          lo[i] = make_float4(wr[n0 < N ? n0 : 0], wr[n0 + 1 < N ? n0 + 1 : 0], wr[n0 + 2 < N ? n0 + 2 : 0], wr[n0 + 3 < N ? n0 + 3 : 0]);
+          hi[i] = make_float4(wr[n1 < N ? n1 : 0], wr[n1 + 1 < N ? n1 + 1 : 0], wr[n1 + 2 < N ? n1 + 2 : 0], wr[n1 + 3 < N ? n1 + 3 : 0]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TRB; ++i) {
+        const int item = (threadIdx.x >> 6) + i * (kBwdThreads / 64);
+        const int J = item / KT, kt = item - J * KT, k = kt * 16 + k16;
+        const int n0 = 32 * J + 4 * gg, n1 = n0 + 16;
+        const int kin = k < K ? -1 : 0;
+        auto msk = [&](float v, int n) { return __int_as_float(__float_as_int(v) & kin & (n < N ? -1 : 0)); };
+        uint32_t ph[4], pm[4], pl[4];
+        split3(msk(lo[i].x, n0), msk(lo[i].y, n0 + 1), ph[0], pm[0], pl[0]);
+        split3(msk(lo[i].z, n0 + 2), msk(lo[i].w, n0 + 3), ph[1], pm[1], pl[1]);
+        split3(msk(hi[i].x, n1), msk(hi[i].y, n1 + 1), ph[2], pm[2], pl[2]);
+        split3(msk(hi[i].z, n1 + 2), msk(hi[i].w, n1 + 3), ph[3], pm[3], pl[3]);
+        if (item < ITEMS) {
+          if (J < NBF) {
+            float* d = Ws + (((J * 3 * 4 + gg) * Kp + k) << 2);
+            *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            *reinterpret_cast<uint4*>(d + 4 * Kp * 4) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+            *reinterpret_cast<uint4*>(d + 2 * 4 * Kp * 4) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          } else {
+            float* d = Ws + NBF * 3 * 4 * Kp * 4 + ((gg * Kp + k) << 1);
+            *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
+            *reinterpret_cast<uint2*>(d + 4 * Kp * 2) = make_uint2(pm[0], pm[1]);
+            *reinterpret_cast<uint2*>(d + 2 * 4 * Kp * 2) = make_uint2(pl[0], pl[1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {   // W: 4 floats along n per thread (one 16-B load when N % 4 == 0).  Clamped addresses, no lane conditions around the loads and
         // the zero padding applied as a bit mask afterwards: with `if (in range) load` per element hipcc built an exec-masked block
         // with its own s_waitcnt vmcnt(0) around each of the 7 loads - seven memory round trips in a row before the first tile
       constexpr int TOT = Kp * (Np / 4), TR = (TOT + kBwdThreads - 1) / kBwdThreads;
@@ -155,52 +202,15 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
           wv[i] = make_float4(wr[n < N ? n : 0], wr[n + 1 < N ? n + 1 : 0], wr[n + 2 < N ? n + 2 : 0], wr[n + 3 < N ? n + 3 : 0]);
         }
       }
-      // EMU: the fp32 rows pass through the (still unused) Zp region in NCH chunks of KCH rows; after each chunk thread -> (J, g, k) reads the
-      // 8 n-values of a lane's B fragment (n = 32J + 16(i >> 2) + 4g + (i & 3): the columns of the dx waves' float4 registers dz[2J],
-      // dz[2J+1]), splits them and writes the pieces to Wp.  Both roles run stage(): the barriers below are workgroup-wide.
-      constexpr int NCH = EMU ? bwd_emu_chunks(Kp, ldw, NT * kZpTile) : 1, KCH = (Kp + NCH - 1) / NCH;
   #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-  #pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          const int idx = threadIdx.x + i * kBwdThreads;
-          const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
-          const int kin = k < K ? -1 : 0;
-          const int m0 = kin & (n < N ? -1 : 0), m1 = kin & (n + 1 < N ? -1 : 0), m2 = kin & (n + 2 < N ? -1 : 0), m3 = kin & (n + 3 < N ? -1 : 0);
-          const float4 w = make_float4(__int_as_float(__float_as_int(wv[i].x) & m0), __int_as_float(__float_as_int(wv[i].y) & m1),
-                                       __int_as_float(__float_as_int(wv[i].z) & m2), __int_as_float(__float_as_int(wv[i].w) & m3));
-          if constexpr (EMU) {
-            if (idx < TOT && k >= c * KCH && k < (c + 1) * KCH) *reinterpret_cast<float4*>(Zs + (k - c * KCH) * ldw + n) = w;
-          } else {
-            if (idx < TOT) *reinterpret_cast<float4*>(Ws + k * ldw + n) = w;
-          }
-        }
-        if constexpr (EMU) {
-          __syncthreads();
-          constexpr int TOTP = NB * 4 * KCH;
-          for (int idx = threadIdx.x; idx < TOTP; idx += kBwdThreads) {
-            const int kc = idx % KCH, Jg = idx / KCH, J = Jg >> 2, gg = Jg & 3, k = c * KCH + kc;
-            if (k >= Kp) continue;
-            const float4 lo = *reinterpret_cast<const float4*>(Zs + kc * ldw + 32 * J + 4 * gg);
-            const bool full = J < NBF;
-            const float4 hi = full ? *reinterpret_cast<const float4*>(Zs + kc * ldw + 32 * J + 16 + 4 * gg) : make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t ph[4], pm[4], pl[4];
-            split3(lo.x, lo.y, ph[0], pm[0], pl[0]); split3(lo.z, lo.w, ph[1], pm[1], pl[1]);
-            split3(hi.x, hi.y, ph[2], pm[2], pl[2]); split3(hi.z, hi.w, ph[3], pm[3], pl[3]);
-            if (full) {
-              float* d = Ws + (((J * 3 * 4 + gg) * Kp + k) << 2);
-              *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-              *reinterpret_cast<uint4*>(d + 4 * Kp * 4) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-              *reinterpret_cast<uint4*>(d + 2 * 4 * Kp * 4) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-            } else {
-              float* d = Ws + NBF * 3 * 4 * Kp * 4 + ((gg * Kp + k) << 1);
-              *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
-              *reinterpret_cast<uint2*>(d + 4 * Kp * 2) = make_uint2(pm[0], pm[1]);
-              *reinterpret_cast<uint2*>(d + 2 * 4 * Kp * 2) = make_uint2(pl[0], pl[1]);
-            }
-          }
-          __syncthreads();
-        }
+      for (int i = 0; i < TR; ++i) {
+        const int idx = threadIdx.x + i * kBwdThreads;
+        const int k = idx / (Np / 4), n = (idx - k * (Np / 4)) * 4;
+        const int kin = k < K ? -1 : 0;
+        const int m0 = kin & (n < N ? -1 : 0), m1 = kin & (n + 1 < N ? -1 : 0), m2 = kin & (n + 2 < N ? -1 : 0), m3 = kin & (n + 3 < N ? -1 : 0);
+        const float4 w = make_float4(__int_as_float(__float_as_int(wv[i].x) & m0), __int_as_float(__float_as_int(wv[i].y) & m1),
+                                     __int_as_float(__float_as_int(wv[i].z) & m2), __int_as_float(__float_as_int(wv[i].w) & m3));
+        if (idx < TOT) *reinterpret_cast<float4*>(Ws + k * ldw + n) = w;
       }
     }
 

@@ -248,7 +248,51 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
   fwd_load_tile<KJ, VEC>(av, kb, a, tile, c16, g);      // the first tile's loads fly while W is staged (row clamped)
   BR_STAMP(1);
 
-  if constexpr (EMU) {
+  if (EMU && (N & 3) == 0) {
+    // bf16 image, rows of W 16-B aligned: thread -> (J, g, four consecutive n): eight 16-B loads (the rows k = 32J + 16(q >> 2) + 4g + (q & 3) of
+    // its fragment) instead of 32 dword loads - the same bytes through a quarter of the address-pipe slots (the staging of 128 x 100 took
+    // 7 250 cycles, most of it issuing 512 dword loads per CU) - then four fragments' pieces, 64 contiguous bytes per piece
+    constexpr int NQ = Np / 4, TOTQ = KB * 4 * NQ, TRQ = (TOTQ + kFwdThreads - 1) / kFwdThreads;
+    float4 wq[TRQ][8];
+#pragma unroll
+    for (int i = 0; i < TRQ; ++i) {
+      const int idx = threadIdx.x + i * kFwdThreads;
+      const int idc = idx < TOTQ ? idx : 0;
+      const int Jg = idc / NQ, n = (idc - Jg * NQ) * 4;
+      const int J = Jg >> 2, gg = Jg & 3;
+      const int nc = n < N ? n : 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 32 * J + 16 * (q >> 2) + 4 * gg + (q & 3);
+        wq[i][q] = *reinterpret_cast<const float4*>(a.W + (int64_t)(k < K ? k : 0) * N + nc);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TRQ; ++i) {
+      const int idx = threadIdx.x + i * kFwdThreads;
+      const int Jg = idx / NQ, n = (idx - Jg * NQ) * 4;
+      const int J = Jg >> 2, gg = Jg & 3;
+      const int nin = n < N ? -1 : 0;
+      uint32_t* wsu = reinterpret_cast<uint32_t*>(Ws);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k0 = 32 * J + 16 * (q >> 1) + 4 * gg + 2 * (q & 1);
+          const float4 v0 = wq[i][2 * q], v1 = wq[i][2 * q + 1];
+          const float f0 = e == 0 ? v0.x : (e == 1 ? v0.y : (e == 2 ? v0.z : v0.w)), f1 = e == 0 ? v1.x : (e == 1 ? v1.y : (e == 2 ? v1.z : v1.w));
+          split3(__int_as_float(__float_as_int(f0) & nin & (k0 < K ? -1 : 0)), __int_as_float(__float_as_int(f1) & nin & (k0 + 1 < K ? -1 : 0)), ph[q], pm[q], pl[q]);
+        }
+        if (idx < TOTQ) {
+          *reinterpret_cast<uint4*>(wsu + ((((J * 3 + 0) * 4 + gg) * Np + n + e) << 2)) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+          *reinterpret_cast<uint4*>(wsu + ((((J * 3 + 1) * 4 + gg) * Np + n + e) << 2)) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+          *reinterpret_cast<uint4*>(wsu + ((((J * 3 + 2) * 4 + gg) * Np + n + e) << 2)) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (EMU) {
     // bf16 image: thread -> (J, g, n): the 8 k-values a lane's fragment of k-block J holds (k = 32J + 16(i >> 2) + 4g + (i & 3): the
     // columns of the two float4 A loads of 16-column blocks 2J and 2J+1), split into three bf16 pieces, one 16-B LDS write per piece
     constexpr int TOT = KB * 4 * Np, TR = (TOT + kFwdThreads - 1) / kFwdThreads;
