@@ -104,7 +104,67 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
   // ---------------- staging: W image, BN constants ----------------
   // (a lambda that both roles call AFTER they have issued their first tile's loads: in program order ahead of them, the staging's
   //  three dependent memory round trips - constants, BatchNorm sums, W - ran before the first tile was even requested)
+  // EMU: the W loads are REQUESTED before the first tile's loads (stage_w_issue) and consumed behind them (in stage()): the in-order vmcnt
+  // then lets the wave wait for W alone - L2 hits that arrive within ~2 k cycles - and split it into the piece image while the tile's
+  // 88 KB are still streaming in at the CU's ~10 B/clk of HBM; requested behind the tile they arrived last, ~14 k cycles after entry.
+  constexpr int W_ITEMS = NB * KT, W_TRB = EMU ? (W_ITEMS * 64 + kBwdThreads - 1) / kBwdThreads : 1;
+  float4 wlo[W_TRB], whi[W_TRB];
+  auto stage_w_issue = [&]() {
+    if constexpr (EMU) {
+      const int k16 = threadIdx.x & 15, gg = (threadIdx.x >> 4) & 3;
+      const bool n4 = (N & 3) == 0;
+#pragma unroll
+      for (int i = 0; i < W_TRB; ++i) {
+        const int item = (threadIdx.x >> 6) + i * (kBwdThreads / 64);
+        const int itc = item < W_ITEMS ? item : 0;
+        const int J = itc / KT, kt = itc - J * KT, k = kt * 16 + k16;
+        const float* wr = a.W + (int64_t)(k < K ? k : 0) * N;
+        const int n0 = 32 * J + 4 * gg, n1 = n0 + 16;
+        if (n4) {      // quads are wholly inside or outside N
+          wlo[i] = *reinterpret_cast<const float4*>(wr + (n0 < N ? n0 : 0));
+          whi[i] = *reinterpret_cast<const float4*>(wr + (n1 < N ? n1 : 0));
+        } else {
+          wlo[i] = make_float4(wr[n0 < N ? n0 : 0], wr[n0 + 1 < N ? n0 + 1 : 0], wr[n0 + 2 < N ? n0 + 2 : 0], wr[n0 + 3 < N ? n0 + 3 : 0]);
+          whi[i] = make_float4(wr[n1 < N ? n1 : 0], wr[n1 + 1 < N ? n1 + 1 : 0], wr[n1 + 2 < N ? n1 + 2 : 0], wr[n1 + 3 < N ? n1 + 3 : 0]);
+        }
+      }
+    }
+  };
   auto stage = [&]() {
+    if constexpr (EMU) {
+      // W -> Wp straight from global memory: item = (n-block J, k-tile kt) x 64 lanes (k16 = lane & 15, gg = lane >> 4) holds the 8 n-values of
+      // ITS B fragment (k = 16 kt + k16; n = 32J + 4gg..+3 and 32J + 16 + 4gg..+3: 16 rows x 64 B per load, the access shape of the gy
+      // loads), splits them and writes three 16-B pieces (16 lanes = 256 contiguous bytes per g: conflict-free).  (The first version
+      // staged the fp32 rows through the dz region in two chunks - four more barriers and two LDS round trips.)
+      const int k16 = threadIdx.x & 15, gg = (threadIdx.x >> 4) & 3;
+#pragma unroll
+      for (int i = 0; i < W_TRB; ++i) {
+        const int item = (threadIdx.x >> 6) + i * (kBwdThreads / 64);
+        const int J = item / KT, kt = item - J * KT, k = kt * 16 + k16;
+        const int n0 = 32 * J + 4 * gg, n1 = n0 + 16;
+        const int kin = k < K ? -1 : 0;
+        auto msk = [&](float v, int n) { return __int_as_float(__float_as_int(v) & kin & (n < N ? -1 : 0)); };
+        uint32_t ph[4], pm[4], pl[4];
+        split3(msk(wlo[i].x, n0), msk(wlo[i].y, n0 + 1), ph[0], pm[0], pl[0]);
+        split3(msk(wlo[i].z, n0 + 2), msk(wlo[i].w, n0 + 3), ph[1], pm[1], pl[1]);
+        split3(msk(whi[i].x, n1), msk(whi[i].y, n1 + 1), ph[2], pm[2], pl[2]);
+        split3(msk(whi[i].z, n1 + 2), msk(whi[i].w, n1 + 3), ph[3], pm[3], pl[3]);
+        if (item < W_ITEMS) {
+          if (J < NBF) {
+            float* d = Ws + (((J * 3 * 4 + gg) * Kp + k) << 2);
+            *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            *reinterpret_cast<uint4*>(d + 4 * Kp * 4) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+            *reinterpret_cast<uint4*>(d + 2 * 4 * Kp * 4) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          } else {
+            float* d = Ws + NBF * 3 * 4 * Kp * 4 + ((gg * Kp + k) << 1);
+            *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
+            *reinterpret_cast<uint2*>(d + 4 * Kp * 2) = make_uint2(pm[0], pm[1]);
+            *reinterpret_cast<uint2*>(d + 2 * 4 * Kp * 2) = make_uint2(pl[0], pl[1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     for (int k = threadIdx.x; k < Kp; k += kBwdThreads) {
       Is[k] = (IBN && k < K) ? a.i_mean[k] : 0.f;
       Is[Kp + k] = (IBN && k < K) ? a.i_rstd[k] : 0.f;
@@ -126,59 +186,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
       // da = c1 * (gy - c2 - (y - mu) * c3)
       Cs[n] = c1; Cs[Np + n] = c2; Cs[2 * Np + n] = c3; Cs[3 * Np + n] = mu;
     }
-    if constexpr (EMU) {
-      // W -> Wp straight from global memory: item = (n-block J, k-tile kt) x 64 lanes (k16 = lane & 15, gg = lane >> 4) reads the 8 n-values of
-      // ITS B fragment (k = 16 kt + k16; n = 32J + 4gg..+3 and 32J + 16 + 4gg..+3: 16 rows x 64 B per load, the access shape of the gy
-      // loads), splits them and writes three 16-B pieces (16 lanes = 256 contiguous bytes per g: conflict-free).  All loads of the
-      // workgroup's items are requested before the first split.  (The first version staged the fp32 rows through the dz region in two
-      // chunks - four more barriers and two LDS round trips: 12.9 k cycles of prologue; this form needs no fp32 image at all.)
-      constexpr int ITEMS = NB * KT, TRB = (ITEMS * 64 + kBwdThreads - 1) / kBwdThreads;
-      float4 lo[TRB], hi[TRB];
-      const int k16 = threadIdx.x & 15, gg = (threadIdx.x >> 4) & 3;
-      const bool n4 = (N & 3) == 0;
-#pragma unroll
-      for (int i = 0; i < TRB; ++i) {
-        const int item = (threadIdx.x >> 6) + i * (kBwdThreads / 64);
-        const int itc = item < ITEMS ? item : 0;
-        const int J = itc / KT, kt = itc - J * KT, k = kt * 16 + k16;
-        const float* wr = a.W + (int64_t)(k < K ? k : 0) * N;
-        const int n0 = 32 * J + 4 * gg, n1 = n0 + 16;
-        if (n4) {      // quads are wholly inside or outside N
-          lo[i] = *reinterpret_cast<const float4*>(wr + (n0 < N ? n0 : 0));
-          hi[i] = *reinterpret_cast<const float4*>(wr + (n1 < N ? n1 : 0));
-        } else {
-          lo[i] = make_float4(wr[n0 < N ? n0 : 0], wr[n0 + 1 < N ? n0 + 1 : 0], wr[n0 + 2 < N ? n0 + 2 : 0], wr[n0 + 3 < N ? n0 + 3 : 0]);
-          hi[i] = make_float4(wr[n1 < N ? n1 : 0], wr[n1 + 1 < N ? n1 + 1 : 0], wr[n1 + 2 < N ? n1 + 2 : 0], wr[n1 + 3 < N ? n1 + 3 : 0]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TRB; ++i) {
-        const int item = (threadIdx.x >> 6) + i * (kBwdThreads / 64);
-        const int J = item / KT, kt = item - J * KT, k = kt * 16 + k16;
-        const int n0 = 32 * J + 4 * gg, n1 = n0 + 16;
-        const int kin = k < K ? -1 : 0;
-        auto msk = [&](float v, int n) { return __int_as_float(__float_as_int(v) & kin & (n < N ? -1 : 0)); };
-        uint32_t ph[4], pm[4], pl[4];
-        split3(msk(lo[i].x, n0), msk(lo[i].y, n0 + 1), ph[0], pm[0], pl[0]);
-        split3(msk(lo[i].z, n0 + 2), msk(lo[i].w, n0 + 3), ph[1], pm[1], pl[1]);
-        split3(msk(hi[i].x, n1), msk(hi[i].y, n1 + 1), ph[2], pm[2], pl[2]);
-        split3(msk(hi[i].z, n1 + 2), msk(hi[i].w, n1 + 3), ph[3], pm[3], pl[3]);
-        if (item < ITEMS) {
-          if (J < NBF) {
-            float* d = Ws + (((J * 3 * 4 + gg) * Kp + k) << 2);
-            *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-            *reinterpret_cast<uint4*>(d + 4 * Kp * 4) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-            *reinterpret_cast<uint4*>(d + 2 * 4 * Kp * 4) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-          } else {
-            float* d = Ws + NBF * 3 * 4 * Kp * 4 + ((gg * Kp + k) << 1);
-            *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
-            *reinterpret_cast<uint2*>(d + 4 * Kp * 2) = make_uint2(pm[0], pm[1]);
-            *reinterpret_cast<uint2*>(d + 2 * 4 * Kp * 2) = make_uint2(pl[0], pl[1]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {   // W: 4 floats along n per thread (one 16-B load when N % 4 == 0).  Clamped addresses, no lane conditions around the loads and
+    if constexpr (!EMU) {   // W: 4 floats along n per thread (one 16-B load when N % 4 == 0).  Clamped addresses, no lane conditions around the loads and
         // the zero padding applied as a bit mask afterwards: with `if (in range) load` per element hipcc built an exec-masked block
         // with its own s_waitcnt vmcnt(0) around each of the 7 loads - seven memory round trips in a row before the first tile
       constexpr int TOT = Kp * (Np / 4), TR = (TOT + kBwdThreads - 1) / kBwdThreads;
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
       for (int j = 0; j < NT; ++j) load_gy_j(j);
     };
     int64_t tile = blockIdx.x;
+    stage_w_issue();
     if (tile < n_tiles) load_gy(tile);
     BR_STAMP(1);
     stage();
@@ -510,6 +519,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
       }
     };
     int64_t tile = blockIdx.x;
+    stage_w_issue();
     if (q_live && tile < n_tiles) load_x(tile);
     BR_STAMP(1);
     stage();
@@ -672,6 +682,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
     // one of the next tile's 16 loads (8 x rows, 8 keep words): issued one per k-step of the product - back to back they hold the wave
     // at the issue port for thousands of cycles (the CU's address pipe takes ~30 cycles per 16-row access)
     int64_t tile = blockIdx.x;
+    stage_w_issue();
     if (q_live && tile < n_tiles) load_x(tile);
     BR_STAMP(1);
     stage();

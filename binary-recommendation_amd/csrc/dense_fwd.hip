@@ -242,31 +242,54 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
   BR_STAMP_DECL;
   BR_STAMP_RT(10);
   BR_STAMP(0);
+  // EMU: the W loads are requested BEFORE the first tile's loads and consumed behind them: the in-order vmcnt lets the wave wait for W alone
+  // (L2 hits, ~2 k cycles) and build the piece image while the tile streams in at the CU's share of HBM; behind the tile they arrived last.
+  const bool wquad = EMU && (N & 3) == 0;               // rows of W 16-B aligned: 16-B loads
+  constexpr int NQ = Np / 4, TOTQ = KB * 4 * NQ, TRQ = EMU ? (TOTQ + kFwdThreads - 1) / kFwdThreads : 1;
+  constexpr int TOTS = KB * 4 * Np, TRS = EMU ? (TOTS + kFwdThreads - 1) / kFwdThreads : 1;
+  float4 wq[TRQ][8];
+  float wv1[TRS][8];
+  if constexpr (EMU) {
+    if (wquad) {
+#pragma unroll
+      for (int i = 0; i < TRQ; ++i) {
+        const int idx = threadIdx.x + i * kFwdThreads;
+        const int idc = idx < TOTQ ? idx : 0;
+        const int Jg = idc / NQ, n = (idc - Jg * NQ) * 4;
+        const int J = Jg >> 2, gg = Jg & 3;
+        const int nc = n < N ? n : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = 32 * J + 16 * (q >> 2) + 4 * gg + (q & 3);
+          wq[i][q] = *reinterpret_cast<const float4*>(a.W + (int64_t)(k < K ? k : 0) * N + nc);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TRS; ++i) {
+        const int idx = threadIdx.x + i * kFwdThreads;
+        const int idc = idx < TOTS ? idx : 0;
+        const int Jg = idc / Np, n = idc - Jg * Np;
+        const int J = Jg >> 2, gg = Jg & 3;
+        const int nc = n < N ? n : N - 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = 32 * J + 16 * (q >> 2) + 4 * gg + (q & 3);
+          wv1[i][q] = a.W[(k < K ? k : K - 1) * N + nc];
+        }
+      }
+    }
+  }
   float4 av[KJ];
   uint32_t kb[KWJ];
   int64_t tile = (int64_t)blockIdx.x * kFwdWaves + wave;
   fwd_load_tile<KJ, VEC>(av, kb, a, tile, c16, g);      // the first tile's loads fly while W is staged (row clamped)
   BR_STAMP(1);
 
-  if (EMU && (N & 3) == 0) {
+  if (wquad) {
     // bf16 image, rows of W 16-B aligned: thread -> (J, g, four consecutive n): eight 16-B loads (the rows k = 32J + 16(q >> 2) + 4g + (q & 3) of
-    // its fragment) instead of 32 dword loads - the same bytes through a quarter of the address-pipe slots (the staging of 128 x 100 took
-    // 7 250 cycles, most of it issuing 512 dword loads per CU) - then four fragments' pieces, 64 contiguous bytes per piece
-    constexpr int NQ = Np / 4, TOTQ = KB * 4 * NQ, TRQ = (TOTQ + kFwdThreads - 1) / kFwdThreads;
-    float4 wq[TRQ][8];
-#pragma unroll
-    for (int i = 0; i < TRQ; ++i) {
-      const int idx = threadIdx.x + i * kFwdThreads;
-      const int idc = idx < TOTQ ? idx : 0;
-      const int Jg = idc / NQ, n = (idc - Jg * NQ) * 4;
-      const int J = Jg >> 2, gg = Jg & 3;
-      const int nc = n < N ? n : 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = 32 * J + 16 * (q >> 2) + 4 * gg + (q & 3);
-        wq[i][q] = *reinterpret_cast<const float4*>(a.W + (int64_t)(k < K ? k : 0) * N + nc);
-      }
-    }
+    // its fragment) instead of 32 dword loads - the same bytes through a quarter of the address-pipe slots - then four fragments' pieces,
+    // 64 contiguous bytes per piece
 #pragma unroll
     for (int i = 0; i < TRQ; ++i) {
       const int idx = threadIdx.x + i * kFwdThreads;
@@ -295,21 +318,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void dense_fwd_kernel(const FwdArgs
   } else if constexpr (EMU) {
     // bf16 image: thread -> (J, g, n): the 8 k-values a lane's fragment of k-block J holds (k = 32J + 16(i >> 2) + 4g + (i & 3): the
     // columns of the two float4 A loads of 16-column blocks 2J and 2J+1), split into three bf16 pieces, one 16-B LDS write per piece
-    constexpr int TOT = KB * 4 * Np, TR = (TOT + kFwdThreads - 1) / kFwdThreads;
-    float wv[TR][8];
-#pragma unroll
-    for (int i = 0; i < TR; ++i) {
-      const int idx = threadIdx.x + i * kFwdThreads;
-      const int idc = idx < TOT ? idx : 0;
-      const int Jg = idc / Np, n = idc - Jg * Np;
-      const int J = Jg >> 2, gg = Jg & 3;
-      const int nc = n < N ? n : N - 1;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = 32 * J + 16 * (q >> 2) + 4 * gg + (q & 3);
-        wv[i][q] = a.W[(k < K ? k : K - 1) * N + nc];
-      }
-    }
+    constexpr int TOT = TOTS, TR = TRS;
+    auto& wv = wv1;
 #pragma unroll
     for (int i = 0; i < TR; ++i) {
       const int idx = threadIdx.x + i * kFwdThreads;
@@ -629,12 +639,15 @@ static void launch_fwd_v(unsigned grid, size_t shmem, hipStream_t s, const FwdAr
 }
 // waves per SIMD of a forward launch: 2 (two tiles per wave, software-pipelined) once every wave of a one-workgroup-per-CU grid would
 // get two tiles anyway, else 4 (one tile per wave, more waves to hide latency); BR_FWD_WPS=2|4 forces one (experiments)
-static int fwd_wps(int64_t batch, bool vec, int KJ) {
+static int fwd_wps(int64_t batch, bool vec, int KJ, int NT, bool emu) {
   static const int forced = [] { const char* e = getenv("BR_FWD_WPS"); return e ? atoi(e) : 0; }();
   if (!vec) return 4;
   if (forced == 2 || forced == 4) return forced;
   // measured at batch 65 536: 128 x 100 36.2 -> 33.8 us with two pipelined tiles per wave, 100 x 50 23.0 -> 23.9 us (its loads are
   // short: the extra waves hide more than the prefetch does)
+  // bf16x6 with K > 64 and more than one pass of n-tiles (or a ragged one): the 4-waves form spills (128 x 100: 135 VGPRs; N = 49..64
+  // with its single full pass does not, and keeps the form that measured faster for 100 x 50)
+  if (emu && KJ >= 5 && NT >= 3 && NT != 4) return 2;
   return (KJ >= 8 && ceil_div(batch, (int64_t)16) >= (int64_t)2 * 256 * 8) ? 2 : 4;
 }
 
@@ -644,7 +657,7 @@ static void launch_fwd(size_t shmem_words_fixed, int Np, hipStream_t s, const Fw
   // or N floats are then padded to 4, and a 16-B access that starts inside a row stays inside its allocation)
   const bool vec = (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
                    (a.yin == nullptr || a.K % 4 == 0);
-  const int wps = fwd_wps(a.batch, vec, KJ);
+  const int wps = fwd_wps(a.batch, vec, KJ, NT, emu);
   const int waves = 4 * wps;
   const size_t shmem = (shmem_words_fixed + (size_t)waves * (wps == 2 ? 4 : 1) * 16 * kPatchLd + (size_t)waves * 2 * Np) * sizeof(float);
   const int64_t wgs = ceil_div(ceil_div(a.batch, (int64_t)16), (int64_t)waves);
