@@ -298,27 +298,52 @@ def twotower_leg(ops, dev, U, I, E, S, B, seed):
 _CURSOR = {}
 
 
-def run_steps(eng, batches, n, row0, batch_total, arm=None):
+_GROUPS = {}
+
+
+def make_groups(batches, S):
+    """the cycle's batches back to back in groups of S (what NeuMFEngine.train_steps stages with one launch); a cycle that S does not
+    divide keeps its last batches for single steps"""
+    g = [tuple(torch.cat([batches[c + k][j] for k in range(S)]) for j in range(3)) for c in range(0, len(batches) - len(batches) % S, S)]
+    _GROUPS[id(batches)] = (S, g)
+    return g
+
+
+def run_steps(eng, batches, n, row0, batch_total, arm=None, arm_group=None):
     """n steps over the batch cycle, CONTINUING where the last call on this cycle stopped: every leg of a run then sees batches in cycle
     order (restarting at batch 0 per call replayed the same ~20 batches in every leg - their rows came back with lags of a few steps
-    while the seeded long-run state of --steady-state-lags sat untouched in the rest of the table)."""
+    while the seeded long-run state of --steady-state-lags sat untouched in the rest of the table).
+    With a multi-step graph on the engine (enable_graph_multi) and the cycle grouped (make_groups), every run of S steps that starts on a
+    group boundary is ONE train_steps call; the steps in front of the first boundary and behind the last are single train_step calls."""
     nb = len(batches)
     c0 = _CURSOR.get(id(batches), 0)
     _CURSOR[id(batches)] = c0 + n
-    for s in range(n):
-        u, i, y = batches[(c0 + s) % nb]
+    gm = getattr(eng, "_graph_multi", None)
+    S, groups = _GROUPS.get(id(batches), (0, None))
+    use_groups = gm is not None and groups and gm["S"] == S and row0 == 0 and batch_total == batches[0][0].shape[0]
+    s = 0
+    while s < n:
+        c = (c0 + s) % nb
+        if use_groups and c % S == 0 and c // S < len(groups) and n - s >= S:
+            if arm_group is not None:
+                arm_group(s)    # chooses the probed or the plain capture for this group and arms the probed one's record nodes
+            eng.train_steps(*groups[c // S])
+            s += S
+            continue
+        u, i, y = batches[c]
         if arm is not None:
             arm(s)              # points the graph's event-record nodes at this replay's event pair (brProbeGraphArm)
         eng.train_step(u, i, y, row0=row0, batch_total=batch_total)
+        s += 1
 
 
-def timed(eng, batches, steps, warmup, ctx, row0, batch_total, arm=None):
+def timed(eng, batches, steps, warmup, ctx, row0, batch_total, arm=None, arm_group=None):
     run_steps(eng, batches, warmup, row0, batch_total)
     if ctx is not None:
         ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(eng, batches, steps, row0, batch_total, arm)
+    run_steps(eng, batches, steps, row0, batch_total, arm, arm_group)
     torch.cuda.synchronize()
     if ctx is not None:
         ctx.barrier()
@@ -381,6 +406,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the extra adam_lazy timing")
     ap.add_argument("--no-graph", action="store_true", help="single GPU: time the eager launch sequence instead of hipGraph replay")
+    ap.add_argument("--steps-per-launch", type=int, default=4,
+                    help="single GPU, graph mode: training steps captured per hipGraph launch (NeuMFEngine.enable_graph_multi; 1 = one graph launch per step, "
+                         "what rounds 1-2 timed)")
     ap.add_argument("--no-legs", action="store_true", help="skip the gather / Zipf / BPR / TwoTower legs")
     ap.add_argument("--cycle", type=int, default=256, help="distinct synthetic batches cycled (the tables are primed with one pass over them)")
     ap.add_argument("--profile-steps", type=int, default=10, help="graph mode: eager steps probed per kernel before the timed region")
@@ -569,13 +597,22 @@ def main():
         # (brProbeGraph*: a node per replay pointed at that replay's own event pair), so its duration is measured live in every step
         # Every record node is a barrier in the replayed graph (~7 us each, measured), so the timed region alternates two captures of
         # the same step: the plain graph, and every PROBE_EVERY-th step the one that carries the two nodes.
+        # Round 3: S = --steps-per-launch consecutive steps are ONE graph launch (NeuMFEngine.enable_graph_multi: the gap between two graph
+        # launches and the staging launch are paid once per S steps); the record nodes then sit around the LAST step's launch of every
+        # second group.
         PROBE_EVERY = 4
-        graph_exec = g_probe = g_plain = None
+        S_MULTI = args.steps_per_launch if (ctx is None and args.steps_per_launch > 1 and row0 == 0 and batch_total == B) else 1
+        graph_exec = g_probe = g_plain = gm_probe = gm_plain = None
         try:
-            lib.brProbeGraphSelect(TAG[dom_tag])
-            eng.enable_graph(B, keep_graph=True)
-            g_probe = eng._graph
-            gobj = g_probe["graphs"][0]
+            if S_MULTI > 1:
+                make_groups(batches, S_MULTI)
+                gm_probe = eng.enable_graph_multi(B, S_MULTI, keep_graph=True, probe_tag=TAG[dom_tag])
+                gobj = gm_probe["graph"]
+            else:
+                lib.brProbeGraphSelect(TAG[dom_tag])
+                eng.enable_graph(B, keep_graph=True)
+                g_probe = eng._graph
+                gobj = g_probe["graphs"][0]
             if lib.brProbeGraphNodes() > 0 and hasattr(gobj, "raw_cuda_graph_exec"):
                 graph_exec = ctypes.c_void_p(int(gobj.raw_cuda_graph_exec()))
                 if lib.brProbeGraphEnable(args.steps) != 0 or lib.brProbeGraphArm(graph_exec, 0) != 0:
@@ -585,7 +622,12 @@ def main():
             if graph_exec is None:
                 # no record nodes in this runtime: keep the dominant kernel between two graphs instead (graph A -> eager launch with
                 # events -> graph B), the round-1 arrangement
+                eng.disable_graph()
+                S_MULTI = 1
                 eng.enable_graph(B, eager_phases=SPEC[dom_tag][1])
+            elif S_MULTI > 1:
+                gm_plain = eng.enable_graph_multi(B, S_MULTI)
+                g_plain = eng._graph              # the single-step graph: steps off the group boundaries
             else:
                 eng.enable_graph(B)
                 g_plain = eng._graph
@@ -595,7 +637,33 @@ def main():
             eng.disable_graph()
             use_graph = False
             graph_error = f"{type(exc).__name__}: {exc}"
-    if use_graph and graph_exec is not None:
+    if use_graph and graph_exec is not None and S_MULTI > 1:
+        probed, seen = [], [0]
+
+        def arm_group(k):
+            if seen[0] % 2 == 0:
+                if lib.brProbeGraphArm(graph_exec, seen[0]) != 0:
+                    raise RuntimeError(lib.brGetLastError().decode())
+                eng._graph_multi = gm_probe
+                probed.append(seen[0])
+            else:
+                eng._graph_multi = gm_plain
+            seen[0] += 1
+        eng._graph = g_plain
+        dt = timed(eng, batches, args.steps, 0, ctx, row0, batch_total, None, arm_group)
+        eng._graph_multi = gm_plain
+        ms, tot = ctypes.c_float(), 0.0
+        for k in probed:
+            if lib.brProbeGraphRead(k, ctypes.byref(ms)) != 0:
+                raise RuntimeError(lib.brGetLastError().decode())
+            tot += ms.value
+        if probed:
+            per_tag[TAG[dom_tag]] = (tot / len(probed) * 1e3, len(probed))
+        probe_src = {t: ((f"timed region: event-record nodes inside the replayed graph around the last step of every 2nd group of {S_MULTI} steps "
+                          f"({len(probed)} samples in {args.steps} steps)", len(probed))
+                         if (t == TAG[dom_tag] and probed) else ("eager profiling pass", np_)) for t in per_tag}
+        lib.brProbeGraphEnable(0)
+    elif use_graph and graph_exec is not None:
         probed = [k for k in range(args.steps) if k % PROBE_EVERY == 0]
 
         def arm(k):
@@ -699,10 +767,21 @@ def main():
     if use_graph:
         # the same graph without the two event-record nodes (what a training loop runs)
         try:
-            eng.enable_graph(B)
+            if S_MULTI > 1:
+                eng._graph_multi = gm_plain
+                eng._graph = g_plain
+            else:
+                eng.enable_graph(B)
             dtg = timed(eng, batches, args.steps, args.warmup, ctx, row0, batch_total)
-            full_graph = {"value": B * args.steps / dtg, "unit": "pairs/s", "ms_per_step": dtg / args.steps * 1e3}
+            full_graph = {"value": B * args.steps / dtg, "unit": "pairs/s", "ms_per_step": dtg / args.steps * 1e3, "steps_per_graph_launch": S_MULTI}
             log(f"whole-step graph: {dtg / args.steps * 1e3:.3f} ms/step")
+            if S_MULTI > 1:
+                # one graph launch per step, as rounds 1-2 timed it
+                eng._graph_multi = None
+                dt1 = timed(eng, batches, args.steps, args.warmup, ctx, row0, batch_total)
+                full_graph["one_step_per_launch"] = {"value": B * args.steps / dt1, "unit": "pairs/s", "ms_per_step": dt1 / args.steps * 1e3}
+                log(f"whole-step graph, one step per launch: {dt1 / args.steps * 1e3:.3f} ms/step")
+                eng._graph_multi = gm_plain
         except Exception as exc:  # noqa: BLE001
             log(f"whole-step graph leg failed: {exc}")
             eng.disable_graph()
@@ -803,10 +882,13 @@ def main():
                                    f"embed_dim={D}, {args.users} users x {args.items} items per GPU, batch {B} per GPU, "
                                    f"{'Zipf(1.05)' if args.zipf else 'uniform'} ids",
                        "global_batch": batch_total, "parallelism": "single GPU" if ctx is None else f"row-sharded tables x{world} + dp{world}, {'global' if args.sync_bn else 'per-replica'} BatchNorm",
+                       "steps_per_graph_launch": (S_MULTI if use_graph else None),
                        "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
             "roofline": roofline, "cpu_baseline": cpu, "legs": legs, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
             "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i}, "steady_state_lags": seeded,
-            "launch_mode": ((f"hipGraph replay of the whole step, one graph per step; {dom_key} bracketed by event-record nodes inside every 4th replay (a HIP event pair each)"
+            "launch_mode": ((((f"hipGraph replay, {S_MULTI} consecutive steps per graph launch (NeuMFEngine.enable_graph_multi; the group's ids / labels staged by one launch); "
+                              f"{dom_key} bracketed by event-record nodes around the last step of every 2nd group (a HIP event pair each)") if S_MULTI > 1 else
+                             f"hipGraph replay of the whole step, one graph per step; {dom_key} bracketed by event-record nodes inside every 4th replay (a HIP event pair each)")
                              if graph_exec is not None else f"hipGraph replay (graph A -> eager {dom_key} with HIP events -> graph B)") if use_graph
                             else (("sharded step incl. its RCCL collectives as one hipGraph per step" if sharded_graph is not None and sharded_graph.graph_active
                                    else "eager launches (brNeumfStepRun phases + torch.distributed collectives)" + (f" [graph refused: {sharded_graph._sgraph['refused']}]" if sharded_graph is not None and sharded_graph._sgraph else ""))

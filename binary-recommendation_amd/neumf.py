@@ -286,6 +286,7 @@ class NeuMFEngine:
         PH = self.PH = {k[6:]: v for k, v in _lib.parse_enums().items() if k.startswith("BR_PH_")}
         PH["OPT_ROWS"] = PH["ROWS_USER"] | PH["SWEEP_USER"] | PH["ROWS_ITEM"] | PH["SWEEP_ITEM"]
         self._graph = None
+        self._graph_multi = None
 
     def _bind_indexes(self, st):
         ui, ii = self.user_index, self.item_index
@@ -481,6 +482,73 @@ class NeuMFEngine:
 
     def disable_graph(self):
         self._graph = None
+        self._graph_multi = None
+
+    def enable_graph_multi(self, batch: int | None = None, steps: int = 4, keep_graph: bool = False, probe_tag: int | None = None):
+        """Capture `steps` consecutive training steps as ONE hipGraph (`train_steps` replays it): a training loop whose batches are already
+        on the device - `fit()` over resident arrays, bench.py - then pays the per-launch costs of a graph (the gap between two graph
+        launches, ~8 us here, and the staging launch) once per `steps` steps instead of once per step.  Everything that differs between
+        the steps of a group lives on the device (step counter, alpha_t, the alpha ring, the dropout planes the previous step's
+        Adam-rows launch prefetched); the group's ids / labels are staged by one brStageBatch launch into static buffers of `steps`
+        batches.  Needs the single-step graph (captured here if absent: it runs the dry step that loads every code object).
+        probe_tag: bench.py's measurement - only the LAST step of the group carries the event-record nodes around that kernel."""
+        S = int(steps)
+        if S < 2:
+            raise ValueError("enable_graph_multi: steps >= 2 (enable_graph is the single-step form)")
+        B = self.max_batch if batch is None else int(batch)
+        if self._graph is None or self._graph["batch"] != B or len(self._graph["graphs"]) != 1 or self._graph["graphs"][0] is None:
+            self.enable_graph(B)
+        dev, st, PH = self.device, self.step_struct, self.PH
+        gm = getattr(self, "_graph_multi", None)
+        if gm is None or gm["S"] != S or gm["batch"] != B:
+            self.in_users_m = torch.zeros(S * B, dtype=self.id_dtype, device=dev)
+            self.in_items_m = torch.zeros(S * B, dtype=self.id_dtype, device=dev)
+            self.in_labels_m = torch.zeros(S * B, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                for k in range(S):
+                    sl = slice(k * B, (k + 1) * B)
+                    self._set_batch(self.in_users_m[sl], self.in_items_m[sl], self.in_labels_m[sl], B, True, 0, B)
+                    st.keep_ready = 1 if st.keep_prefetch else 0
+                    if probe_tag is not None and k == S - 1:
+                        lib.brProbeGraphSelect(int(probe_tag))
+                    self._run(PH["ALL"])
+        finally:
+            if probe_tag is not None:
+                lib.brProbeGraphSelect(-1)
+        if keep_graph:
+            g.instantiate()
+        self._set_batch(self.in_users, self.in_items, self.in_labels, B, True, 0, B)     # the single-step graph's view of the step struct
+        st.keep_ready = 1 if st.keep_prefetch else 0
+        self._graph_multi = {"S": S, "batch": B, "graph": g}
+        return self._graph_multi
+
+    def train_steps(self, users, items, labels):
+        """`steps` training steps in one graph launch (enable_graph_multi): users / items / labels hold the group's batches back to back,
+        (steps * batch,) or (steps, batch), contiguous device tensors.  Equal to `steps` calls of train_step on the slices."""
+        gm = getattr(self, "_graph_multi", None)
+        if gm is None:
+            raise RuntimeError("train_steps: enable_graph_multi first")
+        S, B = gm["S"], gm["batch"]
+        if users.numel() != S * B or items.numel() != S * B or labels.numel() != S * B:
+            raise ValueError(f"train_steps: {S} batches of {B} pairs expected")
+        self._check_batch(users, items, labels)
+        cfg = self.cfg
+        if self.deferred:
+            if self.t + S - self._flush_t >= self.ALPHA_RING - 8:      # the replay reads alpha_j from a ring
+                self.flush()
+            self._stale = True
+        if users.data_ptr() != self.in_users_m.data_ptr() or items.data_ptr() != self.in_items_m.data_ptr() or labels.data_ptr() != self.in_labels_m.data_ptr():
+            _lib.check(_lib.load().brStageBatch(self.in_users_m.data_ptr(), self.in_items_m.data_ptr(), self.in_labels_m.data_ptr(), users.data_ptr(),
+                                                items.data_ptr(), labels.data_ptr(), self.step_struct.id_type, S * B, ops._stream()), "brStageBatch")
+        prefetching = cfg.dropout > 0 and self.step_struct.aux_stream
+        if prefetching and self._keep_for != (self.t + 1, 0):
+            ops.dropout_keep_bits(cfg.dropout, cfg.seed, self.t + 1, 0, self.max_batch, (0, 1, 2), self._keep_widths, self._keep_planes)
+        self.t += S
+        gm["graph"].replay()
+        self._keep_for = (self.t + 1, 0) if prefetching else None
 
     def _snapshot_for_dry_run(self):
         """what enable_graph's dry-run step can change.  Per-step sweep: every table row moves, so the whole (flushed) state.  Deferred /

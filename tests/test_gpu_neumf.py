@@ -228,6 +228,46 @@ def test_graph_replay_matches_eager_steps(dev, optimizer, impl, eager):
     _close(gr.msums.sum(0).cpu().numpy(), eg.msums.sum(0).cpu().numpy(), "metric sums", rtol=1e-6)
 
 
+def test_multi_step_graph_equals_single_step_graph(dev):
+    """NeuMFEngine.enable_graph_multi / train_steps: four steps captured as ONE hipGraph against the same four steps replayed one graph
+    launch each - the same kernels on the same device-side step state, so every table, moment, dense parameter, moving statistic and
+    metric sum must be BIT-equal; a single step and a reload sit between the groups (the device step counter and the prefetched dropout
+    planes must carry over in both directions)."""
+    B, S = 192, 4
+    ops, one, spec, cfg, p, u, i, y = _setup("A", 64, B, dev, optimizer="adam_dense")
+    _, grp, *_ = _setup("A", 64, B, dev, optimizer="adam_dense")
+    one.enable_graph(B)
+    grp.enable_graph_multi(B, steps=S)
+    rng = np.random.default_rng(23)
+    td = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
+
+    def group():
+        uu, ii = rng.integers(0, 97, (S, B)), rng.integers(0, 53, (S, B))
+        yy = (rng.random((S, B)) < 0.3).astype(np.float32)
+        for k in range(S):
+            one.train_step(td(uu[k], torch.int32), td(ii[k], torch.int32), td(yy[k], torch.float32))
+        grp.train_steps(td(uu, torch.int32), td(ii, torch.int32), td(yy, torch.float32))
+
+    group()
+    uu, ii, yy = rng.integers(0, 97, B), rng.integers(0, 53, B), (rng.random(B) < 0.3).astype(np.float32)
+    for e in (one, grp):
+        e.train_step(td(uu, torch.int32), td(ii, torch.int32), td(yy, torch.float32))
+    group()
+    grp.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in grp.state_dict().items()})
+    one.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in one.state_dict().items()})
+    group()
+    torch.cuda.synchronize()
+    grp.check_ids()
+    assert grp.t == one.t == 3 * S + 1 and int(grp.step_state[0].item()) == grp.t
+    grp.flush(); one.flush()
+    for k in ("user", "item"):
+        assert torch.equal(grp.fused[k], one.fused[k]), "table " + k
+        assert torch.equal(grp.fused_m[k], one.fused_m[k]) and torch.equal(grp.fused_v[k], one.fused_v[k]), "moments " + k
+    assert torch.equal(grp.theta.buf, one.theta.buf) and torch.equal(grp.adam_v.buf, one.adam_v.buf)
+    assert torch.equal(grp.moving_buf, one.moving_buf)
+    assert torch.equal(grp.msums.sum(0), one.msums.sum(0))
+
+
 def test_graph_replay_against_oracle(dev):
     """Three replayed steps against the oracle (dropout masks keyed by the DEVICE step counter, alpha_t
     computed on the device); same bounds as test_three_optimizer_steps."""
