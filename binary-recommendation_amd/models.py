@@ -136,8 +136,18 @@ class KerasLikeNeuMF:
                 uu, ii, ll = u[perm], i[perm], yy[perm]
             else:
                 uu, ii, ll = u, i, yy
-            for lo, hi, row0, bt in slices:
+            gm = getattr(e, "_graph_multi", None) if ctx is None else None
+            k = 0
+            while k < len(slices):
+                lo, hi, row0, bt = slices[k]
+                # engine.enable_graph_multi(batch_size, S): S consecutive full batches of the (contiguous) epoch order are one graph launch
+                if gm is not None and gm["batch"] == bs and k + gm["S"] <= len(slices) and slices[k + gm["S"] - 1][1] - lo == gm["S"] * bs:
+                    end = lo + gm["S"] * bs
+                    e.train_steps(uu[lo:end], ii[lo:end], ll[lo:end])
+                    k += gm["S"]
+                    continue
                 e.train_step(uu[lo:hi], ii[lo:hi], ll[lo:hi], row0=row0, batch_total=bt)
+                k += 1
             e.check_ids()
             if ctx is not None:
                 ctx.all_reduce_sum(e.msums)          # the epoch's metric sums of all replicas (a collective: every rank runs fit)

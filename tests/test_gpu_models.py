@@ -59,6 +59,27 @@ def test_keras_like_fit_learns_and_evaluates(dev):
         model.fit([np.array([0, 500], np.int32), np.array([0, 1], np.int32)], np.array([1.0, 0.0], np.float32), batch_size=2)
 
 
+def test_fit_with_the_multi_step_graph_equals_fit_with_single_step_graphs(dev):
+    """KerasLikeNeuMF.fit over an epoch order of full batches + a ragged tail: with engine.enable_graph_multi (4 consecutive batches per
+    graph launch) the history and every parameter equal, bit for bit, the run that replays one graph per step (NFC_plain.py:165)."""
+    models, neumf, data = _m("models"), _m("neumf"), _m("data")
+    u, i = _toy(3, n=3000)
+    U, I, Y = data.bootstrap_dataset(u, i, neg_ratio=3.0, seed=4)              # 12 000 samples: 11 full batches of 1 024 + a tail
+    out = []
+    for multi in (False, True):
+        eng = neumf.NeuMFEngine(neumf.NeuMFConfig("A", dim=16), 121, 81, dev, max_batch=1024)
+        if multi:
+            eng.enable_graph_multi(1024, steps=4)
+        else:
+            eng.enable_graph(1024)
+        h = models.KerasLikeNeuMF(eng).fit([U, I], Y, epochs=2, batch_size=1024, shuffle=True, seed=9)
+        eng.flush()
+        out.append((h.history["loss"], eng.fused["user"].clone(), eng.fused["item"].clone(), eng.theta.buf.clone(), eng.t))
+    (l0, u0, i0, t0, n0), (l1, u1, i1, t1, n1) = out
+    assert n0 == n1 == 2 * 12 and l0 == l1
+    assert torch.equal(u0, u1) and torch.equal(i0, i1) and torch.equal(t0, t1)
+
+
 def test_bpr_model_fit(dev):
     models = _m("models")
     u, i = _toy(3)
