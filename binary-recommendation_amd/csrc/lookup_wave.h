@@ -66,6 +66,74 @@ __device__ __forceinline__ void lookup_wave_pair(const LookupArgs& a, int64_t b,
   if (lane == 63) a.dot[b] = s;
 }
 
+// R consecutive pairs by one wave: every id, then every last[], then every row load of the 2 R rows is requested before the first replay
+// (see gather_deferred_wave_rows below for why).  Pairs past the batch are skipped.  Same arithmetic per pair as lookup_wave_pair.
+template <typename IdT, int VEC, int R>
+__device__ __forceinline__ void lookup_wave_pairs(const LookupArgs& a, int64_t b0, int lane) {
+  using V = typename VecT<VEC>::type;
+  constexpr int dim = 32 * VEC;
+  constexpr int64_t ld = 2 * dim;
+  const float* __restrict__ user_tab = a.user_tab; const float* __restrict__ item_tab = a.item_tab;
+  const StepStateDev* __restrict__ ss = a.ss;
+  const int col = lane * VEC;
+  const uint32_t t = ss->step + a.step_add;
+  int64_t u[R], i[R], bq[R];
+  bool live[R], uok[R], iok[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    live[q] = b0 + q < a.batch;
+    bq[q] = live[q] ? b0 + q : a.batch - 1;
+    u[q] = load_id((const IdT*)a.users, bq[q]); i[q] = load_id((const IdT*)a.items, bq[q]);
+  }
+  uint32_t lu[R], li[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    uok[q] = (uint64_t)u[q] < (uint64_t)a.user_rows; iok[q] = (uint64_t)i[q] < (uint64_t)a.item_rows;
+    if ((!uok[q] || !iok[q]) && a.err && lane == 0 && live[q]) *a.err = 1;
+    if (!uok[q]) u[q] = 0;
+    if (!iok[q]) i[q] = 0;
+    lu[q] = (uint32_t)a.user_last[u[q]]; li[q] = (uint32_t)a.item_last[i[q]];
+  }
+  V ur[R], ir[R], um[R], uv[R], im[R], iv[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int64_t uo = u[q] * ld + col, io = i[q] * ld + col;
+    ur[q] = vload<VEC>(user_tab + uo); ir[q] = vload<VEC>(item_tab + io);
+    um[q] = vzero<VEC>(); uv[q] = vzero<VEC>(); im[q] = vzero<VEC>(); iv[q] = vzero<VEC>();
+    if (lu[q] + 1 < t) { um[q] = vload<VEC>(a.user_m + uo); uv[q] = vload<VEC>(a.user_v + uo); }
+    if (li[q] + 1 < t) { im[q] = vload<VEC>(a.item_m + io); iv[q] = vload<VEC>(a.item_v + io); }
+  }
+  const bool mlp = lane < 32;
+  const int uoff = a.item_first ? dim : 0, ioff = a.item_first ? 0 : dim;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (li[q] + 1 < t) adam_catch_up_uniform<false>(ir[q], im[q], iv[q], li[q], t - 1, ss, a.h);
+    if (lu[q] + 1 < t) adam_catch_up_uniform<false>(ur[q], um[q], uv[q], lu[q], t - 1, ss, a.h);
+    if (!uok[q]) ur[q] = vzero<VEC>();
+    if (!iok[q]) ir[q] = vzero<VEC>();
+    if (!live[q]) continue;
+    const int64_t b = bq[q];
+    vstore<VEC>(mlp ? a.x0 + b * ld + uoff + col : a.stash_user + b * a.ld_stash + (col - dim), ur[q]);
+    vstore<VEC>(mlp ? a.x0 + b * ld + ioff + col : a.stash_item + b * a.ld_stash + (col - dim), ir[q]);
+    float s;
+    if constexpr (VEC == 4) {
+      s = 0.f + vdot(ur[q], ir[q]);
+      s += __shfl_xor(s, 16, 64);
+    } else {
+      static_assert(VEC == 2 || VEC == 4, "wave lookup: embed_dim 64 or 128");
+      const float e = __builtin_fmaf(ur[q].y, ir[q].y, ur[q].x * ir[q].x);
+      const float prev = __shfl_up(e, 1, 64);
+      s = 0.f + __builtin_fmaf(ur[q].y, ir[q].y, __builtin_fmaf(ur[q].x, ir[q].x, prev));
+      s += __shfl_xor(s, 16, 64);
+    }
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    if constexpr (VEC == 4) s += __shfl_xor(s, 1, 64);
+    if (lane == 63) a.dot[b] = s;
+  }
+}
+
 // one row of a deferred table by one wave (rows of 64 * VEC floats): out[p] = row ids[p] as of step - 1, p = the physical position of
 // logical position b (segmented id arrays: common.h seg_phys)
 struct GatherDefJob { const float* table; const float* M; const float* Vv; const int32_t* last; int64_t rows; const void* ids; float* out; int64_t n; int64_t seg_off = 0; };

@@ -735,16 +735,22 @@ __global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, 
 // 16 pairs that flow around them.  As a launch of their own on a side stream the sorts needed a fork and a join in the step's
 // hipGraph (~10 us each on the main branch, ROCm 7.2) and stretched the lookup they ran beside; the chunk-rank launch follows on the
 // same stream.  LDS: the sort's image is reserved by every workgroup (two per CU = 32 waves: the lookup's full occupancy anyway).
-template <typename IdT, int VEC>
+template <typename IdT, int VEC, int R>
 __global__ __launch_bounds__(kThreadsL) void lookup_sort_kernel(const LookupArgs a, IdxJobs jobs, int64_t n, int n_chunks) {
   const int n_sort = 2 * n_chunks;
   if ((int)blockIdx.x < n_sort) {
     chunk_sort_block<IdT, kChunkL, kThreadsL>(jobs, n, (int)blockIdx.x % n_chunks, (int)blockIdx.x / n_chunks);
     return;
   }
-  const int64_t b = ((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t b = (((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * R;
   if (b >= a.batch) return;
-  lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
+  if constexpr (R == 1) lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
+  else lookup_wave_pairs<IdT, VEC, R>(a, b, (int)(threadIdx.x & 63));
+}
+// pairs per wave of the fused lookup (BR_LOOKUP_PAIRS=1|2; experiments)
+static int lookup_pairs_per_wave() {
+  static const int r = [] { const char* e = getenv("BR_LOOKUP_PAIRS"); const int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();
+  return r;
 }
 
 // Two deferred gathers of one row width (rows of 64 * VEC floats, one wave per row) and the chunk sorts of their two id streams in ONE
@@ -960,11 +966,19 @@ int br::lookup_with_index(const LookupArgs& la, int dim, int id_type, const Inde
   jobs.j[0] = make_job(la.users, ix.sorted_ids_a, ix.sorted_pos_a, ix.ws_a, n, la.user_rows);
   jobs.j[1] = make_job(la.items, ix.sorted_ids_b, ix.sorted_pos_b, ix.ws_b, n, la.item_rows);
   const int n_chunks = (int)ceil_div(n, kChunkL);
-  const unsigned grid = (unsigned)(2 * n_chunks + ceil_div(n, kThreadsL / 64));
   hipStream_t s = (hipStream_t)stream;
   const int wvec = dim / 32;
-  if (id_type == BR_IDS_I32) { if (wvec == 2) lookup_sort_kernel<int32_t, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); else lookup_sort_kernel<int32_t, 4><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); }
-  else { if (wvec == 2) lookup_sort_kernel<int64_t, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); else lookup_sort_kernel<int64_t, 4><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks); }
+  const int ppw = wvec == 2 ? lookup_pairs_per_wave() : 1;
+  const unsigned grid = (unsigned)(2 * n_chunks + ceil_div(ceil_div(n, (int64_t)ppw), (int64_t)(kThreadsL / 64)));
+  if (id_type == BR_IDS_I32) {
+    if (wvec == 2 && ppw == 2) lookup_sort_kernel<int32_t, 2, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    else if (wvec == 2) lookup_sort_kernel<int32_t, 2, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    else lookup_sort_kernel<int32_t, 4, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+  } else {
+    if (wvec == 2 && ppw == 2) lookup_sort_kernel<int64_t, 2, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    else if (wvec == 2) lookup_sort_kernel<int64_t, 2, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    else lookup_sort_kernel<int64_t, 4, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+  }
   BR_CHECK_LAUNCH("lookup_with_index(lookup + sort)");
   probe_split(BR_TAG_EMBED_FWD, s);
   const StepAdvance av = adv ? *adv : StepAdvance{};
