@@ -64,12 +64,18 @@ __device__ __forceinline__ int bwd_swz(int col16, int row_quad) { return (((col1
 // The dz arithmetic, the dx epilogue and the slab layout are the fp32 kernel's, line for line.
 template <int NT, int KT>
 constexpr size_t bwd_emu_wp_floats() { return (size_t)(NT / 2) * 3 * 4 * (KT * 16) * 4 + (size_t)(NT & 1) * 3 * 4 * (KT * 16) * 2; }
-constexpr int kZpTile = 2 * 3 * 4 * 16 * 4;               // floats of one n-tile of Zp (6 KB)
-constexpr size_t bwd_emu_lds(int NT, int KT) {
+// Zp: per (n-tile, 32-row block, piece) four lane groups g of 16 fragments x 16 B.  The g stride is 17 slots where the LDS has room for it
+// (all shapes but N > 112 with K > 96): the dx waves publish element by element, lanes (row & 3) -> g, and with a 256-B stride their four
+// groups hit the same banks (rocprofv3: 35 % of the 128 x 100 backward's LDS cycles were conflict cycles); the dW waves' 16-B fragment reads
+// are contiguous per group either way.
+constexpr int bwd_zp_tile(int zg) { return 2 * 3 * 4 * zg * 4; }       // floats of one n-tile of Zp (6 KB at zg = 16)
+constexpr size_t bwd_emu_lds_zg(int NT, int KT, int zg) {
   const size_t Np = NT * 16, Kp = KT * 16;
-  return sizeof(float) * ((size_t)(NT / 2) * 3 * 4 * Kp * 4 + (size_t)(NT & 1) * 3 * 4 * Kp * 2 + 4 * Np + 4 * Kp + (size_t)NT * kZpTile +
+  return sizeof(float) * ((size_t)(NT / 2) * 3 * 4 * Kp * 4 + (size_t)(NT & 1) * 3 * 4 * Kp * 2 + 4 * Np + 4 * Kp + (size_t)NT * bwd_zp_tile(zg) +
                           4 * 2 * 32 * 16 + 4 * 16 * (size_t)kBwdPatchLd) + sizeof(double) * 2 * Kp;
 }
+constexpr int bwd_zg(int NT, int KT) { return bwd_emu_lds_zg(NT, KT, 17) <= 160 * 1024 ? 17 : 16; }
+constexpr size_t bwd_emu_lds(int NT, int KT) { return bwd_emu_lds_zg(NT, KT, bwd_zg(NT, KT)); }
 constexpr bool bwd_emu_fits(int NT, int KT) { return bwd_emu_lds(NT, KT) <= 160 * 1024; }
 
 template <int NT, int KT, bool IBN, bool EMU>
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
   constexpr int KW = (KT + 1) / 2;                      // keep words per row
   constexpr int NBF = NT / 2, NB = (NT + 1) / 2;        // full 32-deep n-blocks of the dx product / all of them (an odd NT ends in a half block)
   constexpr int kWsFloats = EMU ? (int)bwd_emu_wp_floats<NT, KT>() : Kp * ldw;
+  constexpr int ZG = bwd_zg(NT, KT), kZpTile = bwd_zp_tile(ZG);
   float* Ws = smem;                                     // fp32: [Kp][ldw] W row-major, zero padded.  EMU: the piece image Wp
   float* Cs = Ws + kWsFloats;                           // [4][Np]     out-BN constants
   float* Is = Cs + 4 * Np;                              // [mean Kp | rstd Kp] of the in BN
@@ -324,17 +331,17 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
         // ... and published element by element for the dW waves: element (row r = 16 rt + c16, column n = 16 j + 4 g + e), piece p ->
         // Zp[j][b = r >> 5][p][r & 3][n & 15] half-word (r >> 2) & 7.  Per lane a base + compile-time offsets; the low / high half of a packed
         // pair goes out with ds_write_b16 / ds_write_b16_d16_hi (no VALU).
-        uint16_t* zp = reinterpret_cast<uint16_t*>(Zs) + (rt >> 1) * (3 * 4 * 16 * 8) + (((c16 & 3) * 16 + 4 * g) << 3) + 4 * (rt & 1) + (c16 >> 2);
+        uint16_t* zp = reinterpret_cast<uint16_t*>(Zs) + (rt >> 1) * (3 * 4 * ZG * 8) + (((c16 & 3) * ZG + 4 * g) << 3) + 4 * (rt & 1) + (c16 >> 2);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int J = j >> 1, d = 2 * (j & 1) + (e >> 1);
-            uint16_t* q = zp + j * (2 * 3 * 4 * 16 * 8) + e * 8;
+            uint16_t* q = zp + j * (2 * 3 * 4 * ZG * 8) + e * 8;
             const uint32_t vh = ah[J][d], vm = am[J][d], vl = al[J][d];
             q[0] = (uint16_t)((e & 1) ? (vh >> 16) : (vh & 0xffffu));
-            q[4 * 16 * 8] = (uint16_t)((e & 1) ? (vm >> 16) : (vm & 0xffffu));
-            q[2 * 4 * 16 * 8] = (uint16_t)((e & 1) ? (vl >> 16) : (vl & 0xffffu));
+            q[4 * ZG * 8] = (uint16_t)((e & 1) ? (vm >> 16) : (vm & 0xffffu));
+            q[2 * 4 * ZG * 8] = (uint16_t)((e & 1) ? (vl >> 16) : (vl & 0xffffu));
           }
         }
         __syncthreads();                                 // A_it: dz(it) is visible to them
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
     const uint32_t ones2 = 0x3F803F80u;
     const uint32_t ones4[4] = {ones2, ones2, ones2, ones2};
     const bf16x8 ones = frag8(ones4);
-    const float* zl = Zs + ((g * 16 + c16) << 2);        // + (((nt * 2 + b) * 3 + p) * 4 * 16) * 4
+    const float* zl = Zs + ((g * ZG + c16) << 2);        // + (((nt * 2 + b) * 3 + p) * 4 * ZG) * 4
     int it = 0;
     for (; tile < n_tiles; tile += gridDim.x, ++it) {
       const bool has_next = tile + gridDim.x < n_tiles;                      // wave-uniform
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
       {
         float4 bq[2][3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const float4*>(zl + ((p * 4 * 16) << 2));
+        for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const float4*>(zl + ((p * 4 * ZG) << 2));
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const bf16x8 a0h = frag8(xh[0][b]), a0m = frag8(xm[0][b]), a0l = frag8(xl[0][b]);
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(kBwdThreads, EMU ? 1 : 2) void dense_bwd_kernel(con
             const int bn = (nt + 1 < NT) ? b : b + 1, ntn = (nt + 1 < NT) ? nt + 1 : 0;
             if (bn < 2) {
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bq[cur ^ 1][p] = *reinterpret_cast<const float4*>(zl + ((((ntn * 2 + bn) * 3 + p) * 4 * 16) << 2));
+              for (int p = 0; p < 3; ++p) bq[cur ^ 1][p] = *reinterpret_cast<const float4*>(zl + ((((ntn * 2 + bn) * 3 + p) * 4 * ZG) << 2));
             }
             const bf16x8 wh = frag8(bq[cur][0]), wm = frag8(bq[cur][1]), wl = frag8(bq[cur][2]);
             if (q_live) {

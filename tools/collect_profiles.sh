@@ -3,7 +3,7 @@
 # cannot share a pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots") of the default bench workload.
 # Outputs land in $GRAFT_REPO_ROOT/gpurun_out/prof_<tag>/ ; tools/summarize_profile.py turns them into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
