@@ -339,6 +339,10 @@ def run_steps(eng, batches, n, row0, batch_total, arm=None, arm_group=None):
 
 def timed(eng, batches, steps, warmup, ctx, row0, batch_total, arm=None, arm_group=None):
     run_steps(eng, batches, warmup, row0, batch_total)
+    S, groups = _GROUPS.get(id(batches), (0, None))
+    if groups and getattr(eng, "_graph_multi", None) is not None:
+        # start the timed region on a group boundary of the batch cycle (a few more untimed steps): K timed steps are then K // S graph launches
+        run_steps(eng, batches, (-_CURSOR.get(id(batches), 0)) % S, row0, batch_total)
     if ctx is not None:
         ctx.barrier()
     torch.cuda.synchronize()
