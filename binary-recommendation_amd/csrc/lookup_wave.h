@@ -4,6 +4,7 @@
 #include "common.h"
 #include "rows.h"
 #include "adam_math.h"
+#include <stdlib.h>
 
 namespace br {
 
@@ -16,7 +17,17 @@ struct LookupArgs {
   const StepStateDev* ss; AdamHp h;
   float *x0, *dot, *stash_user, *stash_item; int64_t ld_stash; int* err;
   uint32_t step_add = 0;      // 1: the step state is advanced BEHIND this launch (by the chunk-rank launch): the step being computed is ss->step + 1
+  // bit 0 / bit 1: request the user / item row's m and v TOGETHER with theta instead of behind last[] (lookup_spec()): a row that
+  // turns out to need no replay wasted 2 row reads, every other row saved one of its three dependent round trips
+  uint32_t spec = 0;
 };
+// which streams of the deferred lookup load m / v speculatively: BR_LOOKUP_SPEC = 0 (default) | 1 (users) | 2 (items) | 3 (both).  Measured at
+// config 2 (94 % of the user rows lag): 69-70 us with and without - like two pairs per wave (BR_LOOKUP_PAIRS=2), it does not move the launch:
+// neither the dependent round trips nor the bytes in flight per wave bound it.
+static inline uint32_t lookup_spec(int64_t, int64_t, int64_t) {
+  static const int forced = [] { const char* e = getenv("BR_LOOKUP_SPEC"); return e ? atoi(e) : 0; }();
+  return (uint32_t)forced & 3u;
+}
 
 // pair b (wave-uniform) of embed_dim = 32 * VEC: a lane owns VEC columns of the fused user row and the same columns of the item row
 template <typename IdT, int VEC>
@@ -37,8 +48,8 @@ __device__ __forceinline__ void lookup_wave_pair(const LookupArgs& a, int64_t b,
   const int64_t uo = u * ld + col, io = i * ld + col;
   V ur = vload<VEC>(user_tab + uo), ir = vload<VEC>(item_tab + io);
   V um = vzero<VEC>(), uv = vzero<VEC>(), im = vzero<VEC>(), iv = vzero<VEC>();
-  if (lu + 1 < t) { um = vload<VEC>(a.user_m + uo); uv = vload<VEC>(a.user_v + uo); }
-  if (li + 1 < t) { im = vload<VEC>(a.item_m + io); iv = vload<VEC>(a.item_v + io); }
+  if ((a.spec & 1u) || lu + 1 < t) { um = vload<VEC>(a.user_m + uo); uv = vload<VEC>(a.user_v + uo); }
+  if ((a.spec & 2u) || li + 1 < t) { im = vload<VEC>(a.item_m + io); iv = vload<VEC>(a.item_v + io); }
   if (li + 1 < t) adam_catch_up_uniform<false>(ir, im, iv, li, t - 1, ss, a.h);
   if (lu + 1 < t) adam_catch_up_uniform<false>(ur, um, uv, lu, t - 1, ss, a.h);
   if (!uok) ur = vzero<VEC>();

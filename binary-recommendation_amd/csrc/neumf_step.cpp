@@ -311,6 +311,7 @@ static int step_run_impl(const brNeumfStep* s, uint32_t ph, brStream stream) {
                               s->g_user + D, s->g_item + D, 2 * D, s->err_flag};
       const br::IndexPairArgs ix{s->u_sorted_ids, s->u_sorted_pos, s->u_ws, s->u_ws_bytes, s->i_sorted_ids, s->i_sorted_pos, s->i_ws, s->i_ws_bytes};
       br::LookupArgs la2 = la;
+      la2.spec = br::lookup_spec(s->user_rows, s->item_rows, B);
       br::StepAdvance adv;
       if (defer_advance) {
         la2.step_add = 1;
