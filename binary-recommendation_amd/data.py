@@ -71,7 +71,11 @@ def generate_negative_feedback(users, items, n_users, n_items, size, seed=0, dev
     """generateNegativeFeedback (synthetic.py:237-256) on the device (csrc/sampling.hip): `size` DISTINCT (user,item) pairs
     outside the positives; customers and products are drawn by shuffling the two columns of the data independently, round
     after round (generateSyntethic, synthetic.py:208-223).  -> (users, items) numpy int32.
-    oracle/binrec_oracle.py::ncf_negatives restates it bit for bit."""
+    oracle/binrec_oracle.py::ncf_negatives restates it bit for bit.
+    Deviations from the reference's pandas code (same marginals, not the same sample): the reference reshuffles the GROWING frame of
+    negatives each round and `drop_duplicates(keep=False)` removes every copy of a pair that came up twice; here the candidates of all
+    rounds are independent shuffles of the two columns, duplicates keep ONE copy (sort + unique) and positives are rejected against the
+    customer's CSR.  The reference's exact frame depends on pandas' / numpy's global RNG state and is not reproducible anyway."""
     from . import ops
     u, i = _dev_ids(users, device), _dev_ids(items, device)
     off, pit = ops.positives_csr(u, i, n_users, u.device)
