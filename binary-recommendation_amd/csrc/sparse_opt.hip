@@ -946,6 +946,86 @@ extern "C" int brRowIndexBuildPairSeg(const void* ids_a, int64_t upper_a, void* 
   return index_build_rank(jobs, 2, id_type, n, (hipStream_t)stream);
 }
 
+// ---- the same index when every segment of the array is ALREADY sorted ascending (the fixed-capacity exchange: a requester sends each
+// owner its distinct local rows in key order, pads = the spare row = the largest id, behind them): the W segments of a stream are W sorted
+// runs, so the index is their merge - rank(e) = position in its own run + the number of smaller keys (earlier runs: smaller or equal) in
+// every other run, one binary search each - and the 35 us chunk sort of brRowIndexBuildPairSeg is not needed.  Output identical to it
+// (stable in logical order).  A run that is not sorted sets BR_ERRFLAG_RANGE in *err_flag (the index is then wrong).
+template <typename IdT>
+__global__ __launch_bounds__(256) void run_rank_kernel(IdxJobs jobs, int64_t n, int64_t run_len, int n_runs, int steps, int* err) {
+  const IdxJob& job = jobs.j[blockIdx.y];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const IdT* __restrict__ ids = (const IdT*)job.ids;
+  auto key_at = [&](int64_t t) -> uint32_t {
+    const int64_t id = (int64_t)ids[seg_phys(t, job.seg_len, job.seg_stride, job.seg_off)];
+    return ((uint64_t)id < (uint64_t)job.upper) ? (uint32_t)id : job.upper;
+  };
+  const int r = (int)(e / run_len);
+  const int64_t i = e - (int64_t)r * run_len;
+  const uint32_t key = key_at(e);
+  if (i > 0 && key_at(e - 1) > key && err) atomicOr(err, BR_ERRFLAG_RANGE);
+  uint32_t rank = (uint32_t)i;
+  constexpr int G = 8;                                   // runs searched together (independent probes in flight per step)
+  for (int r0 = 0; r0 < n_runs; r0 += G) {
+    uint32_t lo[G], len[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int rr = r0 + u;
+      const int64_t left = n - (int64_t)rr * run_len;
+      len[u] = (rr < n_runs && rr != r) ? (uint32_t)(left < run_len ? left : run_len) : 0u;
+      lo[u] = 0u;
+    }
+    for (int st = steps - 1; st >= 0; --st) {
+      const uint32_t step = 1u << st;
+      uint32_t v[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t idx = lo[u] + step;
+        const uint32_t at = idx <= len[u] ? idx - 1u : 0u;                          // clamped probe, branch-free
+        v[u] = key_at((int64_t)(r0 + u < n_runs ? r0 + u : 0) * run_len + at);
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t idx = lo[u] + step;
+        const uint32_t lt = (r0 + u < r) ? (v[u] <= key ? 1u : 0u) : (v[u] < key ? 1u : 0u);   // earlier run: ties sort before
+        lo[u] += (idx <= len[u] ? lt : 0u) * step;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) rank += lo[u];
+  }
+  ((IdT*)job.sorted_ids)[rank] = (IdT)key;
+  job.sorted_pos[rank] = (int32_t)seg_phys(e, job.seg_len, job.seg_stride, job.seg_off);
+}
+
+extern "C" int brRowIndexMergePairSeg(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, const void* ids_b, int64_t upper_b,
+                                      void* sorted_ids_b, int32_t* sorted_pos_b, int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a,
+                                      int64_t seg_off_b, int* err_flag, brStream stream) {
+  BR_CHECK_ARG(id_type == BR_IDS_I32 || id_type == BR_IDS_I64, "brRowIndexMergePairSeg: bad id_type");
+  BR_CHECK_ARG(seg_len >= 1 && seg_stride >= seg_len && seg_off_a >= 0 && seg_off_b >= 0, "brRowIndexMergePairSeg: bad segment geometry");
+  if (n == 0) return BR_OK;
+  BR_CHECK_ARG(ids_a && ids_b && sorted_ids_a && sorted_ids_b && sorted_pos_a && sorted_pos_b, "brRowIndexMergePairSeg: null pointer");
+  BR_CHECK_ARG(upper_a > 0 && upper_b > 0 && upper_a < ((int64_t)1 << 31) - 2 && upper_b < ((int64_t)1 << 31) - 2 && n < ((int64_t)1 << 31) &&
+                   seg_phys(n - 1, seg_len, seg_stride, seg_off_a > seg_off_b ? seg_off_a : seg_off_b) < ((int64_t)1 << 31),
+               "brRowIndexMergePairSeg: positions and id bounds < 2^31 - 2");
+  IdxJobs jobs;
+  jobs.j[0].ids = ids_a; jobs.j[0].sorted_ids = sorted_ids_a; jobs.j[0].sorted_pos = sorted_pos_a; jobs.j[0].upper = (uint32_t)upper_a;
+  jobs.j[1].ids = ids_b; jobs.j[1].sorted_ids = sorted_ids_b; jobs.j[1].sorted_pos = sorted_pos_b; jobs.j[1].upper = (uint32_t)upper_b;
+  jobs.j[0].ck = jobs.j[1].ck = nullptr; jobs.j[0].cp = jobs.j[1].cp = nullptr; jobs.j[0].end_bit = jobs.j[1].end_bit = 0;
+  jobs.j[0].seg_len = jobs.j[1].seg_len = seg_len; jobs.j[0].seg_stride = jobs.j[1].seg_stride = seg_stride;
+  jobs.j[0].seg_off = seg_off_a; jobs.j[1].seg_off = seg_off_b;
+  const int n_runs = (int)ceil_div(n, seg_len);
+  int steps = 0;
+  while (((int64_t)1 << steps) <= seg_len) ++steps;       // 2^steps > seg_len: the search covers every length <= seg_len
+  const dim3 grid((unsigned)ceil_div(n, 256), 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (id_type == BR_IDS_I32) run_rank_kernel<int32_t><<<grid, 256, 0, s>>>(jobs, n, seg_len, n_runs, steps, err_flag);
+  else run_rank_kernel<int64_t><<<grid, 256, 0, s>>>(jobs, n, seg_len, n_runs, steps, err_flag);
+  BR_CHECK_LAUNCH("brRowIndexMergePairSeg");
+  return BR_OK;
+}
+
 static bool wave_rows_enabled();
 // neumf_step.cpp: lookup + both dedup indexes on one stream (lookup_sort_kernel, then the chunk-rank launch).  supported(): the wave
 // lookup's shapes, the large-chunk sort's range, BR_FUSED_SORT != 0.

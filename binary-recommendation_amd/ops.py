@@ -302,6 +302,19 @@ def row_index_build_pair_seg(idx_a: RowIndex, upper_a: int, idx_b: RowIndex, upp
                                              ty, n, *[int(v) for v in seg], _stream()), "brRowIndexBuildPairSeg")
 
 
+def row_index_merge_pair_seg(idx_a: RowIndex, upper_a: int, idx_b: RowIndex, upper_b: int, ids, n: int, seg, err_flag=None):
+    """the same two indexes when every segment of `ids` is already sorted ascending (the fixed-capacity exchange delivers each requester's
+    distinct rows in key order, pads last): a merge of the per-source runs, no sort (brRowIndexMergePairSeg).  An unsorted segment sets
+    BR_ERRFLAG_RANGE in err_flag."""
+    t, ty = _ids(ids, "ids")
+    if ty != idx_a.id_type or ty != idx_b.id_type or n > min(idx_a.capacity, idx_b.capacity):
+        raise ValueError("row_index_merge_pair_seg: dtype / capacity mismatch")
+    idx_a.n = idx_b.n = n
+    check(_lib.load().brRowIndexMergePairSeg(t.data_ptr(), int(upper_a), idx_a.sorted_ids.data_ptr(), idx_a.sorted_pos.data_ptr(),
+                                             t.data_ptr(), int(upper_b), idx_b.sorted_ids.data_ptr(), idx_b.sorted_pos.data_ptr(),
+                                             ty, n, *[int(v) for v in seg], _p(err_flag), _stream()), "brRowIndexMergePairSeg")
+
+
 def gather_rows_deferred_pair_seg(tab_a, m_a, v_a, last_a, tab_b, m_b, v_b, last_b, ids, out, n, seg, step_state, beta1=0.9, beta2=0.999, eps=1e-7, err_flag=None):
     """owner-side lookup of both streams of the merged exchange buffer on deferred tables, one launch: out[p] = row ids[p] of the stream's
     table (as of step - 1) at every physical slot p."""

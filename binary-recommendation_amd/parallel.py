@@ -15,6 +15,8 @@ CPU tests (gloo, world_size 2) pass the oracle.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -405,7 +407,12 @@ def make_sharded_engine(base_cls):
                 self._ev_ids.record(main)
                 self._side.wait_event(self._ev_ids)
                 with torch.cuda.stream(self._side):
-                    ops.row_index_build_pair_seg(self.user_index, self.local_rows("user_mf"), self.item_index, self.local_rows("item_mf"), rid, S, x.seg)
+                    # every source's segment arrives sorted (distinct local rows in key order, pads = the spare row last): the index is a
+                    # merge of W sorted runs, no sort (BR_MERGE_INDEX=0: the chunk-sort build, A/B)
+                    if os.environ.get("BR_MERGE_INDEX", "1") != "0":
+                        ops.row_index_merge_pair_seg(self.user_index, self.local_rows("user_mf"), self.item_index, self.local_rows("item_mf"), rid, S, x.seg, self.err)
+                    else:
+                        ops.row_index_build_pair_seg(self.user_index, self.local_rows("user_mf"), self.item_index, self.local_rows("item_mf"), rid, S, x.seg)
                     self._ev_index.record(self._side)
                 # owner-side G1 on the fused [mlp | mf] rows (512 B at dim 64): both shards, one launch, straight into the slots
                 if self.deferred and 2 * D in (64, 128, 256):

@@ -174,6 +174,14 @@ int brSegmentSumToSlotsPair(const void* sorted_ids_a, const int32_t* sorted_pos_
 int brRowIndexBuildPairSeg(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, void* ws_a, int64_t ws_a_bytes,
                            const void* ids_b, int64_t upper_b, void* sorted_ids_b, int32_t* sorted_pos_b, void* ws_b, int64_t ws_b_bytes,
                            int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b, brStream stream);
+/* The same index when every segment is ALREADY sorted ascending - what the fixed-capacity exchange delivers: each requester sends an owner
+ * its distinct local rows in key order with the pads (the spare row = the largest id) behind them, so the W segments of a stream are W
+ * sorted runs and the index is their merge (one binary search per other run and key, no sort, no workspace).  Output identical to
+ * brRowIndexBuildPairSeg.  A segment that is not sorted sets BR_ERRFLAG_RANGE in *err_flag (may be NULL); the index is then wrong.
+ * Replaces on the owners of parallel.py what RModel.py:119's MultiWorkerMirroredStrategy does with an all-reduce of IndexedSlices. */
+int brRowIndexMergePairSeg(const void* ids_a, int64_t upper_a, void* sorted_ids_a, int32_t* sorted_pos_a, const void* ids_b, int64_t upper_b,
+                           void* sorted_ids_b, int32_t* sorted_pos_b, int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a,
+                           int64_t seg_off_b, int* err_flag, brStream stream);
 int brGatherRowsDeferredPairSeg(const float* table_a, const float* m_a, const float* v_a, const int32_t* last_a, int64_t rows_a, const float* table_b,
                                 const float* m_b, const float* v_b, const int32_t* last_b, int64_t rows_b, const void* ids, float* out, int dim,
                                 int id_type, int64_t n, int64_t seg_len, int64_t seg_stride, int64_t seg_off_a, int64_t seg_off_b,

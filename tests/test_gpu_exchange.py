@@ -113,6 +113,13 @@ def test_dedup_exchange_virtual_ranks(dev, W, idt, kind):
         S = W * cap
         iu, ii = ops.RowIndex(S, idt, dev), ops.RowIndex(S, idt, dev)
         ops.row_index_build_pair_seg(iu, shard[r]["u"].shape[0], ii, shard[r]["i"].shape[0], R.recv, S, seg)
+        # the received segments are sorted runs: the merge (no sort) must give the very same index, and raise no flag
+        mu, mi = ops.RowIndex(S, idt, dev), ops.RowIndex(S, idt, dev)
+        mflag = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.row_index_merge_pair_seg(mu, shard[r]["u"].shape[0], mi, shard[r]["i"].shape[0], R.recv, S, seg, mflag)
+        for a_, b_ in ((iu, mu), (ii, mi)):
+            assert torch.equal(a_.sorted_ids[:S], b_.sorted_ids[:S]) and torch.equal(a_.sorted_pos[:S], b_.sorted_pos[:S]), f"owner {r}: merge index != sort index"
+        assert int(mflag.item()) == 0
         for idx, key in ((iu, "u"), (ii, "i")):
             out, head = ops.segment_sum_rows(idx, R.grecv, dim=dim, ldg=dim)
             torch.cuda.synchronize()
