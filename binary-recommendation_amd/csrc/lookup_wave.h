@@ -77,6 +77,70 @@ __device__ __forceinline__ void lookup_wave_pair(const LookupArgs& a, int64_t b,
   if (lane == 63) a.dot[b] = s;
 }
 
+// embed_dim 64, fast replay: the pair's two fused rows (128 floats each) side by side in ONE wave - lanes 0-31 the user row, lanes 32-63 the
+// item row, 16 B per lane - so theta, m and v are one load instruction each for BOTH rows (1 KB per instruction; the form above moves
+// 512 B per instruction and needs twice as many), and the two replays run together: max(lag_u, lag_i) iterations instead of their sum, each
+// half with its own alpha (the ids and last[] of a pair are wave-uniform, so both alphas are scalar loads; a half whose lag is used up
+// gets alpha = 0, which leaves theta as it is).  Same fp32 operations per element as lookup_wave_pair in the same order: same bits
+// (x0, MF stash and dot: the dot's lanes hold four columns each, as the row-group kernels' do).
+template <typename IdT>
+__device__ __forceinline__ void lookup_half_pair(const LookupArgs& a, int64_t b, int lane) {
+  constexpr int dim = 64;
+  constexpr int64_t ld = 2 * dim;
+  const StepStateDev* __restrict__ ss = a.ss;
+  const bool it = lane >= 32;                          // this lane's row: the item's
+  const int col = (lane & 31) * 4;                     // column of the fused row: [0, dim) MLP, [dim, 2 dim) MF
+  int64_t u = load_id((const IdT*)a.users, b), i = load_id((const IdT*)a.items, b);
+  const bool uok = (uint64_t)u < (uint64_t)a.user_rows, iok = (uint64_t)i < (uint64_t)a.item_rows;
+  if ((!uok || !iok) && a.err && lane == 0) *a.err = 1;
+  if (!uok) u = 0;
+  if (!iok) i = 0;
+  const uint32_t t = ss->step + a.step_add;
+  const uint32_t lu = (uint32_t)a.user_last[u], li = (uint32_t)a.item_last[i];
+  const FastRp f = fast_rp(ss);
+  uint32_t lag_u = lu + 1 < t ? t - 1 - lu : 0u, lag_i = li + 1 < t ? t - 1 - li : 0u;
+  const int64_t off = (it ? i : u) * ld + col;
+  const float4 th = vload<4>((it ? a.item_tab : a.user_tab) + off);
+  float4 m = vzero<4>(), v = vzero<4>();
+  if (it ? lag_i > 0 : lag_u > 0) { m = vload<4>((it ? a.item_m : a.user_m) + off); v = vload<4>((it ? a.item_v : a.user_v) + off); }
+  float4 out = th;
+  lag_u = lag_u < f.trunc ? lag_u : f.trunc; lag_i = lag_i < f.trunc ? lag_i : f.trunc;      // theta is replayed over min(lag, trunc) steps
+  const uint32_t steps = lag_u > lag_i ? lag_u : lag_i, mine = it ? lag_i : lag_u;
+  if (steps > 0 && __builtin_amdgcn_ballot_w64(!(all_zero(m) && all_zero(v))) != 0) {
+    FastSt<float4> st;
+    st.open(th, m, v, a.h.eps);
+    uint32_t k = 1;
+    for (; k + 7 <= steps; k += 8) {      // eight alphas of each row per scalar load (the ring's first eight entries are mirrored behind its end)
+      const float* __restrict__ ru = ss->alpha_hist + ((lu + k) & (BR_ALPHA_RING - 1));
+      const float* __restrict__ ri = ss->alpha_hist + ((li + k) & (BR_ALPHA_RING - 1));
+      float au[8], ai[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { au[q] = ru[q]; ai[q] = ri[q]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) st.step(k + q <= mine ? (it ? ai[q] : au[q]) : 0.f, a.h.b1, f);
+    }
+    for (; k <= steps; ++k) {
+      const float au = ss->alpha_hist[(lu + k) & (BR_ALPHA_RING - 1)], ai = ss->alpha_hist[(li + k) & (BR_ALPHA_RING - 1)];
+      st.step(k <= mine ? (it ? ai : au) : 0.f, a.h.b1, f);
+    }
+    out = st.theta();
+  }
+  if (it ? !iok : !uok) out = vzero<4>();
+  const bool mlp = col < dim;
+  const int uoff = a.item_first ? dim : 0, ioff = a.item_first ? 0 : dim;
+  float* dst = mlp ? a.x0 + b * ld + (it ? ioff : uoff) + col : (it ? a.stash_item : a.stash_user) + b * a.ld_stash + (col - dim);
+  vstore<4>(dst, out);
+  // GMF dot of the MF halves (lanes 16-31: user, 48-63: item): four columns per lane by vdot's chain, then the xor tree over the 16 lanes
+  float4 other;
+  other.x = __shfl_xor(out.x, 32, 64); other.y = __shfl_xor(out.y, 32, 64); other.z = __shfl_xor(out.z, 32, 64); other.w = __shfl_xor(out.w, 32, 64);
+  float sdot = 0.f + (it ? vdot(other, out) : vdot(out, other));       // (user, item) operand order of the other kernels
+  sdot += __shfl_xor(sdot, 8, 64);
+  sdot += __shfl_xor(sdot, 4, 64);
+  sdot += __shfl_xor(sdot, 2, 64);
+  sdot += __shfl_xor(sdot, 1, 64);
+  if (lane == 63) a.dot[b] = sdot;
+}
+
 // R consecutive pairs by one wave: every id, then every last[], then every row load of the 2 R rows is requested before the first replay
 // (see gather_deferred_wave_rows below for why).  Pairs past the batch are skipped.  Same arithmetic per pair as lookup_wave_pair.
 template <typename IdT, int VEC, int R>

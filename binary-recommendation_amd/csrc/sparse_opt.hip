@@ -736,20 +736,26 @@ __global__ __launch_bounds__(kSortThreads) void chunk_sort_kernel(IdxJobs jobs, 
 // hipGraph (~10 us each on the main branch, ROCm 7.2) and stretched the lookup they ran beside; the chunk-rank launch follows on the
 // same stream.  LDS: the sort's image is reserved by every workgroup (two per CU = 32 waves: the lookup's full occupancy anyway).
 template <typename IdT, int VEC, int R>
-__global__ __launch_bounds__(kThreadsL) void lookup_sort_kernel(const LookupArgs a, IdxJobs jobs, int64_t n, int n_chunks) {
+__global__ __launch_bounds__(kThreadsL, 8) void lookup_sort_kernel(const LookupArgs a, IdxJobs jobs, int64_t n, int n_chunks) {
   const int n_sort = 2 * n_chunks;
   if ((int)blockIdx.x < n_sort) {
     chunk_sort_block<IdT, kChunkL, kThreadsL>(jobs, n, (int)blockIdx.x % n_chunks, (int)blockIdx.x / n_chunks);
     return;
   }
-  const int64_t b = (((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * R;
+  const int64_t b = (((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * (R < 1 ? 1 : R);
   if (b >= a.batch) return;
-  if constexpr (R == 1) lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
+  if constexpr (R == 0) {      // embed_dim 64: both rows of the pair side by side (lookup_half_pair); exact replay keeps the form above
+    if (a.ss->fast) lookup_half_pair<IdT>(a, b, (int)(threadIdx.x & 63));
+    else lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
+  } else if constexpr (R == 1) lookup_wave_pair<IdT, VEC>(a, b, (int)(threadIdx.x & 63));
   else lookup_wave_pairs<IdT, VEC, R>(a, b, (int)(threadIdx.x & 63));
 }
-// pairs per wave of the fused lookup (BR_LOOKUP_PAIRS=1|2; experiments)
+// form of the fused lookup at embed_dim 64: BR_LOOKUP_PAIRS = 1 (default: one pair per wave, lookup_wave_pair) | 2 (two pairs per wave) |
+// 0 (lookup_half_pair: both rows of the pair side by side, 16 B per lane).  Measured at config 2, same bits in all three: 68-69 us | 70.5 us |
+// 86-88 us - the half-wave form halves the load instructions but replays four elements per lane over max(lag_u, lag_i) steps with a
+// per-lane alpha select: the launch follows its VALU work, not its instruction count.
 static int lookup_pairs_per_wave() {
-  static const int r = [] { const char* e = getenv("BR_LOOKUP_PAIRS"); const int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();
+  static const int r = [] { const char* e = getenv("BR_LOOKUP_PAIRS"); const int v = e ? atoi(e) : 1; return (v == 0 || v == 2) ? v : 1; }();
   return r;
 }
 
@@ -1049,13 +1055,15 @@ int br::lookup_with_index(const LookupArgs& la, int dim, int id_type, const Inde
   hipStream_t s = (hipStream_t)stream;
   const int wvec = dim / 32;
   const int ppw = wvec == 2 ? lookup_pairs_per_wave() : 1;
-  const unsigned grid = (unsigned)(2 * n_chunks + ceil_div(ceil_div(n, (int64_t)ppw), (int64_t)(kThreadsL / 64)));
+  const unsigned grid = (unsigned)(2 * n_chunks + ceil_div(ceil_div(n, (int64_t)(ppw < 1 ? 1 : ppw)), (int64_t)(kThreadsL / 64)));
   if (id_type == BR_IDS_I32) {
-    if (wvec == 2 && ppw == 2) lookup_sort_kernel<int32_t, 2, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    if (wvec == 2 && ppw == 0) lookup_sort_kernel<int32_t, 2, 0><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    else if (wvec == 2 && ppw == 2) lookup_sort_kernel<int32_t, 2, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
     else if (wvec == 2) lookup_sort_kernel<int32_t, 2, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
     else lookup_sort_kernel<int32_t, 4, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
   } else {
-    if (wvec == 2 && ppw == 2) lookup_sort_kernel<int64_t, 2, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    if (wvec == 2 && ppw == 0) lookup_sort_kernel<int64_t, 2, 0><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
+    else if (wvec == 2 && ppw == 2) lookup_sort_kernel<int64_t, 2, 2><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
     else if (wvec == 2) lookup_sort_kernel<int64_t, 2, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
     else lookup_sort_kernel<int64_t, 4, 1><<<grid, kThreadsL, 0, s>>>(la, jobs, n, n_chunks);
   }
