@@ -730,15 +730,15 @@ def main():
         if bound == "hbm":
             k.update({"bound": "hbm", "bytes": work, "achieved_GBps": work / us * 1e-3, "frac": work / us * 1e-3 / HBM_PEAK_GBPS})
         elif bound == "mfma":
-            # the tower's GEMMs: fp32-equivalent flop against the fp32-MFMA peak (`frac`, comparable across rounds), the share of the launch
-            # the matrix pipe is busy (bf16x6, DESIGN.md 4c: six 16-cycle bf16 MFMAs do the work of eight 32-cycle fp32 ones -> 0.375 x), and
-            # the activation traffic against HBM; `bound` names the nearer roofline
+            # the tower's GEMMs: fp32-equivalent flop against the fp32-MFMA peak (`frac_mfma_fp32_equiv`, comparable across rounds), the share of
+            # the launch the matrix pipe is busy (bf16x6, DESIGN.md 4c: six 16-cycle bf16 MFMAs do the work of eight 32-cycle fp32 ones ->
+            # 0.375 x), and the activation traffic against HBM; `bound` names the nearer roofline and `frac` is the fraction of THAT one
             flop, nbytes = work
             frac = flop / us * 1e-6 / MFMA_F32_PEAK_TFLOPS
             busy = frac * (0.375 if MLP_MATH == "bf16x6" else 1.0)
             fh = nbytes / us * 1e-3 / HBM_PEAK_GBPS
-            k.update({"bound": "hbm" if fh > busy else "mfma", "math": MLP_MATH, "flop": flop, "achieved_TFLOPs": flop / us * 1e-6, "frac": frac,
-                      "matrix_pipe_busy": busy, "bytes": nbytes, "achieved_GBps": nbytes / us * 1e-3, "frac_hbm": fh})
+            k.update({"bound": "hbm" if fh > busy else "mfma", "frac": max(fh, busy), "math": MLP_MATH, "flop": flop, "achieved_TFLOPs": flop / us * 1e-6,
+                      "frac_mfma_fp32_equiv": frac, "matrix_pipe_busy": busy, "bytes": nbytes, "achieved_GBps": nbytes / us * 1e-3, "frac_hbm": fh})
         kernels[name] = k
         gpu_us_per_step += k["us_per_step"]
     for k in kernels.values():
@@ -759,7 +759,7 @@ def main():
                 traffic = None
         roofline = {"bound": dom["bound"], "kernel": f"{dom_sym} ({dom_key})", "achieved": dom["achieved_GBps" if dom["bound"] == "hbm" else "achieved_TFLOPs"],
                     "peak": HBM_PEAK_GBPS if dom["bound"] == "hbm" else MFMA_F32_PEAK_TFLOPS, "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s",
-                    "frac": (dom.get("frac_hbm", dom["frac"]) if dom["bound"] == "hbm" else dom["frac"]), "traffic": traffic, "traffic_from": tmeta, "avg_launch_us": dom["us"], "measured_in": dom["measured_in"],
+                    "frac": dom["frac"], "traffic": traffic, "traffic_from": tmeta, "avg_launch_us": dom["us"], "measured_in": dom["measured_in"],
                     "share_of_kernel_time": dom["share_of_kernel_time"], "chosen_by": "largest measured time per step among the kernels of the eager pass"}
         roofline["algorithmic_bytes_per_launch" if dom["bound"] == "hbm" else "algorithmic_flop_per_launch"] = dom["bytes" if dom["bound"] == "hbm" else "flop"]
         if dom["bound"] == "hbm" and dom_tag.startswith("ADAM_ROWS"):
