@@ -496,6 +496,9 @@ def main():
     fused_rows = deferred_mode and ctx is None      # the pair launch forms the MF-row gradients itself (neumf_step.cpp fuse_mf)
     uniq_u = sum(int(torch.unique(b[0]).numel()) for b in batches) / len(batches)
     uniq_i = sum(int(torch.unique(b[1]).numel()) for b in batches) / len(batches)
+    # deferred lookup: a pair whose row was NOT updated in the previous step also reads the row's m and v (the replay needs them): measured
+    # on the primed tables for the batch the cursor stands at (steady state: ~94 % of the user rows, ~52 % of the item rows at config 2)
+    lag_u = lag_i = 0.0      # (measured behind the timed region, where the tables are in steady state)
     # algorithmic work per launch (DESIGN.md "Algorithmic bytes"): name, kernel symbol, bound, work, phases to keep eager
     rows_pair = 8 + 2 * D * 4 + (4 if fused_rows else 0)            # sorted id + position, one 2D-float gradient row (+ ddot)
     per_uniq = 6 * 2 * D * 4 + (8 if deferred_mode else 0)           # table, m, v rows read and written (+ last[])
@@ -719,11 +722,17 @@ def main():
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     pairs_per_s = B * world * args.steps / dt
 
+    if deferred_mode and ctx is None and hasattr(eng, "last"):
+        ub, ib, _ = batches[_CURSOR.get(id(batches), 0) % len(batches)]
+        lag_u = float((eng.last["user"][ub.long()].long() + 1 < eng.t + 1).float().mean().item())      # the next step is t + 1: rows must hold steps <= t
+        lag_i = float((eng.last["item"][ib.long()].long() + 1 < eng.t + 1).float().mean().item())
     kernels = {}
     gpu_us_per_step = 0.0
     for tname, ((name, sym, bound, work), _ph) in SPEC.items():
         if TAG.get(tname) not in per_tag:
             continue
+        if tname == "EMBED_FWD" and bound == "hbm" and deferred_mode and ctx is None:
+            work = work + int(B * (lag_u + lag_i) * 2 * 2 * D * 4)      # m and v rows of the lagging rows (fused [mlp | mf] rows: 2 D floats)
         us, n = per_tag[TAG[tname]]
         src, nsteps = probe_src[TAG[tname]]
         k = {"kernel": sym, "us": us, "launches_per_step": n / nsteps, "us_per_step": us * n / nsteps, "measured_in": src}
@@ -889,7 +898,7 @@ def main():
                        "steps_per_graph_launch": (S_MULTI if use_graph else None),
                        "optimizer": args.optimizer + (f" ({'deferred replay' if deferred_mode else 'per-step sweep'})" if args.optimizer == "adam_dense" else "")},
             "roofline": roofline, "cpu_baseline": cpu, "legs": legs, "adam_lazy": lazy, "adam_dense_sweep": sweep_leg, "whole_step_graph": full_graph, "deferred_flush": flush_info, "gpu_kernel_us_per_step": gpu_us_per_step,
-            "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i}, "steady_state_lags": seeded,
+            "unique_rows_per_batch": {"user": uniq_u, "item": uniq_i}, "lagging_rows_per_batch": {"user": lag_u, "item": lag_i}, "steady_state_lags": seeded,
             "launch_mode": ((((f"hipGraph replay, {S_MULTI} consecutive steps per graph launch (NeuMFEngine.enable_graph_multi; the group's ids / labels staged by one launch); "
                               f"{dom_key} bracketed by event-record nodes around the last step of every 2nd group (a HIP event pair each)") if S_MULTI > 1 else
                              f"hipGraph replay of the whole step, one graph per step; {dom_key} bracketed by event-record nodes inside every 4th replay (a HIP event pair each)")
