@@ -185,6 +185,60 @@ def test_dense_layer_shapes(dev, K, N, act):
     _close(ins[K:], (gxr * xhat).sum(0), "sum dh*xhat", rtol=1e-4, atol_frac=1e-5)
 
 
+@pytest.mark.parametrize("K,N,B,act", [(128, 100, 1000, "sigmoid"), (100, 50, 777, "relu"), (64, 112, 640, "linear"), (37, 23, 333, "sigmoid"), (128, 64, 65, "relu"),
+                                       (16, 16, 64, "linear"), (112, 128, 300, "sigmoid"), (128, 120, 200, "relu"), (50, 10, 4097, "sigmoid"), (96, 33, 129, "relu"),
+                                       (128, 100, 13, "sigmoid"), (256, 100, 500, "sigmoid")])
+def test_dense_layer_shapes_padded_rows(dev, K, N, B, act):
+    """The same checks with rows padded to a multiple of 4 floats (what the engines allocate): these are the shapes that take the FUSED
+    backward kernel and the 16-B forward - on the bf16 pipe where the piece images fit the LDS (odd n-tile counts = a half
+    block, N > 112 with K > 96 = the 16-slot dz image, 128 x 120 = no fit, fp32 kernels), with ragged last tiles and batches smaller than a
+    tile, input BatchNorm-affine + dropout + the producer's BatchNorm-backward sums."""
+    ops, _ = _mods()
+    rng = np.random.default_rng(K * 977 + N * 31 + B)
+    ldk, ldn = (K + 3) & ~3, (N + 3) & ~3
+    x = rng.normal(size=(B, K)).astype(np.float32); W = rng.normal(scale=0.2, size=(K, N)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32); sh = rng.normal(size=K).astype(np.float32)
+    mean_in = rng.normal(size=K).astype(np.float32); rstd_in = rng.uniform(0.5, 2, K).astype(np.float32)
+    seed, step, site, p, row0 = 987654321, 3, 1, 0.2, 64
+    td = lambda a: torch.from_numpy(a).to(dev)
+    pad = lambda a, ld: (lambda buf: (buf[:, :a.shape[1]].copy_(td(a)), buf[:, :a.shape[1]])[1])(torch.full((a.shape[0], ld), float("nan"), device=dev))
+    xv = pad(x, ldk)
+    yv = torch.full((B, ldn), float("nan"), device=dev)[:, :N]
+    stats = torch.zeros(8, 2 * N, dtype=torch.float64, device=dev)
+    ops.dense_forward(xv, td(W), td(b), yv, act, td(sc), td(sh), p, seed, step, site, row0, stats)
+    mask = O.dropout_mask(seed, step, site, B, K, p, row0)
+    tx = (x.astype(np.float64) * sc + sh) * mask / (1 - p)
+    yr = O.act_fwd(tx @ W.astype(np.float64) + b, act)
+    _close(yv.cpu().numpy(), yr, "y")
+    st = stats.sum(0).cpu().numpy()
+    _close(st[:N], yr.sum(0), "colsum", rtol=1e-6)
+    _close(st[N:], (yr ** 2).sum(0), "colsumsq", rtol=1e-6)
+    gy = rng.normal(size=(B, N)).astype(np.float32)
+    gyv = pad(gy, ldn)
+    ns = ops.dense_backward_slabs(B, K, N)
+    slabs = torch.full((ns * (K * N + N),), float("nan"), device=dev)
+    gxv = torch.full((B, ldk), float("nan"), device=dev)[:, :K]
+    insum = torch.zeros(8, 2 * K, dtype=torch.float64, device=dev)
+    wide = K > 128
+    ops.dense_backward(gyv, yv, xv, td(W), act, slabs, ns, gx=gxv, in_scale=td(sc), in_shift=td(sh),
+                       in_bn=None if wide else (td(mean_in), td(rstd_in)), in_drop_p=p, in_site=site, seed=seed, step=step, row0=row0,
+                       in_bn_sums=None if wide else insum)
+    out = torch.empty(K * N + N, device=dev)
+    ops.reduce_slabs(slabs, ns, K * N + N, out)
+    dz = gy.astype(np.float64) * O.act_bwd_from_out(yr, act)
+    _close(out.cpu().numpy()[: K * N].reshape(K, N), tx.T @ dz, "dW", rtol=1e-4, atol_frac=1e-5)
+    _close(out.cpu().numpy()[K * N:], dz.sum(0), "db", rtol=1e-4, atol_frac=1e-5)
+    gxr = (dz @ W.astype(np.float64).T) * mask / (1 - p)
+    _close(gxv.cpu().numpy(), gxr, "gx", rtol=1e-4, atol_frac=1e-5)
+    if wide:
+        return
+    xhat = (x.astype(np.float64) - mean_in) * rstd_in
+    ins = insum.sum(0).cpu().numpy()
+    _close(ins[:K], gxr.sum(0), "sum dh", rtol=1e-4, atol_frac=1e-5)
+    _close(ins[K:], (gxr * xhat).sum(0), "sum dh*xhat", rtol=1e-4, atol_frac=1e-5)
+
+
 def test_empty_batch_is_noop(dev):
     ops, eng, spec, cfg, p, u, i, y = _setup("A", 8, 16, dev)
     e = torch.empty(0, dtype=torch.int32, device=dev)
