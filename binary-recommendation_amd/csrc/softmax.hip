@@ -29,12 +29,35 @@
 //   float atomics).  Without a workspace the split count is 1 and results are written directly.
 // [TF-sem] accidental hits: S_ij += FLT_MIN_TFRS (= float32 min / 100) when cand_ids[j] equals the
 // id of query i's own positive and j is not that positive's column; SUM reduction over rows.
+//   Round 3 (EMU, "bf16x6": csrc/dense.h): both GEMMs as fp32 products on the bf16 matrix pipe - v_mfma_f32_32x32x16_bf16, six
+//   per 16-deep block on three-piece operands, the same result layout as the fp32 32x32x2 (so everything above stays as it is).  Every
+//   operand is split once: the owned rows at kernel start (registers), the streamed tile by the thread that stages it - into TP
+//   [sub-tile][k-block][piece][lane half][entity][8 bf16] (A fragments of the score product, k = 16 kb + 8 hb + j) and TT
+//   [sub-tile][16-entity group][feature tile][piece][lane half][feature][8 bf16] (A fragments of the second GEMM: slot j of lane half hb
+//   <-> the streamed entity register 8 g2 + j of the score tile holds, m = 8 (r / 4) + 4 hb + r % 4) - and P by the lane that holds it
+//   (consecutive registers = consecutive k slots).  BR_MLP_MATH=f32 keeps the fp32 MFMAs.
 #include "common.h"
+#include "dense.h"
 
 namespace br {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32b(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+  return c;
+#endif
+}
+// x w as six bf16 products, smallest first (x = xh + xm + xl, w = wh + wm + wl)
+__device__ __forceinline__ f32x16 mfma32x6(bf16x8 xh, bf16x8 xm, bf16x8 xl, bf16x8 wh, bf16x8 wm, bf16x8 wl, f32x16 c) {
+  c = mfma32b(xl, wh, c); c = mfma32b(xh, wl, c); c = mfma32b(xm, wm, c);
+  c = mfma32b(xm, wh, c); c = mfma32b(xh, wm, c); c = mfma32b(xh, wh, c);
+  return c;
+}
+constexpr int kGs = 33;                      // 16-B slots per (..., lane half) group of the piece images: 32 + 1 (the staging's half-word stores of
+                                             // the 8 groups a wave touches would otherwise hit the same banks)
 
 enum { MODE_SCORES = 0, MODE_LSE = 1, MODE_GRAD_R = 2, MODE_GRAD_C = 3, MODE_LSE_GRAD_R = 4 };
 
@@ -60,17 +83,19 @@ struct InbatchArgs {
 };
 
 // KQ = 16-byte vectors per lane half of the feature axis: features are padded to Kp = 8 KQ
-template <int MODE, int KQ, typename IdT>
+template <int MODE, int KQ, typename IdT, bool EMU>
 __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
   constexpr int KH = 4 * KQ, Kp = 8 * KQ, ldt = Kp + 4;
   constexpr int FT = (Kp + 31) / 32;                     // 32-feature tiles of the second GEMM
+  constexpr int KB = (Kp + 15) / 16;                     // EMU: 16-deep k-blocks of the score product
   constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C || MODE == MODE_LSE_GRAD_R;
   constexpr bool FUSED = MODE == MODE_LSE_GRAD_R;
   constexpr int NPRE = (2 * KQ + 3) / 4;                 // 16-byte vectors each thread stages per step
+  constexpr int kTpFloats = 2 * KB * 3 * 2 * kGs * 4, kTtFloats = GRAD ? 2 * 2 * FT * 3 * 2 * kGs * 4 : 0;      // EMU piece images
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ts = smem;                                      // [64][ldt]     streamed tile, row-major (A operand of the score product)
-  float* TsT = Ts + kTs * ldt;                           // [FT*32][68]   transposed (A operand of the second GEMM), GRAD only
-  float* tlse = TsT + (GRAD ? FT * 32 * kLdT : 0);       // [64]          GRAD_C: lse of the streamed queries
+  float* Ts = smem;                                      // [64][ldt]     streamed tile, row-major (A operand of the score product).  EMU: TP
+  float* TsT = Ts + (EMU ? kTpFloats : kTs * ldt);       // [FT*32][68]   transposed (A operand of the second GEMM), GRAD only.  EMU: TT
+  float* tlse = TsT + (EMU ? kTtFloats : (GRAD ? FT * 32 * kLdT : 0));       // [64]          GRAD_C: lse of the streamed queries
   IdT* tid = reinterpret_cast<IdT*>(tlse + kTs);         // [64]          ids of the streamed entities
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,9 +107,22 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
   const int64_t t_begin = (int64_t)blockIdx.y * a.t_per_split;
   const int64_t t_end = t_begin + a.t_per_split < a.n_t ? t_begin + a.t_per_split : a.n_t;
 
-  // stationary operand: R[own][KH * hb + kk]
-  float rf[KH];
-  {
+  // stationary operand: R[own][KH * hb + kk].  EMU: R[own][16 kb + 8 hb + j] as three bf16 pieces per k-block
+  float rf[EMU ? 1 : KH];
+  bf16x8 rh[EMU ? KB : 1], rm[EMU ? KB : 1], rl[EMU ? KB : 1];
+  if constexpr (EMU) {
+    const float* rp = a.R + (own_ok ? own : 0) * dim;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      float e8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int k = 16 * kb + 8 * hb + j; e8[j] = (own_ok && k < dim) ? rp[k] : 0.f; }
+      uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split3(e8[2 * q], e8[2 * q + 1], ph[q], pm[q], pl[q]);
+      rh[kb] = frag8(ph); rm[kb] = frag8(pm); rl[kb] = frag8(pl);
+    }
+  } else {
     const float* rp = a.R + (own_ok ? own : 0) * dim;
     const bool v4 = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(a.R) & 15) == 0;
 #pragma unroll
@@ -111,7 +149,9 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
   for (int t = 0; t < (GRAD ? FT : 1); ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
-  if (GRAD) {     // feature rows of the transposed tile that no step writes (Kp <= f < 32 FT) stay zero
+  if constexpr (EMU) {      // slots no step writes (features past Kp, the pad slot of every group) stay zero
+    for (int idx = threadIdx.x; idx < kTpFloats + kTtFloats; idx += 256) Ts[idx] = 0.f;
+  } else if (GRAD) {     // feature rows of the transposed tile that no step writes (Kp <= f < 32 FT) stay zero
     for (int idx = threadIdx.x; idx < (FT * 32 - Kp) * kLdT; idx += 256) TsT[Kp * kLdT + idx] = 0.f;
   }
 
@@ -145,6 +185,25 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
   };
   if (t_begin < t_end) fetch(t_begin);
 
+  // EMU: out^T[f][owned] += sum_k T[k][f] P[k][owned] for one 32-entity sub-tile whose P the lane holds in pv[0..15]: two 16-entity groups
+  // (registers 8 g2 + j = k slot j), P split in registers, the A fragments (T^T pieces) from TT
+  auto second_gemm_emu = [&](int sub, const float (&pv)[16]) {
+    const float* tt = TsT + ((hb * kGs + l32) << 2);      // + ((((sub * 2 + g2) * FT + t) * 3 + p) * 2 * kGs) * 4
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split3(pv[8 * g2 + 2 * q], pv[8 * g2 + 2 * q + 1], ph[q], pm[q], pl[q]);
+      const bf16x8 wh = frag8(ph), wm = frag8(pm), wl = frag8(pl);
+#pragma unroll
+      for (int t = 0; t < (GRAD ? FT : 1); ++t) {
+        bf16x8 x[3];
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) x[p3] = frag8(*reinterpret_cast<const float4*>(tt + ((((((sub * 2 + g2) * FT + t) * 3 + p3) * 2) * kGs) << 2)));
+        gacc[t] = mfma32x6(x[0], x[1], x[2], wh, wm, wl, gacc[t]);
+      }
+    }
+  };
   // diagonal: streamed index of this lane's partner, as an offset into the current tile (compared against the tile-local index)
   const int64_t partner = own + a.diag;
   const int jb = 4 * hb;                                  // lane-half part of the tile-local streamed index
@@ -153,6 +212,35 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) {
       const int c = 4 * (cg + 4 * q);
+      if constexpr (EMU) {
+        if (c < Kp) {
+          uint32_t h0, m0, l0, h1, m1, l1;
+          split3(pre[q].x, pre[q].y, h0, m0, l0);
+          split3(pre[q].z, pre[q].w, h1, m1, l1);
+          const int sub = sr >> 5, mm = sr & 31;
+          {   // TP: features c..c+3 are slots j0..j0+3 of entity mm in k-block c / 16, lane half (c / 8) & 1
+            const int slot = (((sub * KB + (c >> 4)) * 3) * 2 + ((c >> 3) & 1)) * kGs + mm;
+            float* d = Ts + slot * 4 + ((c & 7) >> 1);
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + 2 * kGs * 4) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 4 * kGs * 4) = make_uint2(l0, l1);
+          }
+          if (GRAD) {   // TT: entity mm is slot j of lane half (mm / 4) & 1 in the 16-entity group mm / 16 - the register 8 g2 + j that holds it
+            const int g2 = mm >> 4, hb2 = (mm >> 2) & 1, j = 4 * ((mm >> 3) & 1) + (mm & 3);
+            uint16_t* tt = reinterpret_cast<uint16_t*>(TsT);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int f = c + e;
+              const int slot = ((((sub * 2 + g2) * FT + (f >> 5)) * 3) * 2 + hb2) * kGs + (f & 31);
+              uint16_t* d = tt + slot * 8 + j;
+              const uint32_t vh = e < 2 ? h0 : h1, vm = e < 2 ? m0 : m1, vl = e < 2 ? l0 : l1;
+              d[0] = (uint16_t)((e & 1) ? (vh >> 16) : (vh & 0xffffu));
+              d[2 * kGs * 8] = (uint16_t)((e & 1) ? (vm >> 16) : (vm & 0xffffu));
+              d[4 * kGs * 8] = (uint16_t)((e & 1) ? (vl >> 16) : (vl & 0xffffu));
+            }
+          }
+        }
+      } else
       if (c < Kp) {
         *reinterpret_cast<float4*>(Ts + sr * ldt + c) = pre[q];
         if (GRAD) {
@@ -172,6 +260,20 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    if constexpr (EMU) {
+      const float* tp = Ts + ((hb * kGs + l32) << 2);      // + (((sub * KB + kb) * 3 + p) * 2 * kGs) * 4
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        bf16x8 x0[3], x1[3];
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+          x0[p3] = frag8(*reinterpret_cast<const float4*>(tp + ((((0 * KB + kb) * 3 + p3) * 2 * kGs) << 2)));
+          x1[p3] = frag8(*reinterpret_cast<const float4*>(tp + ((((1 * KB + kb) * 3 + p3) * 2 * kGs) << 2)));
+        }
+        s0 = mfma32x6(x0[0], x0[1], x0[2], rh[kb], rm[kb], rl[kb], s0);
+        s1 = mfma32x6(x1[0], x1[1], x1[2], rh[kb], rm[kb], rl[kb], s1);
+      }
+    } else {
     const float* ap = Ts + l32 * ldt + KH * hb;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
@@ -181,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
       s0 = mfma32(a0.y, rf[4 * q + 1], s0); s1 = mfma32(a1.y, rf[4 * q + 1], s1);
       s0 = mfma32(a0.z, rf[4 * q + 2], s0); s1 = mfma32(a1.z, rf[4 * q + 2], s1);
       s0 = mfma32(a0.w, rf[4 * q + 3], s0); s1 = mfma32(a1.w, rf[4 * q + 3], s1);
+    }
     }
     if (MODE == MODE_SCORES) {
 #pragma unroll
@@ -263,6 +366,16 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
       for (int t = 0; t < FT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gacc[t][r] *= sc;
+      if constexpr (EMU) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          float pv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pv[r] = v[16 * sub + r];
+          second_gemm_emu(sub, pv);
+        }
+        continue;
+      }
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -283,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
     // (streamed rows past the end and owned rows past the end need no mask: their T rows are zero / their results are not stored)
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      float pv[16];
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int j0 = 32 * sub + 8 * rq + jb;
@@ -304,16 +418,20 @@ __global__ __launch_bounds__(256, 2) void inbatch_kernel(const InbatchArgs a) {
           const bool dg = cj == dd;
           if (has_ids) x += (!dg && ids4[e] == own_id) ? kMinFloat : 0.f;
           p[e] = exp_hw(x - (MODE == MODE_GRAD_R ? own_lse : l4[e])) - (dg ? 1.f : 0.f);
+          pv[4 * rq + e] = p[e];
         }
+        if constexpr (!EMU) {
 #pragma unroll
-        for (int t = 0; t < FT; ++t) {
-          const float4 a4 = *reinterpret_cast<const float4*>(TsT + (32 * t + l32) * kLdT + j0);
-          gacc[t] = mfma32(a4.x, p[0], gacc[t]);
-          gacc[t] = mfma32(a4.y, p[1], gacc[t]);
-          gacc[t] = mfma32(a4.z, p[2], gacc[t]);
-          gacc[t] = mfma32(a4.w, p[3], gacc[t]);
+          for (int t = 0; t < FT; ++t) {
+            const float4 a4 = *reinterpret_cast<const float4*>(TsT + (32 * t + l32) * kLdT + j0);
+            gacc[t] = mfma32(a4.x, p[0], gacc[t]);
+            gacc[t] = mfma32(a4.y, p[1], gacc[t]);
+            gacc[t] = mfma32(a4.z, p[2], gacc[t]);
+            gacc[t] = mfma32(a4.w, p[3], gacc[t]);
+          }
         }
       }
+      if constexpr (EMU) second_gemm_emu(sub, pv);
     }
   }
 
@@ -550,18 +668,29 @@ int choose_splits(int64_t n_r, int64_t n_t, int64_t max_splits) {
   return (int)(s < 1 ? 1 : s);
 }
 
-template <int MODE, int KQ, typename IdT>
-void launch_inbatch_k(const InbatchArgs& a, int n_split, hipStream_t s) {
-  constexpr int Kp = 8 * KQ, FT = (Kp + 31) / 32;
+template <int MODE, int KQ, typename IdT, bool EMU>
+void launch_inbatch_e(const InbatchArgs& a, int n_split, hipStream_t s) {
+  constexpr int Kp = 8 * KQ, FT = (Kp + 31) / 32, KB = (Kp + 15) / 16;
   constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C || MODE == MODE_LSE_GRAD_R;
-  const size_t shmem = ((size_t)kTs * (Kp + 4) + (GRAD ? (size_t)FT * 32 * kLdT : 0) + kTs) * sizeof(float) + kTs * sizeof(IdT);
+  const size_t img = EMU ? (size_t)2 * KB * 3 * 2 * kGs * 4 + (GRAD ? (size_t)2 * 2 * FT * 3 * 2 * kGs * 4 : 0)
+                         : (size_t)kTs * (Kp + 4) + (GRAD ? (size_t)FT * 32 * kLdT : 0);
+  const size_t shmem = (img + kTs) * sizeof(float) + kTs * sizeof(IdT);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)inbatch_kernel<MODE, KQ, IdT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)inbatch_kernel<MODE, KQ, IdT, EMU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
   const dim3 grid((unsigned)ceil_div(a.n_r, (int64_t)kOwn), (unsigned)n_split);
-  inbatch_kernel<MODE, KQ, IdT><<<grid, 256, shmem, s>>>(a);
+  inbatch_kernel<MODE, KQ, IdT, EMU><<<grid, 256, shmem, s>>>(a);
+}
+template <int MODE, int KQ, typename IdT>
+void launch_inbatch_k(const InbatchArgs& a, int n_split, hipStream_t s) {
+  // bf16x6 where it measured faster (8 192 x 8 192 x 64: lse 120 -> 93 us, lse + dQ one sweep 185 -> 145, dC 163 -> 125): not for short streamed
+  // axes (2 048: the piece staging costs more than the MFMAs save), not for the gradient modes past 64 features (the stationary pieces +
+  // the accumulators of four feature tiles spill: 264 -> 340 us at 100 features)
+  constexpr bool GRAD = MODE == MODE_GRAD_R || MODE == MODE_GRAD_C || MODE == MODE_LSE_GRAD_R;
+  if (mlp_bf16x6() && a.n_t >= 4096 && (KQ <= 8 || !GRAD)) launch_inbatch_e<MODE, KQ, IdT, true>(a, n_split, s);
+  else launch_inbatch_e<MODE, KQ, IdT, false>(a, n_split, s);
 }
 
 template <int MODE, typename IdT>
