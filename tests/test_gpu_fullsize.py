@@ -258,3 +258,30 @@ def test_inbatch_softmax_dc_stripe_8192(dev):
     ops.inbatch_softmax_grad(Qd, Cd, idd, idd, 0, lse, dq, dc_all)
     _check(case, "dQ (square)", dq.cpu().numpy(), rdq, 1e-4, 1e-5 * np.abs(rdq).max())
     _check(case, "dC (square)", dc_all.cpu().numpy(), rdc, 1e-4, 1e-5 * np.abs(rdc).max())
+
+
+def test_inbatch_softmax_square_4096_dim50(dev):
+    """4 096 x 4 096 at 50 features (padded to 56 / 64 inside the kernel: the k-blocks and feature tiles past the data must stay zero) -
+    the smallest streamed axis and an odd feature count on the bf16 matrix pipe (TP / TT piece images): lse, loss, dQ and dC
+    by the two-pass kernels and lse + loss + dQ by the one-sweep kernel against the float64 oracle."""
+    ops = _m("ops")
+    case = "softmax_4096x4096x50"
+    rng = np.random.default_rng(21)
+    Bt, dim = 4096, 50
+    Q = rng.normal(0, 0.4, (Bt, dim)).astype(np.float32); C = rng.normal(0, 0.4, (Bt, dim)).astype(np.float32)
+    ids = rng.integers(0, 1500, Bt)
+    td = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    Qd, Cd, idd = td(Q), td(C), td(ids, torch.int32)
+    lse = torch.empty(Bt, device=dev); ls = torch.zeros(64, dtype=torch.float64, device=dev)
+    ops.inbatch_softmax_lse(Qd, Cd, idd, idd, 0, lse, ls)
+    loss, rdq, rdc = O.inbatch_softmax_loss(Q.astype(np.float64), C.astype(np.float64), ids)
+    _check(case, "loss", ls.sum().item(), loss, 1e-5, 0.0)
+    dq = torch.empty(Bt, dim, device=dev); dc = torch.empty(Bt, dim, device=dev)
+    ops.inbatch_softmax_grad(Qd, Cd, idd, idd, 0, lse, dq, dc)
+    _check(case, "dQ", dq.cpu().numpy(), rdq, 1e-4, 1e-5 * np.abs(rdq).max())
+    _check(case, "dC", dc.cpu().numpy(), rdc, 1e-4, 1e-5 * np.abs(rdc).max())
+    lse2 = torch.empty(Bt, device=dev); ls2 = torch.zeros(64, dtype=torch.float64, device=dev); dq2 = torch.empty(Bt, dim, device=dev)
+    ops.inbatch_softmax_lse_grad_q(Qd, Cd, idd, idd, 0, lse2, ls2, dq2)
+    _check(case, "loss (one sweep)", ls2.sum().item(), loss, 1e-5, 0.0)
+    _check(case, "row lse (one sweep) vs two-pass", lse2.cpu().numpy(), lse.cpu().numpy(), 1e-6, 1e-6)
+    _check(case, "dQ (one sweep)", dq2.cpu().numpy(), rdq, 1e-4, 1e-5 * np.abs(rdq).max())
