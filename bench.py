@@ -785,13 +785,16 @@ def main():
                 eng._graph = g_plain
             else:
                 eng.enable_graph(B)
-            dtg = timed(eng, batches, args.steps, args.warmup, ctx, row0, batch_total)
-            full_graph = {"value": B * args.steps / dtg, "unit": "pairs/s", "ms_per_step": dtg / args.steps * 1e3, "steps_per_graph_launch": S_MULTI}
+            # (these two sub-legs are the median of three runs of K steps: one run is ~15 ms, short enough for a clock ramp to swap their order)
+            med3 = lambda: sorted(timed(eng, batches, args.steps, args.warmup if r == 0 else 0, ctx, row0, batch_total) for r in range(3))[1]
+            dtg = med3()
+            full_graph = {"value": B * args.steps / dtg, "unit": "pairs/s", "ms_per_step": dtg / args.steps * 1e3, "steps_per_graph_launch": S_MULTI,
+                          "timing": "median of 3 runs of --steps steps"}
             log(f"whole-step graph: {dtg / args.steps * 1e3:.3f} ms/step")
             if S_MULTI > 1:
                 # one graph launch per step, as rounds 1-2 timed it
                 eng._graph_multi = None
-                dt1 = timed(eng, batches, args.steps, args.warmup, ctx, row0, batch_total)
+                dt1 = med3()
                 full_graph["one_step_per_launch"] = {"value": B * args.steps / dt1, "unit": "pairs/s", "ms_per_step": dt1 / args.steps * 1e3}
                 log(f"whole-step graph, one step per launch: {dt1 / args.steps * 1e3:.3f} ms/step")
                 eng._graph_multi = gm_plain
