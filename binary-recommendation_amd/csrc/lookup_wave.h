@@ -284,4 +284,72 @@ __device__ __forceinline__ void gather_deferred_wave_rows(const GatherDefJobs& j
   }
 }
 
+// 256-B rows (64 floats), fast replay: FOUR rows per wave side by side - lane group q = lane >> 4 holds row q, 16 B per lane - so theta,
+// m, v and the output are one 1 KB instruction each for the four rows (one wave per row moves 256 B per instruction: theta + last[] alone
+// took 34 us for the BPR step's 196 608 rows where the plain gather of the same rows takes 12, tools/diag/gather_probe.py).  The four replays
+// run together over max(lag) iterations; each group takes ITS alpha (ring index last + k: the four `last` values are read back as scalars,
+// four s_load_dwordx8 per eight steps) and alpha = 0 once its lag is used up, which leaves theta as it is.  Per element the operations of
+// the one-wave-per-row form in the same order: same bits.
+template <typename IdT>
+__device__ __forceinline__ void gather_deferred_group4(const GatherDefJobs& jobs, int64_t b0, int lane, const StepStateDev* __restrict__ ss, const AdamHp& h,
+                                                       int64_t ld_out, int* err) {
+  constexpr int dim = 64;
+  const int64_t n_a = jobs.j[0].n, n_all = n_a + jobs.j[1].n;
+  const uint32_t t = ss->step + jobs.step_add;
+  const int q = lane >> 4, col = (lane & 15) * 4;
+  const int64_t b = b0 + q;
+  const bool live = b < n_all;
+  const int64_t bc = live ? b : n_all - 1;
+  const int which = bc < n_a ? 0 : 1;
+  const GatherDefJob& ja = jobs.j[0];
+  const GatherDefJob& jb = jobs.j[1];
+  const int64_t pos = seg_phys(which ? bc - n_a : bc, jobs.seg_len, jobs.seg_stride, which ? jb.seg_off : ja.seg_off);
+  int64_t row = which ? load_id((const IdT*)jb.ids, pos) : load_id((const IdT*)ja.ids, pos);
+  const int64_t rows = which ? jb.rows : ja.rows;
+  const bool ok = (uint64_t)row < (uint64_t)rows;
+  if (!ok) { if (err && live && (lane & 15) == 0) *err = 1; row = 0; }
+  const uint32_t seen = (uint32_t)(which ? jb.last : ja.last)[row];
+  const FastRp f = fast_rp(ss);
+  uint32_t lag = seen + 1 < t ? t - 1 - seen : 0u;
+  const int64_t off = row * dim + col;
+  float4 th = vload<4>((which ? jb.table : ja.table) + off);
+  float4 m = vzero<4>(), v = vzero<4>();
+  if (lag > 0) { m = vload<4>((which ? jb.M : ja.M) + off); v = vload<4>((which ? jb.Vv : ja.Vv) + off); }
+  lag = lag < f.trunc ? lag : f.trunc;
+  // wave-uniform: the longest lag, and the four groups' `last` as scalars
+  uint32_t steps = lag;
+  steps = max(steps, (uint32_t)__shfl_xor((int)steps, 16, 64));
+  steps = max(steps, (uint32_t)__shfl_xor((int)steps, 32, 64));
+  steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)steps);
+  if (steps > 0 && __builtin_amdgcn_ballot_w64(!(all_zero(m) && all_zero(v))) != 0) {
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)seen, 0), s1 = (uint32_t)__builtin_amdgcn_readlane((int)seen, 16);
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)seen, 32), s3 = (uint32_t)__builtin_amdgcn_readlane((int)seen, 48);
+    FastSt<float4> st;
+    st.open(th, m, v, h.eps);
+    uint32_t k = 1;
+    for (; k + 7 <= steps; k += 8) {
+      const float* __restrict__ r0 = ss->alpha_hist + ((s0 + k) & (BR_ALPHA_RING - 1));
+      const float* __restrict__ r1 = ss->alpha_hist + ((s1 + k) & (BR_ALPHA_RING - 1));
+      const float* __restrict__ r2 = ss->alpha_hist + ((s2 + k) & (BR_ALPHA_RING - 1));
+      const float* __restrict__ r3 = ss->alpha_hist + ((s3 + k) & (BR_ALPHA_RING - 1));
+      float a0[8], a1[8], a2[8], a3[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a0[e] = r0[e]; a1[e] = r1[e]; a2[e] = r2[e]; a3[e] = r3[e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float al = q == 0 ? a0[e] : (q == 1 ? a1[e] : (q == 2 ? a2[e] : a3[e]));
+        st.step(k + e <= lag ? al : 0.f, h.b1, f);
+      }
+    }
+    for (; k <= steps; ++k) {
+      const float a0 = ss->alpha_hist[(s0 + k) & (BR_ALPHA_RING - 1)], a1 = ss->alpha_hist[(s1 + k) & (BR_ALPHA_RING - 1)];
+      const float a2 = ss->alpha_hist[(s2 + k) & (BR_ALPHA_RING - 1)], a3 = ss->alpha_hist[(s3 + k) & (BR_ALPHA_RING - 1)];
+      const float al = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));
+      st.step(k <= lag ? al : 0.f, h.b1, f);
+    }
+    th = st.theta();
+  }
+  if (live) vstore<4>((which ? jb.out : ja.out) + pos * ld_out + col, ok ? th : vzero<4>());
+}
+
 }  // namespace br

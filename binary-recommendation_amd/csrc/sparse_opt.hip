@@ -768,7 +768,7 @@ static int lookup_pairs_per_wave() {
 template <int VEC> constexpr int kGatherRowsPerWave = VEC == 1 ? 4 : (VEC == 2 ? 2 : 1);
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(kThreadsL) void gather_sort_kernel(const GatherDefJobs gj, const StepStateDev* __restrict__ ss, const AdamHp h, int64_t ld_out, int* err,
-                                                                IdxJobs jobs, int n_sort_a, int n_sort_b) {
+                                                                IdxJobs jobs, int n_sort_a, int n_sort_b, bool gather_group4_enabled) {
   const int n_sort = n_sort_a + n_sort_b;
   if ((int)blockIdx.x < n_sort) {
     const int which = (int)blockIdx.x < n_sort_a ? 0 : 1;
@@ -778,6 +778,9 @@ __global__ __launch_bounds__(kThreadsL) void gather_sort_kernel(const GatherDefJ
   constexpr int R = kGatherRowsPerWave<VEC>;
   const int64_t b0 = (((int64_t)blockIdx.x - n_sort) * (kThreadsL / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * R;
   if (b0 >= gj.j[0].n + gj.j[1].n) return;
+  if constexpr (VEC == 1) {      // 256-B rows: four rows side by side at 16 B per lane under the fast replay (gather_deferred_group4)
+    if (ss->fast && (ld_out & 3) == 0 && gather_group4_enabled) { gather_deferred_group4<IdT>(gj, b0, (int)(threadIdx.x & 63), ss, h, ld_out, err); return; }
+  }
   gather_deferred_wave_rows<IdT, VEC, R>(gj, b0, (int)(threadIdx.x & 63), ss, h, ld_out, err);
 }
 
@@ -1109,11 +1112,14 @@ extern "C" int brGatherRowsDeferredPairWithIndex(const float* table_a, const flo
   StepStateDev* ss = (StepStateDev*)step_state;
   hipStream_t s = (hipStream_t)stream;
   const int rpw = wvec == 1 ? 4 : (wvec == 2 ? 2 : 1);      // kGatherRowsPerWave
+  static const bool g4env = [] { const char* e = getenv("BR_GATHER_GROUP4"); return !(e && e[0] == '0'); }();
+  const bool g4 = g4env && ((reinterpret_cast<uintptr_t>(table_a) | reinterpret_cast<uintptr_t>(table_b) | reinterpret_cast<uintptr_t>(m_a) | reinterpret_cast<uintptr_t>(m_b) |
+                             reinterpret_cast<uintptr_t>(v_a) | reinterpret_cast<uintptr_t>(v_b) | reinterpret_cast<uintptr_t>(out_a) | reinterpret_cast<uintptr_t>(out_b)) & 15) == 0;
   const unsigned grid = (unsigned)(ca + cb + ceil_div(ceil_div(n_a + n_b, (int64_t)rpw), (int64_t)(kThreadsL / 64)));
   if (id_type == BR_IDS_I32)
-    BR_DISPATCH_VEC(wvec, (gather_sort_kernel<int32_t, VEC><<<grid, kThreadsL, 0, s>>>(G, ss, h, ld_out, err_flag, jobs, ca, cb)));
+    BR_DISPATCH_VEC(wvec, (gather_sort_kernel<int32_t, VEC><<<grid, kThreadsL, 0, s>>>(G, ss, h, ld_out, err_flag, jobs, ca, cb, g4)));
   else
-    BR_DISPATCH_VEC(wvec, (gather_sort_kernel<int64_t, VEC><<<grid, kThreadsL, 0, s>>>(G, ss, h, ld_out, err_flag, jobs, ca, cb)));
+    BR_DISPATCH_VEC(wvec, (gather_sort_kernel<int64_t, VEC><<<grid, kThreadsL, 0, s>>>(G, ss, h, ld_out, err_flag, jobs, ca, cb, g4)));
   BR_CHECK_LAUNCH("brGatherRowsDeferredPairWithIndex(gather + sort)");
   StepAdvance av;
   if (advance) { av.st = ss; av.lr = lr; av.b1 = beta1; av.b2 = beta2; }
