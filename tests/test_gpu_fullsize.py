@@ -77,14 +77,17 @@ NEUMF_CASES = [("uniform", torch.int32, 65536, False, 64, M1, K1), ("zipf", torc
                # elements, 42 GB with the Adam slots), int64 ids, batch 65 536: the VEC = 4 wave kernels (lookup, Adam rows, flush) at
                # element offsets >= 2^31 and byte offsets >= 2^33
                ("uniform", torch.int64, 65536, False, 128, 12_500_000, 1_250_000)]
+NEUMF_CASES = [c + ("A",) for c in NEUMF_CASES] + [
+    # the other reference graph (src/models/NeuMFModel.py:53-100: user-first concat, relu tower dim -> dim/2 -> dim/4, MSE) at the benchmarked size
+    ("uniform", torch.int32, 65536, False, 64, M1, K1, "B")]
 
 
-@pytest.mark.parametrize("kind,idt,B,graph,dim,U,I", NEUMF_CASES)
-def test_neumf_steps_at_bench_size(dev, kind, idt, B, graph, dim, U, I):
+@pytest.mark.parametrize("kind,idt,B,graph,dim,U,I,variant", NEUMF_CASES)
+def test_neumf_steps_at_bench_size(dev, kind, idt, B, graph, dim, U, I, variant):
     neumf = _m("neumf")
-    case = f"neumf_{kind}_{'i64' if idt == torch.int64 else 'i32'}_b{B}_d{dim}{'_graph' if graph else ''}" + (f"_u{U}" if U != M1 else "") + (f"_i{I}" if I != K1 else "")
+    case = f"neumf_{kind}_{'i64' if idt == torch.int64 else 'i32'}_b{B}_d{dim}{'_graph' if graph else ''}" + (f"_u{U}" if U != M1 else "") + (f"_i{I}" if I != K1 else "") + ("" if variant == "A" else "_" + variant)
     D, steps = dim, 3
-    cfg = neumf.NeuMFConfig(variant="A", dim=D, optimizer="adam_dense", dense_impl="deferred", seed=0x1234ABCD5)
+    cfg = neumf.NeuMFConfig(variant=variant, dim=D, optimizer="adam_dense", dense_impl="deferred", seed=0x1234ABCD5)
     eng = neumf.NeuMFEngine(cfg, U, I, dev, B, id_dtype=idt, init_seed=1)
     rng = np.random.default_rng(17)
     # non-trivial biases / BatchNorm parameters / moving statistics
@@ -102,7 +105,7 @@ def test_neumf_steps_at_bench_size(dev, kind, idt, B, graph, dim, U, I):
         assert (min(int(x[-256:].min()) for x in us) * 2 * D) >= (1 << 31)
     ku, cu = _compact(us, U, rng)
     ki, ci = _compact(its, I, rng)
-    spec = O.NeuMFSpec("A", dim=D)
+    spec = O.NeuMFSpec(variant, dim=D)
     tku, tki = torch.from_numpy(ku).to(dev), torch.from_numpy(ki).to(dev)
     P = {k: eng.theta.view(k).cpu().numpy().astype(np.float64) for k in O.DENSE_ORDER}
     P["W4"] = P["W4"].reshape(-1)
@@ -123,7 +126,7 @@ def test_neumf_steps_at_bench_size(dev, kind, idt, B, graph, dim, U, I):
         masks = [O.dropout_mask(cfg.seed, t, s, B, w, cfg.dropout) for s, w in enumerate((2 * D, n1, n2))]
         loss, c, g, rg, ns = O.neumf_step_grads(spec, P, cu[t - 1], ci[t - 1], y, masks, dt=np.float64)
         if t == 1:     # G1/T1: the concat of the four gathered rows, bit for bit (no replay yet: every row is at step 0)
-            x0 = np.concatenate([P["item_mlp"][ci[0]], P["user_mlp"][cu[0]]], axis=1).astype(np.float32)
+            x0 = np.concatenate([P["item_mlp"][ci[0]], P["user_mlp"][cu[0]]] if cfg.item_first else [P["user_mlp"][cu[0]], P["item_mlp"][ci[0]]], axis=1).astype(np.float32)
             assert np.array_equal(eng.x0[:B].cpu().numpy().view(np.uint32), x0.view(np.uint32)), "x0 not bit-exact"
         # t = 1: both sides hold the same fp32 parameters -> the north_star bounds (1e-5 relative).  t >= 2: the fp32 parameters
         # have taken Adam steps whose m / (sqrt(v) + eps) amplifies the rounding of nearly cancelled gradients (bounded at the
