@@ -445,7 +445,13 @@ def main():
     # BR_BENCH_FORCE_SHARDED=1 (one-GPU box): the whole N > 1 path - RCCL process group, row-sharded engine, every collective really
     # issued - on a 1-rank group; a rehearsal of the multi-GPU code, its figure is not a bench line
     force_sharded = world == 1 and os.environ.get("BR_BENCH_FORCE_SHARDED") == "1"
+    json_out = sys.stdout
     if world > 1 or force_sharded:
+        # RCCL prints a version banner on file descriptor 1 when the communicator comes up: everything native goes to stderr, the ONE
+        # JSON line of the contract to the descriptor stdout had
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if force_sharded:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -912,7 +918,7 @@ def main():
             "eager": eager_profile, "graph_error": graph_error,
             "kernels": kernels,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), file=json_out, flush=True)
     if ctx is not None:
         sys.stdout.flush(); sys.stderr.flush()
         if sharded_graph is not None and sharded_graph.graph_active:
